@@ -1,0 +1,289 @@
+"""Generate tests/golden/*.npz from the reference's own source.  BUILD-CONTAINER ONLY.
+
+The reference (``/root/reference``, acoh64/pde-opt @ 2025-09-26) is pure Python on
+JAX; JAX/diffrax/equinox/gymnasium are not installed here (ordinary
+``ModuleNotFoundError`` -- nothing was refused).  Its array code only uses
+``jnp.roll/fft/exp/abs/stack/sum/sqrt/meshgrid/linspace/ones_like`` + arithmetic,
+whose numpy namesakes have identical semantics, so the reference *source files*
+are executed unmodified, loaded by path, with ``jax.numpy`` bound to ``numpy``
+(SURVEY.md Appendix B).  Nothing from the reference is copied into this repo:
+the files are read where they lie and only arrays (inputs + outputs) are saved.
+
+What this is NOT: a run of real JAX/XLA or of diffrax.  Time stepping loops
+(``diffrax.diffeqsolve``) are third-party and absent; goldens for trajectories
+call the reference's own ``solver.step`` bodies in a plain Python loop.
+
+Run:  python oracle/gen_golden.py          (no-op when /root/reference is absent)
+"""
+
+from __future__ import annotations
+
+import importlib.util
+import os
+import sys
+import types
+
+import numpy as np
+
+REF = "/root/reference"
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
+
+
+def _mod(name, **attrs):
+    m = types.ModuleType(name)
+    m.__dict__.update(attrs)
+    sys.modules[name] = m
+    return m
+
+
+def _pkg(name):
+    m = _mod(name)
+    m.__path__ = []
+    return m
+
+
+def _load(name, relpath):
+    spec = importlib.util.spec_from_file_location(name, os.path.join(REF, relpath))
+    m = importlib.util.module_from_spec(spec)
+    sys.modules[name] = m
+    spec.loader.exec_module(m)
+    return m
+
+
+def load_reference():
+    """Bind stand-ins for the absent third-party modules, then exec the reference files."""
+    jax = _mod("jax", numpy=np, jit=lambda f, **k: f, Array=np.ndarray)
+    sys.modules["jax.numpy"] = np
+    jax.numpy = np
+    _mod("equinox", Module=object, filter_jit=lambda f: f)
+
+    class _Results:
+        successful = 0
+
+    _mod(
+        "diffrax",
+        AbstractSolver=object,
+        ODETerm=object,
+        LocalLinearInterpolation=object,
+        RESULTS=_Results,
+    )
+    for p in (
+        "pde_opt",
+        "pde_opt.numerics",
+        "pde_opt.numerics.utils",
+        "pde_opt.numerics.equations",
+        "pde_opt.numerics.symbolic",
+    ):
+        _pkg(p)
+    _mod("pde_opt.numerics.shapes", Shape=object)
+
+    ns = types.SimpleNamespace()
+    ns.derivatives = _load(
+        "pde_opt.numerics.utils.derivatives", "pde_opt/numerics/utils/derivatives.py"
+    )
+    ns.domains = _load("pde_opt.numerics.domains", "pde_opt/numerics/domains.py")
+    _load("pde_opt.numerics.equations.base_eq", "pde_opt/numerics/equations/base_eq.py")
+    ns.ch = _load(
+        "pde_opt.numerics.equations.cahn_hilliard", "pde_opt/numerics/equations/cahn_hilliard.py"
+    )
+    ns.ac = _load(
+        "pde_opt.numerics.equations.allen_cahn", "pde_opt/numerics/equations/allen_cahn.py"
+    )
+    ns.gpe = _load(
+        "pde_opt.numerics.equations.gross_pitaevskii",
+        "pde_opt/numerics/equations/gross_pitaevskii.py",
+    )
+    _load("pde_opt.numerics.symbolic.base_sym_eq", "pde_opt/numerics/symbolic/base_sym_eq.py")
+    ns.ch_sym = _load(
+        "pde_opt.numerics.symbolic.cahn_hilliard_sym",
+        "pde_opt/numerics/symbolic/cahn_hilliard_sym.py",
+    )
+    ns.ac_sym = _load(
+        "pde_opt.numerics.symbolic.allen_cahn_sym", "pde_opt/numerics/symbolic/allen_cahn_sym.py"
+    )
+    ns.solvers = _load("pde_opt.numerics.solvers", "pde_opt/numerics/solvers.py")
+    return ns
+
+
+class _Terms:
+    def __init__(self, vf):
+        self._vf = vf
+
+    def vf(self, t, y, args):
+        return self._vf(t, y)
+
+
+def _make(cls, **fields):
+    obj = object.__new__(cls)
+    for k, v in fields.items():
+        setattr(obj, k, v)
+    return obj
+
+
+# closure families used across the goldens
+MU = {
+    "cubic": lambda c: c**3 - c,
+    "regsol": lambda c: np.log(c / (1 - c)) + 3 * (1 - 2 * c),
+}
+MOB = {
+    "one": lambda c: np.ones_like(c),
+    "c1mc": lambda c: c * (1 - c),
+    "one_plus_sq": lambda c: 1 + c**2,
+    "const015": lambda c: 0.15 * np.ones_like(c),
+}
+
+
+def main():
+    if not os.path.isdir(REF):
+        print("reference tree absent; nothing to do")
+        return
+    os.makedirs(OUT, exist_ok=True)
+    ref = load_reference()
+    Domain = ref.domains.Domain
+    rng = np.random.default_rng(20251003)
+
+    # ---- Domain meshes -----------------------------------------------------
+    d = Domain((8, 6), ((-1.0, 1.0), (0.0, 3.0)), "dimensionless")
+    ax = d.axes()
+    fx = d.fft_axes()
+    X, Y = d.mesh()
+    np.savez(
+        os.path.join(OUT, "domain_8x6.npz"),
+        ax0=ax[0], ax1=ax[1], f0=fx[0], f1=fx[1], X=X, Y=Y, dx=np.array(d.dx), L=np.array(d.L),
+    )
+
+    # ---- RHS goldens ---------------------------------------------------------
+    cases = {}
+    for (nx, ny) in ((32, 32), (64, 48), (128, 128), (256, 1), (2, 2), (1, 5), (3, 4)):
+        for dtype in (np.float64, np.float32):
+            lx, ly = 0.01 * nx, 0.01 * ny
+            dom = Domain((nx, ny), ((-lx / 2, lx / 2), (-ly / 2, ly / 2)), "dimensionless")
+            u_sym = (0.1 * rng.standard_normal((nx, ny))).astype(dtype)
+            u_c = np.clip(0.5 + 0.2 * rng.standard_normal((nx, ny)), 0.05, 0.95).astype(dtype)
+            tag = f"{nx}x{ny}_{np.dtype(dtype).name}"
+            kappa = 0.002
+            combos = (
+                ("cubic", "one", u_sym),
+                ("cubic", "one_plus_sq", u_sym),
+                ("regsol", "c1mc", u_c),
+                ("cubic", "const015", u_sym),
+            )
+            if nx * ny > 4096:  # keep the fixture file small: one combo at 128^2
+                combos = combos[2:3]
+            for mu_name, mob_name, u in combos:
+                eq = ref.ch.CahnHilliard2DPeriodic(dom, kappa, MU[mu_name], MOB[mob_name], derivs="fd")
+                cases[f"ch_fd/{mu_name}/{mob_name}/{tag}/u"] = u
+                cases[f"ch_fd/{mu_name}/{mob_name}/{tag}/rhs"] = np.asarray(eq.rhs(u, 0.0))
+                eq = ref.ac.AllenCahn2DPeriodic(dom, kappa, MU[mu_name], MOB[mob_name], derivs="fd")
+                cases[f"ac_fd/{mu_name}/{mob_name}/{tag}/u"] = u
+                cases[f"ac_fd/{mu_name}/{mob_name}/{tag}/rhs"] = np.asarray(eq.rhs(u, 0.0))
+            if dtype is np.float64 and 1024 <= nx * ny <= 4096:
+                # spectral constants are f64 in numpy but f32 in JAX-without-x64:
+                # spectral goldens only in fp64
+                eq = ref.ch.CahnHilliard2DPeriodic(dom, kappa, MU["regsol"], MOB["c1mc"], derivs="fourier")
+                cases[f"ch_fourier/regsol/c1mc/{tag}/u"] = u_c
+                cases[f"ch_fourier/regsol/c1mc/{tag}/rhs"] = np.asarray(eq.rhs(u_c, 0.0))
+                cases[f"ch_fourier/regsol/c1mc/{tag}/symbol"] = np.asarray(eq.fourier_symbol)
+                eq = ref.ac.AllenCahn2DPeriodic(dom, kappa, MU["cubic"], MOB["one_plus_sq"], derivs="fourier")
+                cases[f"ac_fourier/cubic/one_plus_sq/{tag}/u"] = u_sym
+                cases[f"ac_fourier/cubic/one_plus_sq/{tag}/rhs"] = np.asarray(eq.rhs(u_sym, 0.0))
+    np.savez_compressed(os.path.join(OUT, "rhs_cases.npz"), **cases)
+
+    # ---- manufactured solution (tests/test_rhs_convergence.py) ---------------
+    import sympy as sp
+
+    x, y, t = sp.symbols("x y t", real=True)
+    u_star = sp.sin(2 * x) * sp.cos(3 * y) * sp.exp(-0.7 * t)
+    man = {}
+    L = 2 * np.pi
+    for n in (32, 64):
+        dom = Domain((n, n), ((-L / 2, L / 2), (-L / 2, L / 2)), "dimensionless")
+        s = ref.ch_sym.SymbolicCahnHilliard2DPeriodic(
+            dom, 1e-2, lambda u: u**3 - u, lambda u: 1 + u**2, u_star
+        )
+        man[f"ch/{n}/u"] = np.asarray(s.u_exact(0))
+        man[f"ch/{n}/rhs_exact"] = np.asarray(s.rhs_exact(0))
+        eq = ref.ch.CahnHilliard2DPeriodic(dom, 1e-2, lambda u: u**3 - u, lambda u: 1 + u**2)
+        man[f"ch/{n}/rhs_fd"] = np.asarray(eq.rhs(man[f"ch/{n}/u"], 0))
+        s = ref.ac_sym.SymbolicAllenCahn2DPeriodic(
+            dom, 1e-2, lambda u: u**3 - u, lambda u: 1 + u**2, u_star
+        )
+        man[f"ac/{n}/rhs_exact"] = np.asarray(s.rhs_exact(0))
+        eq = ref.ac.AllenCahn2DPeriodic(dom, 1e-2, lambda u: u**3 - u, lambda u: 1 + u**2)
+        man[f"ac/{n}/rhs_fd"] = np.asarray(eq.rhs(man[f"ch/{n}/u"], 0))
+    np.savez_compressed(os.path.join(OUT, "manufactured.npz"), **man)
+
+    # ---- IMEX trajectory: reference solver.step looped ------------------------
+    traj = {}
+    nx = ny = 64
+    dom = Domain((nx, ny), ((-0.32, 0.32), (-0.32, 0.32)), "dimensionless")
+    eq = ref.ch.CahnHilliard2DPeriodic(dom, 0.002, MU["regsol"], MOB["c1mc"], derivs="fd")
+    solver = _make(
+        ref.solvers.SemiImplicitFourierSpectral,
+        A=0.5, fourier_symbol=eq.fourier_symbol, fft=eq.fft, ifft=eq.ifft,
+    )
+    y = np.clip(0.5 + 0.01 * rng.standard_normal((nx, ny)), 0.05, 0.95)
+    traj["imex/y0"] = y
+    terms = _Terms(lambda t, yy: eq.rhs(yy, t))
+    dt = 1e-6
+    seq = []
+    for i in range(10):
+        y = solver.step(terms, i * dt, (i + 1) * dt, y, None, None, False)[0]
+        seq.append(np.asarray(y))
+    traj["imex/ys"] = np.stack(seq)
+    traj["imex/dt"] = np.array(dt)
+
+    # 1-D style (256 x 1) IMEX, the tests/test_solvers.py:21-61 set-up, 200 steps
+    nx, ny = 256, 1
+    dom = Domain((nx, ny), ((-1.28, 1.28), (-0.005, 0.005)), "dimensionless")
+    eq = ref.ch.CahnHilliard2DPeriodic(dom, 0.002, MU["cubic"], MOB["one"], derivs="fd")
+    solver = _make(
+        ref.solvers.SemiImplicitFourierSpectral,
+        A=0.5, fourier_symbol=eq.fourier_symbol, fft=eq.fft, ifft=eq.ifft,
+    )
+    y = np.ones((nx, ny))
+    y[: nx // 2, :] = -1.0
+    traj["imex1d/y0"] = y
+    terms = _Terms(lambda t, yy: eq.rhs(yy, t))
+    dt = 5e-5
+    for i in range(200):
+        y = solver.step(terms, i * dt, (i + 1) * dt, y, None, None, False)[0]
+    traj["imex1d/y200"] = np.asarray(y)
+
+    # ---- Strang trajectory (GPE), both the committed A_term == 0 and a real one --
+    n = 48
+    dom = Domain((n, n), ((-12.0, 12.0), (-12.0, 12.0)), "dimensionless")
+    geq = ref.gpe.GPE2DTSControl(dom, 1000.0, 0.1, lambda tt, xx, yy: 0.05 * xx, trap_factor=1.0)
+    Xm, Ym = dom.mesh()
+    psi0 = np.exp(-(Xm**2 + Ym**2) / (2 * 4.0**2)) * np.exp(0.3j * Xm)
+    psi0 = psi0 / np.sqrt(np.sum(np.abs(psi0) ** 2) * dom.dx[0] ** 2)
+    y0 = np.stack([psi0.real, psi0.imag], axis=-1)
+    traj["strang/y0"] = y0
+    a_real = 0.5j * geq.two_pi_i_k_2
+    for name, a_term, tscale in (
+        ("zeroA_imag", geq.A_term, -1j),
+        ("realA_real", a_real, 1.0),
+        ("realA_imag", a_real, -1j),
+    ):
+        solver = _make(
+            ref.solvers.StrangSplitting,
+            A_term=a_term, dx=geq.dx, fft=geq.fft, ifft=geq.ifft, time_scale=tscale,
+        )
+        terms = _Terms(lambda t, yy: geq.B_terms(yy, t))
+        y = y0
+        seq = []
+        dt = 1e-3
+        for i in range(5):
+            y = solver.step(terms, i * dt, (i + 1) * dt, y, None, None, False)[0]
+            seq.append(np.asarray(y))
+        traj[f"strang/{name}/ys"] = np.stack(seq)
+    traj["strang/b_terms"] = np.asarray(geq.B_terms(y0, 0.0))
+    traj["strang/A_real"] = a_real
+    np.savez_compressed(os.path.join(OUT, "trajectories.npz"), **traj)
+    print("wrote goldens to", os.path.abspath(OUT))
+    for f in sorted(os.listdir(OUT)):
+        print("  ", f, os.path.getsize(os.path.join(OUT, f)))
+
+
+if __name__ == "__main__":
+    main()
