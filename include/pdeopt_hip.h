@@ -1,0 +1,182 @@
+/*
+ * pdeopt_hip.h -- C ABI of libpdeopt_hip.so, the MI355X (gfx950) hot path of pde_opt.
+ *
+ * The reference (acoh64/pde-opt @ 2025-09-26) has no FFI: its "plugin boundary" is the
+ * Python class surface.  The hot path it runs per environment step is
+ *
+ *     PDEEnv.step            pde_opt/pde_env.py:244-317      (diffeqsolve at :293-303)
+ *     PDEModel.solve         pde_opt/pde_model.py:68-136     (diffeqsolve at :120-134)
+ *       -> solver.step       pde_opt/numerics/solvers.py:56-70, :99-122 (+ diffrax Euler/ERK)
+ *         -> equation.rhs    pde_opt/numerics/equations/{cahn_hilliard,allen_cahn,gross_pitaevskii}.py
+ *           -> FD stencils   pde_opt/numerics/utils/derivatives.py:8-61, jnp.fft
+ *
+ * Everything below "diffeqsolve(...)" is replaced by the entry points declared here; the
+ * Python shims in pde_opt_amd/ (same class names and signatures as the reference) call
+ * them through ctypes.  Plain pointers and sizes only; no torch types.
+ *
+ * Conventions
+ *   - every call returns a pdeopt_status (0 = ok); pdeopt_last_error() gives the text.
+ *   - caller owns host memory; the library owns device memory (hipMalloc on the ctx device).
+ *   - one ctx per (thread, device); calls on a ctx are ordered on the ctx's HIP stream and are
+ *     not re-entrant.  pdeopt_advance / pdeopt_rhs are asynchronous; get_state / reduce /
+ *     sync / timer_stop synchronise.
+ *   - fields are C-order [batch][nx][ny] (axis 1 contiguous), exactly the reference's
+ *     (Nx, Ny) arrays stacked over a leading batch axis; the GPE state is [batch][nx][ny][2]
+ *     (re, im interleaved == the reference's (N, N, 2) layout, gross_pitaevskii.py:75).
+ */
+#ifndef PDEOPT_HIP_H
+#define PDEOPT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pdeopt_ctx pdeopt_ctx;
+
+typedef enum {
+  PDEOPT_OK = 0,
+  PDEOPT_EINVAL = 1,       /* bad argument / unsupported combination (reference: ValueError) */
+  PDEOPT_EHIP = 2,         /* HIP runtime error */
+  PDEOPT_EFFT = 3,         /* rocFFT error */
+  PDEOPT_ENONFINITE = 4,   /* reported by pdeopt_reduce(op = NONFINITE) callers */
+  PDEOPT_ENOMEM = 5,
+  PDEOPT_ESTATE = 6        /* call order error (e.g. advance before configure) */
+} pdeopt_status;
+
+typedef enum { PDEOPT_F32 = 0, PDEOPT_F64 = 1 } pdeopt_dtype;
+
+/* which equation.rhs() the stencil kernel evaluates */
+typedef enum {
+  PDEOPT_EQ_CAHN_HILLIARD = 0,   /* cahn_hilliard.py:89-109  div(D(u) grad(mu_h(u) - kappa lap u)) */
+  PDEOPT_EQ_ALLEN_CAHN = 1,      /* allen_cahn.py:81-84      -R(u) (mu_h(u) - kappa lap u)          */
+  PDEOPT_EQ_ADVECTION_DIFFUSION = 2, /* not in the reference package: -div(v u) + D lap u */
+  PDEOPT_EQ_GPE = 3              /* gross_pitaevskii.py:67-75 (Strang only)                         */
+} pdeopt_equation;
+
+/* which solver.step() is fused around it */
+typedef enum {
+  PDEOPT_INT_EULER = 0,   /* diffrax.Euler  (pde_env.py:293-303 call site)                 */
+  PDEOPT_INT_RK4 = 1,     /* classical RK4 (new; BASELINE.json configs 2,3,5)              */
+  PDEOPT_INT_IMEX = 2,    /* SemiImplicitFourierSpectral.step   numerics/solvers.py:56-70  */
+  PDEOPT_INT_STRANG = 3,  /* StrangSplitting.step               numerics/solvers.py:99-122 */
+  PDEOPT_INT_TSIT5 = 4    /* diffrax.Tsit5 fixed step (adaptive PID driven from the host)  */
+} pdeopt_integrator;
+
+/* Pointwise closure family standing in for the reference's Python callables mu(u), D(u), R(u)
+ * (dataclass fields cahn_hilliard.py:51-54, allen_cahn.py:47-50; catalogue: SURVEY Appendix D).
+ *     s(c)  = sum_k coef[k] * c^k                      (kind POLY)
+ *           = sum_k coef[k] * P_k(2c - 1)              (kind LEGENDRE, legendre.py:23-34,50,70)
+ *     f(c)  = s(c) [+ log(c / (1 - c)) if LOGIT_PRIOR]   then  exp(.) if EXP_WRAP            */
+#define PDEOPT_CLOSURE_MAX_COEF 16
+typedef enum { PDEOPT_CL_POLY = 0, PDEOPT_CL_LEGENDRE = 1 } pdeopt_closure_kind;
+#define PDEOPT_CL_LOGIT_PRIOR 1
+#define PDEOPT_CL_EXP_WRAP 2
+
+typedef struct {
+  int32_t kind;   /* pdeopt_closure_kind */
+  int32_t flags;  /* PDEOPT_CL_* bits */
+  int32_t n;      /* number of coefficients, 1..PDEOPT_CLOSURE_MAX_COEF */
+  int32_t reserved;
+  double coef[PDEOPT_CLOSURE_MAX_COEF];
+} pdeopt_closure;
+
+typedef struct {
+  int32_t equation;   /* pdeopt_equation */
+  int32_t dtype;      /* pdeopt_dtype: arithmetic type of the whole path */
+  int32_t nx, ny;     /* Domain.points (domains.py:24) */
+  int32_t batch;      /* independent environments advanced in lock step (new; >= 1) */
+  int32_t reserved;
+  double hx, hy;      /* Domain.dx (domains.py:30-33) */
+  double kappa;       /* gradient-energy coefficient (CH/AC); diffusion coefficient D (AD) */
+  pdeopt_closure mu;  /* mu_h (CH/AC) */
+  pdeopt_closure mob; /* D (CH) or R (AC) */
+  /* GPE (gross_pitaevskii.py:35-44): b = -i (V + k |psi|^2); V is an auxiliary field */
+  double gpe_k;
+} pdeopt_problem;
+
+/* auxiliary read-only fields (pdeopt_set_aux) */
+typedef enum {
+  PDEOPT_AUX_VX_FACE = 0,    /* AD: x velocity on faces (i+1/2, j), real [nx][ny]                    */
+  PDEOPT_AUX_VY_FACE = 1,    /* AD: y velocity on faces (i, j+1/2), real [nx][ny]                    */
+  PDEOPT_AUX_IMEX_SYMBOL = 2,/* IMEX: fourier_symbol, complex [nx][ny] (cahn_hilliard.py:74)         */
+  PDEOPT_AUX_GPE_A_TERM = 3, /* Strang: A_term, complex [nx][ny] (gross_pitaevskii.py:62)            */
+  PDEOPT_AUX_GPE_POTENTIAL = 4 /* Strang: V = 1/2 tf((1+e)X^2+(1-e)Y^2) + lights(t,X,Y), real [nx][ny] */
+} pdeopt_aux;
+
+typedef enum {
+  PDEOPT_RED_MEAN = 0,
+  PDEOPT_RED_VAR = 1,       /* population variance == np.var (notebooks/test_pde_env.ipynb:57) */
+  PDEOPT_RED_MIN = 2,
+  PDEOPT_RED_MAX = 3,
+  PDEOPT_RED_SUMSQ = 4,     /* sum |.|^2 (GPE norm without the dx^2 factor) */
+  PDEOPT_RED_NONFINITE = 5  /* count of NaN/Inf cells */
+} pdeopt_reduce_op;
+
+/* kernel-selection knobs (pdeopt_set_option) */
+typedef enum {
+  PDEOPT_OPT_KERNEL_PATH = 0  /* 0 = auto, 1 = force the generic (untiled) kernels, 2 = force LDS-tiled */
+} pdeopt_option;
+
+/* ---- life cycle ------------------------------------------------------------------------- */
+int pdeopt_abi_version(void);
+int pdeopt_device_count(int* count);
+int pdeopt_ctx_create(int device, pdeopt_ctx** out);
+int pdeopt_ctx_destroy(pdeopt_ctx* ctx);
+const char* pdeopt_last_error(const pdeopt_ctx* ctx); /* ctx may be NULL: last create() error */
+int pdeopt_set_option(pdeopt_ctx* ctx, int option, int64_t value);
+
+/* ---- problem set-up == equation_type(domain=..., **parameters)  (pde_env.py:286) -------- */
+int pdeopt_configure(pdeopt_ctx* ctx, const pdeopt_problem* problem);
+/* per-environment overrides of kappa and closure coefficients (control parameters travel with
+ * the environment).  Any pointer may be NULL (= leave unchanged).  mu_coef / mob_coef are
+ * [env_count][PDEOPT_CLOSURE_MAX_COEF]. */
+int pdeopt_set_env_params(pdeopt_ctx* ctx, int env_first, int env_count, const double* kappa,
+                          const double* mu_coef, const double* mob_coef);
+/* shared (per_env = 0: [nx][ny]) or per-environment (per_env = 1: [batch][nx][ny]) auxiliary
+ * field, host pointer, element type = problem dtype (complex = 2 elements). */
+int pdeopt_set_aux(pdeopt_ctx* ctx, int which, const void* host, int per_env);
+
+/* ---- state  == PDEEnv._state (pde_env.py:232,305) ---------------------------------------- */
+int pdeopt_set_state(pdeopt_ctx* ctx, int env_first, int env_count, const void* host);
+int pdeopt_get_state(pdeopt_ctx* ctx, int env_first, int env_count, void* host);
+/* device pointer of the current state (valid until the next advance); for zero-copy consumers */
+int pdeopt_state_device_ptr(pdeopt_ctx* ctx, void** dev_ptr, int64_t* bytes);
+
+/* ---- compute ------------------------------------------------------------------------------ */
+/* out = equation.rhs(state, t) for every environment; host_out may be NULL (compute only). */
+int pdeopt_rhs(pdeopt_ctx* ctx, double t, void* host_out);
+/* n_substeps of size dt starting at local time t0:  the body of diffeqsolve's while-loop
+ * under ConstantStepSize.  Asynchronous. */
+int pdeopt_advance(pdeopt_ctx* ctx, int integrator, double t0, double dt, int64_t n_substeps);
+/* integrator parameters: IMEX A (solvers.py:43); Strang time_scale re/im and dx (solvers.py:86-89) */
+int pdeopt_set_integrator_params(pdeopt_ctx* ctx, double imex_A, double time_scale_re,
+                                 double time_scale_im, double strang_dx);
+/* snapshot <- state ;   host_out <- snapshot + theta (state - snapshot): LocalLinearInterpolation
+ * dense output for SaveAt(ts=...) (solvers.py:48,91; pde_model.py:128) */
+int pdeopt_snapshot(pdeopt_ctx* ctx);
+int pdeopt_get_interpolated(pdeopt_ctx* ctx, double theta, int env_first, int env_count,
+                            void* host_out);
+/* per-environment reductions of the state (reward helpers); out is [batch] doubles. */
+int pdeopt_reduce(pdeopt_ctx* ctx, int op, double* out_per_env);
+
+/* ---- Tsit5 building blocks for host-driven adaptive stepping (row f1) ----------------------- */
+/* one trial step of size dt from the current state: on return err_norm[batch] holds the
+ * diffrax-style scaled RMS error norm per environment (atol + rtol max(|y0|,|y1|)).  The trial
+ * result is kept pending until pdeopt_tsit5_commit(accept). */
+int pdeopt_tsit5_trial(pdeopt_ctx* ctx, double t, double dt, double rtol, double atol,
+                       double* err_norm);
+int pdeopt_tsit5_commit(pdeopt_ctx* ctx, int accept);
+
+/* ---- timing / sync ------------------------------------------------------------------------- */
+int pdeopt_sync(pdeopt_ctx* ctx);
+int pdeopt_timer_start(pdeopt_ctx* ctx);           /* hipEventRecord on the ctx stream */
+int pdeopt_timer_stop(pdeopt_ctx* ctx, double* ms); /* record + synchronise + elapsed */
+/* name of the kernel variant the last advance/rhs dispatched (for tests and profiles) */
+const char* pdeopt_last_kernel(const pdeopt_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PDEOPT_HIP_H */

@@ -1,0 +1,141 @@
+"""ctypes binding of libpdeopt_hip.so (the C ABI declared in include/pdeopt_hip.h).
+
+There is NO CPU fallback: if the shared library is missing or no HIP device is present the
+constructors below raise ``HipUnavailableError``.  Build the library with
+``python -m pde_opt_amd.csrc.build`` (or ``__graft_entry__.build()``).
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpdeopt_hip.so")
+
+MAX_COEF = 16
+
+# enums (mirror include/pdeopt_hip.h)
+OK, EINVAL, EHIP, EFFT, ENONFINITE, ENOMEM, ESTATE = range(7)
+F32, F64 = 0, 1
+EQ_CAHN_HILLIARD, EQ_ALLEN_CAHN, EQ_ADVECTION_DIFFUSION, EQ_GPE = 0, 1, 2, 3
+INT_EULER, INT_RK4, INT_IMEX, INT_STRANG, INT_TSIT5 = 0, 1, 2, 3, 4
+CL_POLY, CL_LEGENDRE = 0, 1
+CL_LOGIT_PRIOR, CL_EXP_WRAP = 1, 2
+AUX_VX_FACE, AUX_VY_FACE, AUX_IMEX_SYMBOL, AUX_GPE_A_TERM, AUX_GPE_POTENTIAL = 0, 1, 2, 3, 4
+RED_MEAN, RED_VAR, RED_MIN, RED_MAX, RED_SUMSQ, RED_NONFINITE = 0, 1, 2, 3, 4, 5
+OPT_KERNEL_PATH = 0
+PATH_AUTO, PATH_GENERIC, PATH_TILED = 0, 1, 2
+
+
+class HipUnavailableError(RuntimeError):
+    """The HIP library or a GPU is missing; the product path has no CPU fallback."""
+
+
+class PdeoptError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"pdeopt status {code}: {msg}")
+        self.code = code
+
+
+class Closure(C.Structure):
+    _fields_ = [
+        ("kind", C.c_int32),
+        ("flags", C.c_int32),
+        ("n", C.c_int32),
+        ("reserved", C.c_int32),
+        ("coef", C.c_double * MAX_COEF),
+    ]
+
+
+class Problem(C.Structure):
+    _fields_ = [
+        ("equation", C.c_int32),
+        ("dtype", C.c_int32),
+        ("nx", C.c_int32),
+        ("ny", C.c_int32),
+        ("batch", C.c_int32),
+        ("reserved", C.c_int32),
+        ("hx", C.c_double),
+        ("hy", C.c_double),
+        ("kappa", C.c_double),
+        ("mu", Closure),
+        ("mob", Closure),
+        ("gpe_k", C.c_double),
+    ]
+
+
+# every symbol include/pdeopt_hip.h declares: name -> (restype, argtypes)
+_VP = C.c_void_p
+_SIGNATURES = {
+    "pdeopt_abi_version": (C.c_int, []),
+    "pdeopt_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "pdeopt_ctx_create": (C.c_int, [C.c_int, C.POINTER(_VP)]),
+    "pdeopt_ctx_destroy": (C.c_int, [_VP]),
+    "pdeopt_last_error": (C.c_char_p, [_VP]),
+    "pdeopt_set_option": (C.c_int, [_VP, C.c_int, C.c_int64]),
+    "pdeopt_configure": (C.c_int, [_VP, C.POINTER(Problem)]),
+    "pdeopt_set_env_params": (C.c_int, [_VP, C.c_int, C.c_int, _VP, _VP, _VP]),
+    "pdeopt_set_aux": (C.c_int, [_VP, C.c_int, _VP, C.c_int]),
+    "pdeopt_set_state": (C.c_int, [_VP, C.c_int, C.c_int, _VP]),
+    "pdeopt_get_state": (C.c_int, [_VP, C.c_int, C.c_int, _VP]),
+    "pdeopt_state_device_ptr": (C.c_int, [_VP, C.POINTER(_VP), C.POINTER(C.c_int64)]),
+    "pdeopt_rhs": (C.c_int, [_VP, C.c_double, _VP]),
+    "pdeopt_advance": (C.c_int, [_VP, C.c_int, C.c_double, C.c_double, C.c_int64]),
+    "pdeopt_set_integrator_params": (C.c_int, [_VP, C.c_double, C.c_double, C.c_double, C.c_double]),
+    "pdeopt_snapshot": (C.c_int, [_VP]),
+    "pdeopt_get_interpolated": (C.c_int, [_VP, C.c_double, C.c_int, C.c_int, _VP]),
+    "pdeopt_reduce": (C.c_int, [_VP, C.c_int, _VP]),
+    "pdeopt_tsit5_trial": (C.c_int, [_VP, C.c_double, C.c_double, C.c_double, C.c_double, _VP]),
+    "pdeopt_tsit5_commit": (C.c_int, [_VP, C.c_int]),
+    "pdeopt_sync": (C.c_int, [_VP]),
+    "pdeopt_timer_start": (C.c_int, [_VP]),
+    "pdeopt_timer_stop": (C.c_int, [_VP, C.POINTER(C.c_double)]),
+    "pdeopt_last_kernel": (C.c_char_p, [_VP]),
+}
+
+_lib = None
+
+
+def load_library():
+    """dlopen libpdeopt_hip.so and bind every declared symbol; raises if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipUnavailableError(
+            f"{LIB_PATH} not found. pde_opt_amd has no CPU fallback: build the HIP library with "
+            "`python -m pde_opt_amd.csrc.build` (needs hipcc, targets gfx950)."
+        )
+    try:
+        lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    except OSError as e:  # missing ROCm runtime etc.
+        raise HipUnavailableError(f"cannot load {LIB_PATH}: {e}") from e
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError = ABI mismatch: let it propagate
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def device_count() -> int:
+    lib = load_library()
+    n = C.c_int(0)
+    lib.pdeopt_device_count(C.byref(n))
+    return n.value
+
+
+def np_dtype(code: int):
+    return np.float32 if code == F32 else np.float64
+
+
+def dtype_code(dt) -> int:
+    dt = np.dtype(dt)
+    if dt == np.float32:
+        return F32
+    if dt == np.float64:
+        return F64
+    raise ValueError(f"unsupported dtype {dt}; the HIP path computes in float32 or float64")

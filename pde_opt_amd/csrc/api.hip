@@ -1,0 +1,434 @@
+// extern "C" entry points of libpdeopt_hip.so (declared in include/pdeopt_hip.h).
+#include <cstdarg>
+#include <cstring>
+#include <mutex>
+
+#include "closures.hpp"
+#include "common.hpp"
+
+namespace pdeopt {
+
+static std::string g_create_error;
+
+int fail(pdeopt_ctx* ctx, int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  if (ctx)
+    ctx->err = buf;
+  else
+    g_create_error = buf;
+  return code;
+}
+
+int ensure_buffer(pdeopt_ctx* ctx, void** p, size_t bytes) {
+  if (*p) return PDEOPT_OK;
+  hipError_t e = hipMalloc(p, bytes);
+  if (e != hipSuccess) {
+    *p = nullptr;
+    return fail(ctx, PDEOPT_ENOMEM, "hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
+  }
+  return PDEOPT_OK;
+}
+
+namespace {
+
+void free_fields(pdeopt_ctx* ctx) {
+  void** bufs[] = {&ctx->Y, &ctx->TA, &ctx->TB, &ctx->ACC, &ctx->SNAP, &ctx->env_params_dev};
+  for (void** b : bufs) {
+    if (*b) (void)hipFree(*b);
+    *b = nullptr;
+  }
+  for (auto& k : ctx->K) {
+    if (k) (void)hipFree(k);
+    k = nullptr;
+  }
+  for (auto& a : ctx->aux) {
+    if (a.dev) (void)hipFree(a.dev);
+    a = AuxField{};
+  }
+  spectral_destroy(ctx);
+  ctx->tsit5_pending = false;
+  ctx->tsit5_fsal_valid = false;
+  ctx->configured = false;
+}
+
+int check_closure(pdeopt_ctx* ctx, const pdeopt_closure& c, const char* name) {
+  if (c.kind != PDEOPT_CL_POLY && c.kind != PDEOPT_CL_LEGENDRE)
+    return fail(ctx, PDEOPT_EINVAL, "closure %s: unknown kind %d", name, c.kind);
+  if (c.n < 1 || c.n > kMaxCoef)
+    return fail(ctx, PDEOPT_EINVAL, "closure %s: n=%d outside 1..%d", name, c.n, kMaxCoef);
+  if (c.flags & ~(PDEOPT_CL_LOGIT_PRIOR | PDEOPT_CL_EXP_WRAP))
+    return fail(ctx, PDEOPT_EINVAL, "closure %s: unknown flags 0x%x", name, c.flags);
+  return PDEOPT_OK;
+}
+
+template <typename T>
+void fill_env_params(pdeopt_ctx* ctx) {
+  const pdeopt_problem& p = ctx->prob;
+  ctx->env_params_host.assign(sizeof(EnvParams<T>) * (size_t)p.batch, 0);
+  auto* e = reinterpret_cast<EnvParams<T>*>(ctx->env_params_host.data());
+  for (int b = 0; b < p.batch; ++b) {
+    e[b].kappa = T(p.kappa);
+    e[b].gpe_k = T(p.gpe_k);
+    for (int k = 0; k < kMaxCoef; ++k) {
+      e[b].mu[k] = k < p.mu.n ? T(p.mu.coef[k]) : T(0);
+      e[b].mob[k] = k < p.mob.n ? T(p.mob.coef[k]) : T(0);
+    }
+  }
+}
+
+template <typename T>
+void patch_env_params(pdeopt_ctx* ctx, int first, int count, const double* kappa, const double* mu,
+                      const double* mob) {
+  auto* e = reinterpret_cast<EnvParams<T>*>(ctx->env_params_host.data());
+  for (int i = 0; i < count; ++i) {
+    EnvParams<T>& d = e[first + i];
+    if (kappa) d.kappa = T(kappa[i]);
+    for (int k = 0; k < kMaxCoef; ++k) {
+      if (mu) d.mu[k] = k < ctx->prob.mu.n ? T(mu[(size_t)i * kMaxCoef + k]) : T(0);
+      if (mob) d.mob[k] = k < ctx->prob.mob.n ? T(mob[(size_t)i * kMaxCoef + k]) : T(0);
+    }
+  }
+}
+
+int upload_env_params(pdeopt_ctx* ctx) {
+  PDEOPT_HIP_CHECK(ctx, hipMemcpyAsync(ctx->env_params_dev, ctx->env_params_host.data(),
+                                       ctx->env_params_host.size(), hipMemcpyHostToDevice,
+                                       ctx->stream));
+  // the host vector may be edited right after this call returns
+  PDEOPT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return PDEOPT_OK;
+}
+
+int check_envs(pdeopt_ctx* ctx, int first, int count) {
+  if (!ctx->configured) return fail(ctx, PDEOPT_ESTATE, "pdeopt_configure has not been called");
+  if (first < 0 || count < 0 || (int64_t)first + count > ctx->prob.batch)
+    return fail(ctx, PDEOPT_EINVAL, "environment range [%d, %d) outside batch %d", first,
+                first + count, ctx->prob.batch);
+  return PDEOPT_OK;
+}
+
+}  // namespace
+}  // namespace pdeopt
+
+using namespace pdeopt;
+
+extern "C" {
+
+int pdeopt_abi_version(void) { return 1; }
+
+int pdeopt_device_count(int* count) {
+  if (!count) return PDEOPT_EINVAL;
+  hipError_t e = hipGetDeviceCount(count);
+  if (e != hipSuccess) {
+    *count = 0;
+    return fail(nullptr, PDEOPT_EHIP, "hipGetDeviceCount: %s", hipGetErrorString(e));
+  }
+  return PDEOPT_OK;
+}
+
+int pdeopt_ctx_create(int device, pdeopt_ctx** out) {
+  if (!out) return fail(nullptr, PDEOPT_EINVAL, "out is NULL");
+  *out = nullptr;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0)
+    return fail(nullptr, PDEOPT_EHIP, "no HIP device available (%s)", hipGetErrorString(e));
+  if (device < 0 || device >= n)
+    return fail(nullptr, PDEOPT_EINVAL, "device %d outside 0..%d", device, n - 1);
+  e = hipSetDevice(device);
+  if (e != hipSuccess) return fail(nullptr, PDEOPT_EHIP, "hipSetDevice: %s", hipGetErrorString(e));
+  auto* ctx = new pdeopt_ctx();
+  ctx->device = device;
+  if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess ||
+      (e = hipEventCreate(&ctx->ev0)) != hipSuccess || (e = hipEventCreate(&ctx->ev1)) != hipSuccess) {
+    fail(nullptr, PDEOPT_EHIP, "stream/event creation: %s", hipGetErrorString(e));
+    delete ctx;
+    return PDEOPT_EHIP;
+  }
+  *out = ctx;
+  return PDEOPT_OK;
+}
+
+int pdeopt_ctx_destroy(pdeopt_ctx* ctx) {
+  if (!ctx) return PDEOPT_OK;
+  (void)hipSetDevice(ctx->device);
+  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  free_fields(ctx);
+  if (ctx->red_dev) (void)hipFree(ctx->red_dev);
+  if (ctx->red_mean_dev) (void)hipFree(ctx->red_mean_dev);
+  if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+  if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+  return PDEOPT_OK;
+}
+
+const char* pdeopt_last_error(const pdeopt_ctx* ctx) {
+  return ctx ? ctx->err.c_str() : g_create_error.c_str();
+}
+
+const char* pdeopt_last_kernel(const pdeopt_ctx* ctx) { return ctx ? ctx->last_kernel.c_str() : ""; }
+
+int pdeopt_set_option(pdeopt_ctx* ctx, int option, int64_t value) {
+  if (!ctx) return PDEOPT_EINVAL;
+  switch (option) {
+    case PDEOPT_OPT_KERNEL_PATH:
+      if (value < 0 || value > 2) return fail(ctx, PDEOPT_EINVAL, "kernel path %lld", (long long)value);
+      ctx->opt_kernel_path = value;
+      return PDEOPT_OK;
+    default:
+      return fail(ctx, PDEOPT_EINVAL, "unknown option %d", option);
+  }
+}
+
+int pdeopt_configure(pdeopt_ctx* ctx, const pdeopt_problem* pr) {
+  if (!ctx || !pr) return PDEOPT_EINVAL;
+  PDEOPT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  PDEOPT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  free_fields(ctx);
+  if (pr->dtype != PDEOPT_F32 && pr->dtype != PDEOPT_F64)
+    return fail(ctx, PDEOPT_EINVAL, "unknown dtype %d", pr->dtype);
+  if (pr->equation < PDEOPT_EQ_CAHN_HILLIARD || pr->equation > PDEOPT_EQ_GPE)
+    return fail(ctx, PDEOPT_EINVAL, "unknown equation %d", pr->equation);
+  if (pr->nx < 1 || pr->ny < 1 || pr->batch < 1)
+    return fail(ctx, PDEOPT_EINVAL, "bad extents nx=%d ny=%d batch=%d", pr->nx, pr->ny, pr->batch);
+  if (!(pr->hx > 0) || !(pr->hy > 0)) return fail(ctx, PDEOPT_EINVAL, "grid spacing must be > 0");
+  if (pr->equation == PDEOPT_EQ_CAHN_HILLIARD || pr->equation == PDEOPT_EQ_ALLEN_CAHN) {
+    int rc;
+    if ((rc = check_closure(ctx, pr->mu, "mu"))) return rc;
+    if ((rc = check_closure(ctx, pr->mob, "mob"))) return rc;
+  }
+  ctx->prob = *pr;
+  if (ctx->prob.mu.n < 1) ctx->prob.mu.n = 1;
+  if (ctx->prob.mob.n < 1) ctx->prob.mob.n = 1;
+  ctx->esize = pr->dtype == PDEOPT_F32 ? 4 : 8;
+  ctx->comps = pr->equation == PDEOPT_EQ_GPE ? 2 : 1;
+  ctx->env_elems = (size_t)pr->nx * pr->ny * ctx->comps;
+  ctx->total_bytes = ctx->env_elems * pr->batch * ctx->esize;
+  int rc;
+  if ((rc = ensure_buffer(ctx, &ctx->Y, ctx->total_bytes))) return rc;
+  PDEOPT_HIP_CHECK(ctx, hipMemsetAsync(ctx->Y, 0, ctx->total_bytes, ctx->stream));
+  if (pr->dtype == PDEOPT_F32)
+    fill_env_params<float>(ctx);
+  else
+    fill_env_params<double>(ctx);
+  if ((rc = ensure_buffer(ctx, &ctx->env_params_dev, ctx->env_params_host.size()))) return rc;
+  ctx->configured = true;
+  return upload_env_params(ctx);
+}
+
+int pdeopt_set_env_params(pdeopt_ctx* ctx, int env_first, int env_count, const double* kappa,
+                          const double* mu_coef, const double* mob_coef) {
+  if (!ctx) return PDEOPT_EINVAL;
+  int rc = check_envs(ctx, env_first, env_count);
+  if (rc) return rc;
+  PDEOPT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  if (ctx->prob.dtype == PDEOPT_F32)
+    patch_env_params<float>(ctx, env_first, env_count, kappa, mu_coef, mob_coef);
+  else
+    patch_env_params<double>(ctx, env_first, env_count, kappa, mu_coef, mob_coef);
+  return upload_env_params(ctx);
+}
+
+int pdeopt_set_aux(pdeopt_ctx* ctx, int which, const void* host, int per_env) {
+  if (!ctx || !host) return PDEOPT_EINVAL;
+  if (!ctx->configured) return fail(ctx, PDEOPT_ESTATE, "pdeopt_configure has not been called");
+  if (which < 0 || which >= kNumAux) return fail(ctx, PDEOPT_EINVAL, "unknown aux field %d", which);
+  PDEOPT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  const bool cplx = which == PDEOPT_AUX_IMEX_SYMBOL || which == PDEOPT_AUX_GPE_A_TERM;
+  const size_t bytes = (size_t)ctx->prob.nx * ctx->prob.ny * (cplx ? 2 : 1) * ctx->esize *
+                       (per_env ? (size_t)ctx->prob.batch : 1);
+  AuxField& a = ctx->aux[which];
+  if (a.dev && a.bytes != bytes) {
+    PDEOPT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    (void)hipFree(a.dev);
+    a.dev = nullptr;
+  }
+  int rc = ensure_buffer(ctx, &a.dev, bytes);
+  if (rc) return rc;
+  a.bytes = bytes;
+  a.per_env = per_env ? 1 : 0;
+  PDEOPT_HIP_CHECK(ctx, hipMemcpyAsync(a.dev, host, bytes, hipMemcpyHostToDevice, ctx->stream));
+  PDEOPT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return PDEOPT_OK;
+}
+
+int pdeopt_set_state(pdeopt_ctx* ctx, int env_first, int env_count, const void* host) {
+  if (!ctx || !host) return PDEOPT_EINVAL;
+  int rc = check_envs(ctx, env_first, env_count);
+  if (rc) return rc;
+  PDEOPT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  const size_t eb = ctx->env_elems * ctx->esize;
+  PDEOPT_HIP_CHECK(ctx, hipMemcpyAsync((char*)ctx->Y + eb * env_first, host, eb * env_count,
+                                       hipMemcpyHostToDevice, ctx->stream));
+  PDEOPT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->tsit5_fsal_valid = false;
+  ctx->tsit5_pending = false;
+  return PDEOPT_OK;
+}
+
+int pdeopt_get_state(pdeopt_ctx* ctx, int env_first, int env_count, void* host) {
+  if (!ctx || !host) return PDEOPT_EINVAL;
+  int rc = check_envs(ctx, env_first, env_count);
+  if (rc) return rc;
+  PDEOPT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  const size_t eb = ctx->env_elems * ctx->esize;
+  PDEOPT_HIP_CHECK(ctx, hipMemcpyAsync(host, (char*)ctx->Y + eb * env_first, eb * env_count,
+                                       hipMemcpyDeviceToHost, ctx->stream));
+  PDEOPT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return PDEOPT_OK;
+}
+
+int pdeopt_state_device_ptr(pdeopt_ctx* ctx, void** dev_ptr, int64_t* bytes) {
+  if (!ctx || !dev_ptr) return PDEOPT_EINVAL;
+  if (!ctx->configured) return fail(ctx, PDEOPT_ESTATE, "pdeopt_configure has not been called");
+  *dev_ptr = ctx->Y;
+  if (bytes) *bytes = (int64_t)ctx->total_bytes;
+  return PDEOPT_OK;
+}
+
+int pdeopt_rhs(pdeopt_ctx* ctx, double t, void* host_out) {
+  if (!ctx) return PDEOPT_EINVAL;
+  if (!ctx->configured) return fail(ctx, PDEOPT_ESTATE, "pdeopt_configure has not been called");
+  if (ctx->prob.equation == PDEOPT_EQ_GPE)
+    return fail(ctx, PDEOPT_EINVAL, "the GPE has no explicit RHS kernel (use the Strang integrator)");
+  PDEOPT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  int rc = ensure_buffer(ctx, &ctx->TA, ctx->total_bytes);
+  if (rc) return rc;
+  if ((rc = launch_rhs(ctx, ctx->Y, ctx->TA, t))) return rc;
+  if (host_out) {
+    PDEOPT_HIP_CHECK(ctx, hipMemcpyAsync(host_out, ctx->TA, ctx->total_bytes, hipMemcpyDeviceToHost,
+                                         ctx->stream));
+    PDEOPT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  return PDEOPT_OK;
+}
+
+int pdeopt_set_integrator_params(pdeopt_ctx* ctx, double imex_A, double time_scale_re,
+                                 double time_scale_im, double strang_dx) {
+  if (!ctx) return PDEOPT_EINVAL;
+  ctx->imex_A = imex_A;
+  ctx->ts_re = time_scale_re;
+  ctx->ts_im = time_scale_im;
+  ctx->strang_dx = strang_dx;
+  return PDEOPT_OK;
+}
+
+int pdeopt_advance(pdeopt_ctx* ctx, int integrator, double t0, double dt, int64_t n_substeps) {
+  if (!ctx) return PDEOPT_EINVAL;
+  if (!ctx->configured) return fail(ctx, PDEOPT_ESTATE, "pdeopt_configure has not been called");
+  if (n_substeps < 0) return fail(ctx, PDEOPT_EINVAL, "n_substeps < 0");
+  if (n_substeps == 0) return PDEOPT_OK;
+  PDEOPT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  ctx->tsit5_fsal_valid = false;
+  ctx->tsit5_pending = false;
+  const int eq = ctx->prob.equation;
+  switch (integrator) {
+    case PDEOPT_INT_EULER:
+    case PDEOPT_INT_RK4:
+      if (eq == PDEOPT_EQ_GPE)
+        return fail(ctx, PDEOPT_EINVAL, "the GPE is integrated by Strang splitting only");
+      return advance_explicit(ctx, integrator, t0, dt, n_substeps);
+    case PDEOPT_INT_IMEX:
+      if (eq != PDEOPT_EQ_CAHN_HILLIARD && eq != PDEOPT_EQ_ALLEN_CAHN)
+        return fail(ctx, PDEOPT_EINVAL, "IMEX needs a Cahn-Hilliard/Allen-Cahn equation");
+      return advance_imex(ctx, t0, dt, n_substeps);
+    case PDEOPT_INT_STRANG:
+      if (eq != PDEOPT_EQ_GPE) return fail(ctx, PDEOPT_EINVAL, "Strang splitting needs the GPE");
+      return advance_strang(ctx, t0, dt, n_substeps);
+    case PDEOPT_INT_TSIT5: {
+      if (eq == PDEOPT_EQ_GPE)
+        return fail(ctx, PDEOPT_EINVAL, "the GPE is integrated by Strang splitting only");
+      std::vector<double> err((size_t)ctx->prob.batch);
+      for (int64_t s = 0; s < n_substeps; ++s) {
+        int rc = tsit5_trial(ctx, t0 + s * dt, dt, 1.0, 1.0, nullptr);
+        if (rc) return rc;
+        if ((rc = tsit5_commit(ctx, 1))) return rc;
+      }
+      return PDEOPT_OK;
+    }
+    default:
+      return fail(ctx, PDEOPT_EINVAL, "unknown integrator %d", integrator);
+  }
+}
+
+int pdeopt_snapshot(pdeopt_ctx* ctx) {
+  if (!ctx) return PDEOPT_EINVAL;
+  if (!ctx->configured) return fail(ctx, PDEOPT_ESTATE, "pdeopt_configure has not been called");
+  PDEOPT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  int rc = ensure_buffer(ctx, &ctx->SNAP, ctx->total_bytes);
+  if (rc) return rc;
+  PDEOPT_HIP_CHECK(ctx, hipMemcpyAsync(ctx->SNAP, ctx->Y, ctx->total_bytes, hipMemcpyDeviceToDevice,
+                                       ctx->stream));
+  return PDEOPT_OK;
+}
+
+int pdeopt_get_interpolated(pdeopt_ctx* ctx, double theta, int env_first, int env_count,
+                            void* host_out) {
+  if (!ctx || !host_out) return PDEOPT_EINVAL;
+  int rc = check_envs(ctx, env_first, env_count);
+  if (rc) return rc;
+  if (!ctx->SNAP) return fail(ctx, PDEOPT_ESTATE, "pdeopt_snapshot has not been called");
+  PDEOPT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  if ((rc = ensure_buffer(ctx, &ctx->TA, ctx->total_bytes))) return rc;
+  if ((rc = launch_lerp(ctx, ctx->SNAP, ctx->Y, ctx->TA, theta, env_first, env_count))) return rc;
+  PDEOPT_HIP_CHECK(ctx, hipMemcpyAsync(host_out, ctx->TA, ctx->env_elems * ctx->esize * env_count,
+                                       hipMemcpyDeviceToHost, ctx->stream));
+  PDEOPT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return PDEOPT_OK;
+}
+
+int pdeopt_reduce(pdeopt_ctx* ctx, int op, double* out_per_env) {
+  if (!ctx || !out_per_env) return PDEOPT_EINVAL;
+  if (!ctx->configured) return fail(ctx, PDEOPT_ESTATE, "pdeopt_configure has not been called");
+  PDEOPT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  return reduce_state(ctx, op, out_per_env);
+}
+
+int pdeopt_tsit5_trial(pdeopt_ctx* ctx, double t, double dt, double rtol, double atol,
+                       double* err_norm) {
+  if (!ctx) return PDEOPT_EINVAL;
+  if (!ctx->configured) return fail(ctx, PDEOPT_ESTATE, "pdeopt_configure has not been called");
+  if (ctx->prob.equation == PDEOPT_EQ_GPE)
+    return fail(ctx, PDEOPT_EINVAL, "the GPE is integrated by Strang splitting only");
+  PDEOPT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  return tsit5_trial(ctx, t, dt, rtol, atol, err_norm);
+}
+
+int pdeopt_tsit5_commit(pdeopt_ctx* ctx, int accept) {
+  if (!ctx) return PDEOPT_EINVAL;
+  if (!ctx->configured) return fail(ctx, PDEOPT_ESTATE, "pdeopt_configure has not been called");
+  PDEOPT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  return tsit5_commit(ctx, accept);
+}
+
+int pdeopt_sync(pdeopt_ctx* ctx) {
+  if (!ctx) return PDEOPT_EINVAL;
+  PDEOPT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  PDEOPT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return PDEOPT_OK;
+}
+
+int pdeopt_timer_start(pdeopt_ctx* ctx) {
+  if (!ctx) return PDEOPT_EINVAL;
+  PDEOPT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  PDEOPT_HIP_CHECK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+  return PDEOPT_OK;
+}
+
+int pdeopt_timer_stop(pdeopt_ctx* ctx, double* ms) {
+  if (!ctx || !ms) return PDEOPT_EINVAL;
+  PDEOPT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  PDEOPT_HIP_CHECK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+  PDEOPT_HIP_CHECK(ctx, hipEventSynchronize(ctx->ev1));
+  float f = 0.f;
+  PDEOPT_HIP_CHECK(ctx, hipEventElapsedTime(&f, ctx->ev0, ctx->ev1));
+  *ms = (double)f;
+  return PDEOPT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,94 @@
+"""Build libpdeopt_hip.so for gfx950 (in-tree, next to the Python package).
+
+    python -m pde_opt_amd.csrc.build          # or: python pde_opt_amd/csrc/build.py
+
+hipcc cross-compiles without a GPU.  Translation units are compiled in parallel and the
+objects are cached by source mtime, so a rebuild after touching one file takes seconds.
+"""
+
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.dirname(HERE)
+ROOT = os.path.dirname(PKG)
+LIB = os.path.join(PKG, "libpdeopt_hip.so")
+OBJ_DIR = os.path.join(HERE, "build")
+
+SOURCES = ["api.hip", "stencil.hip", "reduce.hip", "spectral.hip"]
+HEADERS = [
+    "common.hpp",
+    "closures.hpp",
+    "stencil_generic.hpp",
+    "stencil_tiled.hpp",
+    os.path.join(ROOT, "include", "pdeopt_hip.h"),
+]
+ARCH = "gfx950"
+CXXFLAGS = [
+    "-O3",
+    "-std=c++17",
+    "-fPIC",
+    f"--offload-arch={ARCH}",
+    "-fno-gpu-rdc",
+    "-Wall",
+    "-Wno-unused-function",
+    "-I/opt/rocm/include",
+]
+
+
+def _hipcc() -> str:
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found: the HIP toolchain is required to build libpdeopt_hip.so")
+    return exe
+
+
+def _newest_header() -> float:
+    t = 0.0
+    for h in HEADERS + [os.path.abspath(__file__)]:
+        p = h if os.path.isabs(h) else os.path.join(HERE, h)
+        t = max(t, os.path.getmtime(p))
+    return t
+
+
+def _compile(src: str, force: bool, extra: list[str]) -> str:
+    obj = os.path.join(OBJ_DIR, src.replace(".hip", ".o"))
+    sp = os.path.join(HERE, src)
+    stamp = max(os.path.getmtime(sp), _newest_header())
+    if not force and os.path.exists(obj) and os.path.getmtime(obj) >= stamp:
+        return obj
+    cmd = [_hipcc(), *CXXFLAGS, *extra, "-c", sp, "-o", obj]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"hipcc failed on {src}:\n{' '.join(cmd)}\n{r.stdout}\n{r.stderr}")
+    if r.stderr.strip():
+        sys.stderr.write(r.stderr)
+    return obj
+
+
+def build(force: bool = False, verbose: bool = True, extra_flags: list[str] | None = None) -> str:
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    extra = list(extra_flags or [])
+    with ThreadPoolExecutor(max_workers=min(4, len(SOURCES))) as ex:
+        objs = list(ex.map(lambda s: _compile(s, force, extra), SOURCES))
+    need_link = force or not os.path.exists(LIB) or any(
+        os.path.getmtime(o) > os.path.getmtime(LIB) for o in objs
+    )
+    if need_link:
+        cmd = [_hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB, *objs,
+               "-L/opt/rocm/lib", "-lrocfft", "-Wl,-rpath,/opt/rocm/lib"]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{' '.join(cmd)}\n{r.stdout}\n{r.stderr}")
+    if verbose:
+        print(f"[pde_opt_amd] {LIB} ({os.path.getsize(LIB) / 1e6:.1f} MB)")
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

@@ -1,0 +1,100 @@
+// Pointwise closure family evaluated inside the stencil kernels (device code).
+//
+// Stands in for the reference's Python callables mu(u), D(u), R(u) (dataclass fields
+// pde_opt/numerics/equations/cahn_hilliard.py:51-54, allen_cahn.py:47-50; catalogue SURVEY
+// Appendix D).  See include/pdeopt_hip.h for the definition of the family.
+#pragma once
+
+#include "common.hpp"
+
+namespace pdeopt {
+
+template <typename T>
+__device__ __forceinline__ T t_log(T x);
+template <>
+__device__ __forceinline__ float t_log<float>(float x) {
+  return logf(x);
+}
+template <>
+__device__ __forceinline__ double t_log<double>(double x) {
+  return log(x);
+}
+template <typename T>
+__device__ __forceinline__ T t_exp(T x);
+template <>
+__device__ __forceinline__ float t_exp<float>(float x) {
+  return expf(x);
+}
+template <>
+__device__ __forceinline__ double t_exp<double>(double x) {
+  return exp(x);
+}
+
+// Closure specialisation classes (template parameter CL of the kernels):
+//   CL_GENERIC : any kind / flags / n, decided at run time (wave-uniform branches)
+//   CL_POLY    : mu = cubic polynomial, mobility = quadratic polynomial, fully unrolled
+//   CL_LOGIT   : as CL_POLY with the log(c/(1-c)) prior added to mu (regular-solution model)
+enum { CL_GENERIC = 0, CL_POLY = 1, CL_LOGIT = 2 };
+
+template <typename T>
+__device__ __forceinline__ T series_generic(const ClosureSpec& s, const T* __restrict__ coef, T c) {
+  T r;
+  if (s.kind == PDEOPT_CL_POLY) {
+    r = coef[s.n - 1];
+    for (int k = s.n - 2; k >= 0; --k) r = r * c + coef[k];
+  } else {
+    // forward three-term recurrence on x = 2c - 1, the order legendre.py:23-34 uses
+    const T x = T(2) * c - T(1);
+    r = coef[0];
+    if (s.n > 1) r += coef[1] * x;
+    T pm = T(1), pc = x;
+    for (int k = 2; k < s.n; ++k) {
+      const T pn = (T(2 * k - 1) * x * pc - T(k - 1) * pm) / T(k);
+      r += coef[k] * pn;
+      pm = pc;
+      pc = pn;
+    }
+  }
+  return r;
+}
+
+template <typename T>
+__device__ __forceinline__ T closure_generic(const ClosureSpec& s, const T* __restrict__ coef, T c) {
+  T r = series_generic<T>(s, coef, c);
+  if (s.flags & PDEOPT_CL_LOGIT_PRIOR) r += t_log<T>(c / (T(1) - c));
+  if (s.flags & PDEOPT_CL_EXP_WRAP) r = t_exp<T>(r);
+  return r;
+}
+
+// mu_h(c)
+template <typename T, int CL>
+__device__ __forceinline__ T eval_mu(const ClosureSpec& s, const T* __restrict__ coef, T c) {
+  if constexpr (CL == CL_GENERIC) {
+    return closure_generic<T>(s, coef, c);
+  } else {
+    T r = ((coef[3] * c + coef[2]) * c + coef[1]) * c + coef[0];
+    if constexpr (CL == CL_LOGIT) r += t_log<T>(c / (T(1) - c));
+    return r;
+  }
+}
+
+// D(c) or R(c)
+template <typename T, int CL>
+__device__ __forceinline__ T eval_mob(const ClosureSpec& s, const T* __restrict__ coef, T c) {
+  if constexpr (CL == CL_GENERIC) {
+    return closure_generic<T>(s, coef, c);
+  } else {
+    return (coef[2] * c + coef[1]) * c + coef[0];
+  }
+}
+
+// host side: which specialisation covers a (mu, mob) pair
+inline int classify_closures(const pdeopt_closure& mu, const pdeopt_closure& mob) {
+  const bool mob_ok = mob.kind == PDEOPT_CL_POLY && mob.flags == 0 && mob.n <= 3;
+  const bool mu_poly = mu.kind == PDEOPT_CL_POLY && mu.n <= 4 &&
+                       (mu.flags & ~PDEOPT_CL_LOGIT_PRIOR) == 0;
+  if (mob_ok && mu_poly) return (mu.flags & PDEOPT_CL_LOGIT_PRIOR) ? CL_LOGIT : CL_POLY;
+  return CL_GENERIC;
+}
+
+}  // namespace pdeopt

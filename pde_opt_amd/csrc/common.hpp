@@ -1,0 +1,118 @@
+// Internal declarations shared by the translation units of libpdeopt_hip.so (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <rocfft/rocfft.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "../../include/pdeopt_hip.h"
+
+namespace pdeopt {
+
+constexpr int kMaxCoef = PDEOPT_CLOSURE_MAX_COEF;
+constexpr int kNumAux = 5;
+
+// Per-environment scalar parameters, stored in the arithmetic type of the path.  One struct per
+// environment in device memory; kernels index it with the (wave-uniform) batch index so the
+// loads are scalar.
+template <typename T>
+struct EnvParams {
+  T kappa;
+  T gpe_k;
+  T r0, r1;
+  T mu[kMaxCoef];
+  T mob[kMaxCoef];
+};
+
+// structure of a closure (shared by the whole batch; only coefficient VALUES vary per env)
+struct ClosureSpec {
+  int kind;
+  int flags;
+  int n;
+};
+
+// Where a field lives in memory.  Periodic fields: ld == ny, off == 0, wrap by index.
+// Halo-padded tiles (domain decomposition): neighbours exist in memory, no wrap.
+struct Geo {
+  int nx, ny;       // extent of the computed region
+  int ld;           // row pitch in elements
+  int64_t off;      // element offset of cell (0,0) inside one environment's array
+  int64_t bstride;  // elements between environments
+  int periodic;     // 1: wrap indices; 0: read halo cells at i in [-2, nx+1], j in [-2, ny+1]
+};
+
+struct AuxField {
+  void* dev = nullptr;
+  int per_env = 0;
+  size_t bytes = 0;
+};
+
+struct Spectral;  // rocFFT plans + work buffers (spectral.hip)
+
+}  // namespace pdeopt
+
+struct pdeopt_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  std::string err;
+  std::string last_kernel;
+  bool configured = false;
+  pdeopt_problem prob{};
+  size_t esize = 4;        // bytes per real element
+  int comps = 1;           // 2 for the GPE (re, im)
+  size_t env_elems = 0;    // real elements per environment
+  size_t total_bytes = 0;  // one field, whole batch
+  // field buffers (device).  Y always holds the current state.
+  void* Y = nullptr;
+  void* TA = nullptr;
+  void* TB = nullptr;
+  void* ACC = nullptr;
+  void* SNAP = nullptr;
+  void* K[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // Tsit5 slopes
+  bool tsit5_pending = false;
+  bool tsit5_fsal_valid = false;
+  void* env_params_dev = nullptr;
+  std::vector<char> env_params_host;
+  pdeopt::AuxField aux[pdeopt::kNumAux];
+  int64_t opt_kernel_path = 0;
+  double imex_A = 0.5, ts_re = 1.0, ts_im = 0.0, strang_dx = 1.0;
+  double* red_dev = nullptr;  // reduction scratch
+  size_t red_cap = 0;
+  double* red_mean_dev = nullptr;
+  pdeopt::Spectral* spectral = nullptr;
+};
+
+namespace pdeopt {
+
+int fail(pdeopt_ctx* ctx, int code, const char* fmt, ...);
+
+#define PDEOPT_HIP_CHECK(ctx, expr)                                                        \
+  do {                                                                                      \
+    hipError_t e_ = (expr);                                                                 \
+    if (e_ != hipSuccess)                                                                   \
+      return pdeopt::fail((ctx), PDEOPT_EHIP, "%s failed: %s (%s:%d)", #expr,              \
+                          hipGetErrorString(e_), __FILE__, __LINE__);                      \
+  } while (0)
+
+int ensure_buffer(pdeopt_ctx* ctx, void** p, size_t bytes);
+
+// stencil.hip
+int launch_rhs(pdeopt_ctx* ctx, const void* in, void* out, double t);
+int advance_explicit(pdeopt_ctx* ctx, int integrator, double t0, double dt, int64_t n);
+int tsit5_trial(pdeopt_ctx* ctx, double t, double dt, double rtol, double atol, double* err);
+int tsit5_commit(pdeopt_ctx* ctx, int accept);
+int launch_lerp(pdeopt_ctx* ctx, const void* a, const void* b, void* out, double theta,
+                size_t env_first, size_t env_count);
+// reduce.hip
+int reduce_state(pdeopt_ctx* ctx, int op, double* out);
+// spectral.hip
+int advance_imex(pdeopt_ctx* ctx, double t0, double dt, int64_t n);
+int advance_strang(pdeopt_ctx* ctx, double t0, double dt, int64_t n);
+void spectral_destroy(pdeopt_ctx* ctx);
+
+}  // namespace pdeopt

@@ -1,0 +1,311 @@
+// Host-side dispatch of the fused stencil + integrator-stage kernels (explicit integrators).
+//
+// Replaces the body of diffrax.diffeqsolve's while-loop for explicit solvers at the call sites
+// pde_opt/pde_env.py:293-303 and pde_opt/pde_model.py:120-134: one kernel per Runge-Kutta stage,
+// each evaluating equation.rhs on the stage input and applying the stage's axpy updates in the
+// same pass.
+#include <algorithm>
+#include <cmath>
+
+#include "stencil_generic.hpp"
+#include "stencil_tiled.hpp"
+
+namespace pdeopt {
+
+namespace {
+
+template <typename T>
+StageArgs<T> make_args(pdeopt_ctx* ctx, const void* in, const void* y, void* out, void* acc,
+                       double a, double b, int out_mode, int acc_mode) {
+  const pdeopt_problem& p = ctx->prob;
+  StageArgs<T> s{};
+  s.in = static_cast<const T*>(in);
+  s.y = static_cast<const T*>(y);
+  s.out = static_cast<T*>(out);
+  s.acc = static_cast<T*>(acc);
+  s.a = T(a);
+  s.b = T(b);
+  s.rhx = T(1.0 / p.hx);
+  s.rhy = T(1.0 / p.hy);
+  s.rhx2 = T(1.0 / (p.hx * p.hx));
+  s.rhy2 = T(1.0 / (p.hy * p.hy));
+  s.g.nx = p.nx;
+  s.g.ny = p.ny;
+  s.g.ld = p.ny;
+  s.g.off = 0;
+  s.g.bstride = (int64_t)p.nx * p.ny;
+  s.g.periodic = 1;
+  s.ep = static_cast<const EnvParams<T>*>(ctx->env_params_dev);
+  s.mu = ClosureSpec{p.mu.kind, p.mu.flags, p.mu.n};
+  s.mob = ClosureSpec{p.mob.kind, p.mob.flags, p.mob.n};
+  s.vx = static_cast<const T*>(ctx->aux[PDEOPT_AUX_VX_FACE].dev);
+  s.vy = static_cast<const T*>(ctx->aux[PDEOPT_AUX_VY_FACE].dev);
+  s.vstride = ctx->aux[PDEOPT_AUX_VX_FACE].per_env ? (int64_t)p.nx * p.ny : 0;
+  s.out_mode = out_mode;
+  s.acc_mode = acc_mode;
+  return s;
+}
+
+template <typename T>
+int launch_generic(pdeopt_ctx* ctx, const StageArgs<T>& s) {
+  const pdeopt_problem& p = ctx->prob;
+  dim3 block(64, 4, 1);
+  dim3 grid((p.ny + 63) / 64, (p.nx + 3) / 4, p.batch);
+  if (grid.y > 65535u || grid.z > 65535u)
+    return fail(ctx, PDEOPT_EINVAL, "grid too large for the generic kernel (nx=%d batch=%d)", p.nx,
+                p.batch);
+  switch (p.equation) {
+    case PDEOPT_EQ_CAHN_HILLIARD:
+      hipLaunchKernelGGL((stage_generic_kernel<T, PDEOPT_EQ_CAHN_HILLIARD>), grid, block, 0,
+                         ctx->stream, s);
+      ctx->last_kernel = "stage_generic<CH>";
+      break;
+    case PDEOPT_EQ_ALLEN_CAHN:
+      hipLaunchKernelGGL((stage_generic_kernel<T, PDEOPT_EQ_ALLEN_CAHN>), grid, block, 0,
+                         ctx->stream, s);
+      ctx->last_kernel = "stage_generic<AC>";
+      break;
+    case PDEOPT_EQ_ADVECTION_DIFFUSION:
+      if (!s.vx || !s.vy)
+        return fail(ctx, PDEOPT_ESTATE, "advection-diffusion needs VX_FACE and VY_FACE aux fields");
+      hipLaunchKernelGGL((stage_generic_kernel<T, PDEOPT_EQ_ADVECTION_DIFFUSION>), grid, block, 0,
+                         ctx->stream, s);
+      ctx->last_kernel = "stage_generic<AD>";
+      break;
+    default:
+      return fail(ctx, PDEOPT_EINVAL, "equation %d has no explicit RHS kernel", p.equation);
+  }
+  PDEOPT_HIP_CHECK(ctx, hipGetLastError());
+  return PDEOPT_OK;
+}
+
+// One fused stage: k = rhs(in); out/acc updated per (out_mode, acc_mode).
+template <typename T>
+int launch_stage_t(pdeopt_ctx* ctx, const void* in, const void* y, void* out, void* acc, double a,
+                   double b, int out_mode, int acc_mode) {
+  StageArgs<T> s = make_args<T>(ctx, in, y, out, acc, a, b, out_mode, acc_mode);
+  if (ctx->opt_kernel_path != 1 && tiled_supported<T>(ctx->prob)) {
+    return launch_tiled<T>(ctx, s);
+  }
+  if (ctx->opt_kernel_path == 2)
+    return fail(ctx, PDEOPT_EINVAL, "LDS-tiled kernel forced but shape %dx%d / equation %d is not covered",
+                ctx->prob.nx, ctx->prob.ny, ctx->prob.equation);
+  return launch_generic<T>(ctx, s);
+}
+
+int launch_stage(pdeopt_ctx* ctx, const void* in, const void* y, void* out, void* acc, double a,
+                 double b, int out_mode, int acc_mode) {
+  if (ctx->prob.dtype == PDEOPT_F32)
+    return launch_stage_t<float>(ctx, in, y, out, acc, a, b, out_mode, acc_mode);
+  return launch_stage_t<double>(ctx, in, y, out, acc, a, b, out_mode, acc_mode);
+}
+
+template <typename T>
+__global__ void lerp_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ out,
+                            T theta, int64_t n) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) out[i] = a[i] + theta * (b[i] - a[i]);
+}
+
+}  // namespace
+
+int launch_rhs(pdeopt_ctx* ctx, const void* in, void* out, double) {
+  return launch_stage(ctx, in, in, out, nullptr, 0.0, 0.0, OUT_K, ACC_NONE);
+}
+
+int advance_explicit(pdeopt_ctx* ctx, int integrator, double, double dt, int64_t n) {
+  int rc;
+  if ((rc = ensure_buffer(ctx, &ctx->TA, ctx->total_bytes))) return rc;
+  if (integrator == PDEOPT_INT_EULER) {
+    for (int64_t s = 0; s < n; ++s) {
+      if ((rc = launch_stage(ctx, ctx->Y, ctx->Y, ctx->TA, nullptr, dt, 0.0, OUT_Y_PLUS_AK, ACC_NONE)))
+        return rc;
+      std::swap(ctx->Y, ctx->TA);
+    }
+    return PDEOPT_OK;
+  }
+  if (integrator == PDEOPT_INT_RK4) {
+    if ((rc = ensure_buffer(ctx, &ctx->TB, ctx->total_bytes))) return rc;
+    if ((rc = ensure_buffer(ctx, &ctx->ACC, ctx->total_bytes))) return rc;
+    for (int64_t s = 0; s < n; ++s) {
+      // stage 1: k1 = f(y);        TA = y + dt/2 k1;  ACC = y + dt/6 k1
+      if ((rc = launch_stage(ctx, ctx->Y, ctx->Y, ctx->TA, ctx->ACC, dt / 2, dt / 6, OUT_Y_PLUS_AK, ACC_INIT)))
+        return rc;
+      // stage 2: k2 = f(TA);       TB = y + dt/2 k2;  ACC += dt/3 k2
+      if ((rc = launch_stage(ctx, ctx->TA, ctx->Y, ctx->TB, ctx->ACC, dt / 2, dt / 3, OUT_Y_PLUS_AK, ACC_ADD)))
+        return rc;
+      // stage 3: k3 = f(TB);       TA = y + dt k3;    ACC += dt/3 k3
+      if ((rc = launch_stage(ctx, ctx->TB, ctx->Y, ctx->TA, ctx->ACC, dt, dt / 3, OUT_Y_PLUS_AK, ACC_ADD)))
+        return rc;
+      // stage 4: k4 = f(TA);       y  = ACC + dt/6 k4   (in place: y is only touched pointwise)
+      if ((rc = launch_stage(ctx, ctx->TA, ctx->Y, ctx->Y, ctx->ACC, 0.0, dt / 6, OUT_ACC_PLUS_BK, ACC_NONE)))
+        return rc;
+    }
+    return PDEOPT_OK;
+  }
+  return fail(ctx, PDEOPT_EINVAL, "integrator %d is not an explicit fixed-step integrator", integrator);
+}
+
+// ------------------------------------------------------------------------------------------
+// Tsit5 (diffrax.Tsit5; call sites tests/test_solvers.py:81,263 and most notebooks).  Tableau:
+// Ch. Tsitouras, Comput. Math. Appl. 62 (2011) 770-775 -- the published coefficients diffrax
+// ships.  Row f1 of SURVEY section 8: one trial step + scaled error norm per environment; the
+// PID step-size logic stays on the host (pde_opt_amd/pde_model.py).
+// ------------------------------------------------------------------------------------------
+namespace {
+
+constexpr double kTsA[6][6] = {
+    {0.161, 0, 0, 0, 0, 0},
+    {-0.008480655492356989, 0.335480655492357, 0, 0, 0, 0},
+    {2.8971530571054935, -6.359448489975075, 4.3622954328695815, 0, 0, 0},
+    {5.325864828439257, -11.748883564062828, 7.4955393428898365, -0.09249506636175525, 0, 0},
+    {5.86145544294642, -12.92096931784711, 8.159367898576159, -0.071584973281401,
+     -0.028269050394068383, 0},
+    {0.09646076681806523, 0.01, 0.4798896504144996, 1.379008574103742, -3.290069515436081,
+     2.324710524099774}};
+constexpr double kTsE[7] = {0.00178001105222577714, 0.0008164344596567469, -0.007880878010261995,
+                            0.1447110071732629,     -0.5823571654525552,   0.45808210592918697,
+                            -1.0 / 66.0};
+
+template <typename T>
+struct LinComb {
+  const T* y;
+  const T* k[7];
+  T c[7];
+  int n;
+  T* out;
+};
+
+template <typename T>
+__global__ void lincomb_kernel(const LinComb<T> a, int64_t total) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t st = (int64_t)gridDim.x * blockDim.x;
+  for (; i < total; i += st) {
+    T r = a.y[i];
+    for (int j = 0; j < a.n; ++j) r += a.c[j] * a.k[j][i];
+    a.out[i] = r;
+  }
+}
+
+constexpr int kErrBlocks = 64;
+
+// partial[b][blk] = sum ((dt sum_j e_j k_j) / (atol + rtol max(|y0|,|y1|)))^2
+template <typename T>
+__global__ __launch_bounds__(256) void tsit5_err_kernel(const LinComb<T> a, const T* __restrict__ y1,
+                                                        T rtol, T atol, int64_t env_elems,
+                                                        double* __restrict__ partial) {
+  const int b = blockIdx.y;
+  const int64_t o = (int64_t)b * env_elems;
+  double acc = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < env_elems; i += (int64_t)gridDim.x * 256) {
+    T e = T(0);
+    for (int j = 0; j < 7; ++j) e += a.c[j] * a.k[j][o + i];
+    const T sc = atol + rtol * fmax(fabs(a.y[o + i]), fabs(y1[o + i]));
+    const double q = (double)(e / sc);
+    acc += q * q;
+  }
+  __shared__ double sh[4];
+#pragma unroll
+  for (int s = 32; s > 0; s >>= 1) acc += __shfl_down(acc, s, 64);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[(int64_t)b * gridDim.x + blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+template <typename T>
+int tsit5_trial_t(pdeopt_ctx* ctx, double dt, double rtol, double atol, double* err) {
+  int rc;
+  for (auto& k : ctx->K)
+    if ((rc = ensure_buffer(ctx, &k, ctx->total_bytes))) return rc;
+  if ((rc = ensure_buffer(ctx, &ctx->TA, ctx->total_bytes))) return rc;
+  if ((rc = ensure_buffer(ctx, &ctx->TB, ctx->total_bytes))) return rc;
+  const int64_t total = (int64_t)(ctx->env_elems * ctx->prob.batch);
+  const int blocks = (int)std::min<int64_t>((total + 255) / 256, 4096);
+  if (!ctx->tsit5_fsal_valid) {
+    if ((rc = launch_stage(ctx, ctx->Y, ctx->Y, ctx->K[0], nullptr, 0, 0, OUT_K, ACC_NONE))) return rc;
+  }
+  for (int s = 0; s < 6; ++s) {
+    LinComb<T> lc{};
+    lc.y = (const T*)ctx->Y;
+    lc.n = s + 1;
+    for (int j = 0; j <= s; ++j) {
+      lc.k[j] = (const T*)ctx->K[j];
+      lc.c[j] = T(dt * kTsA[s][j]);
+    }
+    void* dst = (s == 5) ? ctx->TB : ctx->TA;  // the last stage input is the 5th-order solution
+    lc.out = (T*)dst;
+    hipLaunchKernelGGL(lincomb_kernel<T>, dim3(blocks), dim3(256), 0, ctx->stream, lc, total);
+    if ((rc = launch_stage(ctx, dst, dst, ctx->K[s + 1], nullptr, 0, 0, OUT_K, ACC_NONE))) return rc;
+  }
+  ctx->tsit5_pending = true;
+  if (err) {
+    double* part = nullptr;
+    const size_t need = sizeof(double) * kErrBlocks * ctx->prob.batch;
+    if (ctx->red_cap < need) {
+      if (ctx->red_dev) (void)hipFree(ctx->red_dev);
+      ctx->red_dev = nullptr;
+      PDEOPT_HIP_CHECK(ctx, hipMalloc((void**)&ctx->red_dev, need));
+      ctx->red_cap = need;
+    }
+    part = ctx->red_dev;
+    LinComb<T> lc{};
+    lc.y = (const T*)ctx->Y;
+    lc.n = 7;
+    for (int j = 0; j < 7; ++j) {
+      lc.k[j] = (const T*)ctx->K[j];
+      lc.c[j] = T(dt * kTsE[j]);
+    }
+    hipLaunchKernelGGL(tsit5_err_kernel<T>, dim3(kErrBlocks, ctx->prob.batch), dim3(256), 0,
+                       ctx->stream, lc, (const T*)ctx->TB, (T)rtol, (T)atol,
+                       (int64_t)ctx->env_elems, part);
+    PDEOPT_HIP_CHECK(ctx, hipGetLastError());
+    std::vector<double> h((size_t)kErrBlocks * ctx->prob.batch);
+    PDEOPT_HIP_CHECK(ctx, hipMemcpyAsync(h.data(), part, need, hipMemcpyDeviceToHost, ctx->stream));
+    PDEOPT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    for (int b = 0; b < ctx->prob.batch; ++b) {
+      double s = 0;
+      for (int c = 0; c < kErrBlocks; ++c) s += h[(size_t)b * kErrBlocks + c];
+      err[b] = std::sqrt(s / (double)ctx->env_elems);  // diffrax rms_norm
+    }
+  }
+  PDEOPT_HIP_CHECK(ctx, hipGetLastError());
+  return PDEOPT_OK;
+}
+
+}  // namespace
+
+int tsit5_trial(pdeopt_ctx* ctx, double, double dt, double rtol, double atol, double* err) {
+  return ctx->prob.dtype == PDEOPT_F32 ? tsit5_trial_t<float>(ctx, dt, rtol, atol, err)
+                                       : tsit5_trial_t<double>(ctx, dt, rtol, atol, err);
+}
+
+int tsit5_commit(pdeopt_ctx* ctx, int accept) {
+  if (!ctx->tsit5_pending) return fail(ctx, PDEOPT_ESTATE, "no Tsit5 trial step is pending");
+  ctx->tsit5_pending = false;
+  if (accept) {
+    std::swap(ctx->Y, ctx->TB);         // y <- 5th-order candidate
+    std::swap(ctx->K[0], ctx->K[6]);    // FSAL: k7 = f(t+dt, y1) is the next k1
+  }
+  ctx->tsit5_fsal_valid = true;         // on rejection K[0] = f(t, y) is still valid
+  return PDEOPT_OK;
+}
+
+int launch_lerp(pdeopt_ctx* ctx, const void* a, const void* b, void* out, double theta,
+                size_t env_first, size_t env_count) {
+  const size_t off = env_first * ctx->env_elems;
+  const int64_t n = (int64_t)(env_count * ctx->env_elems);
+  const int threads = 256;
+  const int blocks = (int)std::min<int64_t>((n + threads - 1) / threads, 2048);
+  if (ctx->prob.dtype == PDEOPT_F32) {
+    hipLaunchKernelGGL(lerp_kernel<float>, dim3(blocks), dim3(threads), 0, ctx->stream,
+                       (const float*)a + off, (const float*)b + off, (float*)out, (float)theta, n);
+  } else {
+    hipLaunchKernelGGL(lerp_kernel<double>, dim3(blocks), dim3(threads), 0, ctx->stream,
+                       (const double*)a + off, (const double*)b + off, (double*)out, theta, n);
+  }
+  PDEOPT_HIP_CHECK(ctx, hipGetLastError());
+  return PDEOPT_OK;
+}
+
+}  // namespace pdeopt

@@ -1,0 +1,127 @@
+// Generic (untiled) fused RHS + integrator-stage kernel: any grid shape (including Nx or Ny of
+// 1, 2, 3 where periodic neighbours coincide), any closure, fp32 and fp64.  One thread per cell,
+// neighbours fetched straight from global memory (L1/L2 supply the reuse).  This is the
+// correctness anchor and the fallback for shapes the LDS-tiled kernels do not cover; it is a
+// HIP kernel, not a CPU path.
+//
+// Arithmetic follows, in index form:
+//   lap, mu              pde_opt/numerics/utils/derivatives.py:8-12, cahn_hilliard.py:93
+//   face grad / average  derivatives.py:24-31, 39-46
+//   divergence           derivatives.py:54-61, cahn_hilliard.py:105-109
+//   Allen-Cahn           allen_cahn.py:81-84
+#pragma once
+
+#include "closures.hpp"
+
+namespace pdeopt {
+
+// out/acc update performed after k = rhs(in) has been formed for a cell
+enum { OUT_NONE = 0, OUT_K = 1, OUT_Y_PLUS_AK = 2, OUT_ACC_PLUS_BK = 3 };
+enum { ACC_NONE = 0, ACC_INIT = 1, ACC_ADD = 2 };
+
+template <typename T>
+struct StageArgs {
+  const T* in;   // field the RHS is evaluated on (stencil reads)
+  const T* y;    // base state of the substep (pointwise)
+  T* out;        // primary output (pointwise)
+  T* acc;        // running RK accumulator (pointwise)
+  T a, b;        // already multiplied by dt
+  T rhx, rhy, rhx2, rhy2;
+  Geo g;
+  const EnvParams<T>* ep;
+  ClosureSpec mu, mob;
+  const T* vx;   // advection-diffusion face velocities
+  const T* vy;
+  int64_t vstride;
+  int out_mode, acc_mode;
+};
+
+__device__ __forceinline__ int wrap_idx(int i, int n) {
+  i %= n;
+  return i < 0 ? i + n : i;
+}
+
+template <typename T>
+__device__ __forceinline__ T lap_at(T c, T xp, T xm, T yp, T ym, T rhx2, T rhy2) {
+  return (xp - T(2) * c + xm) * rhx2 + (yp - T(2) * c + ym) * rhy2;
+}
+
+template <typename T, int EQ>
+__device__ __forceinline__ T rhs_generic_point(const StageArgs<T>& a, const T* __restrict__ u,
+                                               const EnvParams<T>& p, int i, int j, int b) {
+  const Geo& g = a.g;
+  int i1 = i + 1, i2 = i + 2, im1 = i - 1, im2 = i - 2;
+  int j1 = j + 1, j2 = j + 2, jm1 = j - 1, jm2 = j - 2;
+  if (g.periodic) {
+    i1 = wrap_idx(i1, g.nx); i2 = wrap_idx(i2, g.nx);
+    im1 = wrap_idx(im1, g.nx); im2 = wrap_idx(im2, g.nx);
+    j1 = wrap_idx(j1, g.ny); j2 = wrap_idx(j2, g.ny);
+    jm1 = wrap_idx(jm1, g.ny); jm2 = wrap_idx(jm2, g.ny);
+  }
+  const int64_t ld = g.ld;
+  auto U = [&](int ii, int jj) -> T { return u[(int64_t)ii * ld + jj]; };
+  const T u00 = U(i, j), uxp = U(i1, j), uxm = U(im1, j), uyp = U(i, j1), uym = U(i, jm1);
+
+  if constexpr (EQ == PDEOPT_EQ_ALLEN_CAHN) {
+    const T mu = closure_generic<T>(a.mu, p.mu, u00) -
+                 p.kappa * lap_at<T>(u00, uxp, uxm, uyp, uym, a.rhx2, a.rhy2);
+    return -closure_generic<T>(a.mob, p.mob, u00) * mu;
+  } else if constexpr (EQ == PDEOPT_EQ_ADVECTION_DIFFUSION) {
+    const int64_t vb = (int64_t)b * a.vstride;
+    const T vx0 = a.vx[vb + (int64_t)i * g.ny + j], vxm = a.vx[vb + (int64_t)im1 * g.ny + j];
+    const T vy0 = a.vy[vb + (int64_t)i * g.ny + j], vym = a.vy[vb + (int64_t)i * g.ny + jm1];
+    const T fx0 = vx0 * (T(0.5) * (u00 + uxp)), fxm = vxm * (T(0.5) * (uxm + u00));
+    const T fy0 = vy0 * (T(0.5) * (u00 + uyp)), fym = vym * (T(0.5) * (uym + u00));
+    return -((fx0 - fxm) * a.rhx + (fy0 - fym) * a.rhy) +
+           p.kappa * lap_at<T>(u00, uxp, uxm, uyp, uym, a.rhx2, a.rhy2);
+  } else {
+    const T ux2 = U(i2, j), uxm2 = U(im2, j), uy2 = U(i, j2), uym2 = U(i, jm2);
+    const T upp = U(i1, j1), upm = U(i1, jm1), ump = U(im1, j1), umm = U(im1, jm1);
+    const T kap = p.kappa;
+    auto MU = [&](T c, T xp, T xm, T yp, T ym) -> T {
+      return closure_generic<T>(a.mu, p.mu, c) - kap * lap_at<T>(c, xp, xm, yp, ym, a.rhx2, a.rhy2);
+    };
+    const T m00 = MU(u00, uxp, uxm, uyp, uym);
+    const T mxp = MU(uxp, ux2, u00, upp, upm);
+    const T mxm = MU(uxm, u00, uxm2, ump, umm);
+    const T myp = MU(uyp, upp, ump, uy2, u00);
+    const T mym = MU(uym, upm, umm, u00, uym2);
+    const T d00 = closure_generic<T>(a.mob, p.mob, u00);
+    const T dxp = closure_generic<T>(a.mob, p.mob, uxp);
+    const T dxm = closure_generic<T>(a.mob, p.mob, uxm);
+    const T dyp = closure_generic<T>(a.mob, p.mob, uyp);
+    const T dym = closure_generic<T>(a.mob, p.mob, uym);
+    const T fx0 = (T(0.5) * (d00 + dxp)) * ((mxp - m00) * a.rhx);
+    const T fxm = (T(0.5) * (dxm + d00)) * ((m00 - mxm) * a.rhx);
+    const T fy0 = (T(0.5) * (d00 + dyp)) * ((myp - m00) * a.rhy);
+    const T fym = (T(0.5) * (dym + d00)) * ((m00 - mym) * a.rhy);
+    return (fx0 - fxm) * a.rhx + (fy0 - fym) * a.rhy;
+  }
+}
+
+template <typename T>
+__device__ __forceinline__ void stage_update(const StageArgs<T>& a, int64_t idx, T k) {
+  if (a.acc_mode == ACC_INIT) a.acc[idx] = a.y[idx] + a.b * k;
+  if (a.out_mode == OUT_K) {
+    a.out[idx] = k;
+  } else if (a.out_mode == OUT_Y_PLUS_AK) {
+    a.out[idx] = a.y[idx] + a.a * k;
+  } else if (a.out_mode == OUT_ACC_PLUS_BK) {
+    a.out[idx] = a.acc[idx] + a.b * k;
+  }
+  if (a.acc_mode == ACC_ADD) a.acc[idx] += a.b * k;
+}
+
+template <typename T, int EQ>
+__global__ __launch_bounds__(256) void stage_generic_kernel(const StageArgs<T> a) {
+  const int j = blockIdx.x * 64 + threadIdx.x;
+  const int i = blockIdx.y * 4 + threadIdx.y;
+  const int b = blockIdx.z;
+  if (i >= a.g.nx || j >= a.g.ny) return;
+  const int64_t base = (int64_t)b * a.g.bstride + a.g.off;
+  const EnvParams<T>& p = a.ep[b];
+  const T k = rhs_generic_point<T, EQ>(a, a.in + base, p, i, j, b);
+  stage_update<T>(a, base + (int64_t)i * a.g.ld + j, k);
+}
+
+}  // namespace pdeopt

@@ -1,0 +1,229 @@
+"""HipEngine: one pdeopt_ctx (one GPU, one HIP stream) behind a small Python object.
+
+This is the only module that calls into libpdeopt_hip.so.  Everything the reference does between
+``equation_type(domain=..., **params)`` and ``solution.ys[-1]`` in ``PDEEnv.step``
+(pde_opt/pde_env.py:286-305) maps onto: ``configure`` -> ``set_state`` -> ``advance`` ->
+``get_state``.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence
+
+import numpy as np
+
+from . import _lib as L
+from .numerics.closures import ClosureDesc
+
+
+def _closure_struct(desc: Optional[ClosureDesc]) -> L.Closure:
+    s = L.Closure()
+    if desc is None:
+        s.kind, s.flags, s.n = L.CL_POLY, 0, 1
+        s.coef[0] = 0.0
+        return s
+    s.kind, s.flags, s.n = desc.kind, desc.flags, len(desc.coef)
+    for i, v in enumerate(desc.coef):
+        s.coef[i] = float(v)
+    return s
+
+
+class HipEngine:
+    """Owns a device context and the field buffers of one batched problem."""
+
+    def __init__(self, device: int = 0):
+        self._lib = L.load_library()
+        n = L.device_count()
+        if n <= 0:
+            raise L.HipUnavailableError(
+                "no HIP device visible: pde_opt_amd runs its hot path on an MI355X only "
+                "(there is no CPU fallback)"
+            )
+        h = C.c_void_p()
+        rc = self._lib.pdeopt_ctx_create(int(device), C.byref(h))
+        if rc != L.OK:
+            raise L.PdeoptError(rc, self._lib.pdeopt_last_error(None).decode())
+        self._h = h
+        self.device = int(device)
+        self.problem: Optional[L.Problem] = None
+        self._key = None
+        self.dtype = np.float32
+        self.batch = 0
+        self.state_shape: tuple = ()
+
+    # -- plumbing ---------------------------------------------------------------------------
+    def _check(self, rc: int):
+        if rc != L.OK:
+            msg = self._lib.pdeopt_last_error(self._h).decode()
+            if rc == L.EINVAL:
+                raise ValueError(msg)
+            raise L.PdeoptError(rc, msg)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.pdeopt_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def last_kernel(self) -> str:
+        return self._lib.pdeopt_last_kernel(self._h).decode()
+
+    def set_kernel_path(self, path: int):
+        self._check(self._lib.pdeopt_set_option(self._h, L.OPT_KERNEL_PATH, int(path)))
+
+    # -- problem ----------------------------------------------------------------------------
+    def configure(
+        self,
+        equation: int,
+        dtype,
+        nx: int,
+        ny: int,
+        batch: int,
+        hx: float,
+        hy: float,
+        kappa: float = 0.0,
+        mu: Optional[ClosureDesc] = None,
+        mob: Optional[ClosureDesc] = None,
+        gpe_k: float = 0.0,
+    ):
+        p = L.Problem()
+        p.equation, p.dtype = int(equation), L.dtype_code(dtype)
+        p.nx, p.ny, p.batch = int(nx), int(ny), int(batch)
+        p.hx, p.hy, p.kappa, p.gpe_k = float(hx), float(hy), float(kappa), float(gpe_k)
+        p.mu, p.mob = _closure_struct(mu), _closure_struct(mob)
+        self._check(self._lib.pdeopt_configure(self._h, C.byref(p)))
+        self.problem = p
+        self.dtype = L.np_dtype(p.dtype)
+        self.batch = int(batch)
+        comps = (2,) if equation == L.EQ_GPE else ()
+        self.state_shape = (int(nx), int(ny)) + comps
+
+    def set_env_params(self, env_first: int, kappa=None, mu_coef=None, mob_coef=None):
+        """Per-environment control parameters (kappa and closure coefficient VALUES)."""
+        count = None
+        bufs = []
+        for arr, width in ((kappa, None), (mu_coef, L.MAX_COEF), (mob_coef, L.MAX_COEF)):
+            if arr is None:
+                bufs.append(None)
+                continue
+            a = np.asarray(arr, dtype=np.float64)
+            if width is not None:
+                a = np.atleast_2d(a)
+                pad = np.zeros((a.shape[0], width))
+                pad[:, : a.shape[1]] = a
+                a = pad
+            else:
+                a = np.atleast_1d(a)
+            a = np.ascontiguousarray(a)
+            count = a.shape[0] if count is None else count
+            if a.shape[0] != count:
+                raise ValueError("per-environment parameter arrays disagree on the number of environments")
+            bufs.append(a)
+        if count is None:
+            return
+        ptrs = [b.ctypes.data_as(C.c_void_p) if b is not None else None for b in bufs]
+        self._check(self._lib.pdeopt_set_env_params(self._h, int(env_first), int(count), *ptrs))
+
+    def set_aux(self, which: int, field, per_env: bool = False):
+        cplx = which in (L.AUX_IMEX_SYMBOL, L.AUX_GPE_A_TERM)
+        p = self.problem
+        if cplx:
+            a = np.asarray(field, dtype=np.complex128 if self.dtype == np.float64 else np.complex64)
+        else:
+            a = np.asarray(field, dtype=self.dtype)
+        want = ((p.batch,) if per_env else ()) + (p.nx, p.ny)
+        if a.shape != want:
+            a = np.broadcast_to(a, want)
+        a = np.ascontiguousarray(a)
+        self._check(self._lib.pdeopt_set_aux(self._h, int(which), a.ctypes.data_as(C.c_void_p), int(per_env)))
+
+    def set_integrator_params(self, imex_A=0.5, time_scale=1.0, strang_dx=1.0):
+        ts = complex(time_scale)
+        self._check(
+            self._lib.pdeopt_set_integrator_params(self._h, float(imex_A), ts.real, ts.imag, float(strang_dx))
+        )
+
+    # -- state ------------------------------------------------------------------------------
+    def set_state(self, state, env_first: int = 0):
+        a = np.ascontiguousarray(np.asarray(state, dtype=self.dtype))
+        if a.shape == self.state_shape:
+            a = a[None]
+        if a.shape[1:] != self.state_shape:
+            raise ValueError(f"state shape {a.shape} does not match (batch,)+{self.state_shape}")
+        self._check(self._lib.pdeopt_set_state(self._h, int(env_first), a.shape[0], a.ctypes.data_as(C.c_void_p)))
+
+    def get_state(self, env_first: int = 0, env_count: Optional[int] = None) -> np.ndarray:
+        n = self.batch - env_first if env_count is None else env_count
+        out = np.empty((n,) + self.state_shape, dtype=self.dtype)
+        self._check(self._lib.pdeopt_get_state(self._h, int(env_first), int(n), out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def state_device_ptr(self):
+        p, nbytes = C.c_void_p(), C.c_int64()
+        self._check(self._lib.pdeopt_state_device_ptr(self._h, C.byref(p), C.byref(nbytes)))
+        return p.value, nbytes.value
+
+    # -- compute ----------------------------------------------------------------------------
+    def rhs(self, t: float = 0.0, fetch: bool = True) -> Optional[np.ndarray]:
+        out = np.empty((self.batch,) + self.state_shape, dtype=self.dtype) if fetch else None
+        ptr = out.ctypes.data_as(C.c_void_p) if fetch else None
+        self._check(self._lib.pdeopt_rhs(self._h, float(t), ptr))
+        return out
+
+    def advance(self, integrator: int, dt: float, n_substeps: int, t0: float = 0.0):
+        self._check(self._lib.pdeopt_advance(self._h, int(integrator), float(t0), float(dt), int(n_substeps)))
+
+    def snapshot(self):
+        self._check(self._lib.pdeopt_snapshot(self._h))
+
+    def get_interpolated(self, theta: float, env_first: int = 0, env_count: Optional[int] = None):
+        n = self.batch - env_first if env_count is None else env_count
+        out = np.empty((n,) + self.state_shape, dtype=self.dtype)
+        self._check(
+            self._lib.pdeopt_get_interpolated(self._h, float(theta), int(env_first), int(n), out.ctypes.data_as(C.c_void_p))
+        )
+        return out
+
+    def reduce(self, op: int) -> np.ndarray:
+        out = np.empty(self.batch, dtype=np.float64)
+        self._check(self._lib.pdeopt_reduce(self._h, int(op), out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def tsit5_trial(self, t: float, dt: float, rtol: float, atol: float) -> np.ndarray:
+        err = np.empty(self.batch, dtype=np.float64)
+        self._check(
+            self._lib.pdeopt_tsit5_trial(self._h, float(t), float(dt), float(rtol), float(atol), err.ctypes.data_as(C.c_void_p))
+        )
+        return err
+
+    def tsit5_commit(self, accept: bool):
+        self._check(self._lib.pdeopt_tsit5_commit(self._h, int(bool(accept))))
+
+    def sync(self):
+        self._check(self._lib.pdeopt_sync(self._h))
+
+    def timer_start(self):
+        self._check(self._lib.pdeopt_timer_start(self._h))
+
+    def timer_stop(self) -> float:
+        ms = C.c_double()
+        self._check(self._lib.pdeopt_timer_stop(self._h, C.byref(ms)))
+        return ms.value
+
+
+_default_engines: dict = {}
+
+
+def default_engine(device: int = 0) -> HipEngine:
+    """Process-wide engine per device, shared by equation objects that only need ``rhs``."""
+    eng = _default_engines.get(device)
+    if eng is None:
+        eng = _default_engines[device] = HipEngine(device)
+    return eng

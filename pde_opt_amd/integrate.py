@@ -1,0 +1,211 @@
+"""``diffeqsolve``: the stepping loop of the reference (third-party ``diffrax.diffeqsolve``, call
+sites pde_opt/pde_env.py:293-303, pde_opt/pde_model.py:120-134) driven on the GPU.
+
+Constant stepping: ``n_full`` substeps of exactly ``dt0`` plus one clipped final substep, issued
+as at most a few ``pdeopt_advance`` calls (the per-substep loop lives in the library, so an
+environment step costs one Python->C transition, not one per substep).  ``SaveAt(ts=...)`` uses
+the linear dense output the reference's custom solvers declare (``LocalLinearInterpolation``,
+numerics/solvers.py:48,91): steps never stop at save points.
+
+Adaptive stepping (``Tsit5`` + ``PIDController``): trial steps and the scaled RMS error norm run
+on the GPU (``pdeopt_tsit5_trial``); the scalar PID update runs here.  With a batch, all
+environments share the step (the controller sees the worst error norm).
+"""
+
+from __future__ import annotations
+
+import dataclasses
+import math
+from typing import Optional
+
+import numpy as np
+
+from . import _lib as L
+from .engine import HipEngine
+from .numerics.solvers import ConstantStepSize, PIDController, SaveAt
+
+
+@dataclasses.dataclass
+class Solution:
+    ts: np.ndarray
+    ys: np.ndarray
+    stats: dict
+
+
+def constant_step_plan(t0, t1, dt, rel_tol=1e-9):
+    """(n_full, remainder) of ``while t < t1: t = min(t + dt, t1)``; remainders below
+    ``rel_tol*dt`` (floating-point dust of the accumulated time upstream) are dropped."""
+    span = float(t1) - float(t0)
+    if span <= 0:
+        return 0, 0.0
+    if not dt > 0:
+        raise ValueError("dt0 must be positive")
+    n_full = int(math.floor(span / dt + rel_tol))
+    rem = span - n_full * dt
+    if rem <= rel_tol * dt:
+        rem = 0.0
+    return n_full, rem
+
+
+def _prepare(equation, solver, y0, engine: Optional[HipEngine], t_aux: float):
+    y0 = np.asarray(y0)
+    if np.iscomplexobj(y0):
+        raise ValueError("complex states are stored as (..., 2) real/imag pairs (gross_pitaevskii.py:75)")
+    if y0.dtype not in (np.float32, np.float64):
+        y0 = y0.astype(np.float64)
+    nd = 2 + len(equation._state_trailing)
+    single = y0.ndim == nd
+    yb = y0[None] if single else y0
+    if yb.ndim != nd + 1 or tuple(yb.shape[1:3]) != tuple(equation.domain.points):
+        raise ValueError(f"y0 shape {y0.shape} does not match domain points {equation.domain.points}")
+    if engine is None:
+        from .engine import default_engine
+
+        engine = default_engine()
+    engine.configure(dtype=yb.dtype, batch=yb.shape[0], **equation._engine_problem())
+    equation._engine_upload(engine, t_aux)
+    solver.configure_engine(engine, equation)
+    engine.set_state(yb)
+    return engine, single
+
+
+def diffeqsolve(
+    equation,
+    solver,
+    t0,
+    t1,
+    dt0,
+    y0,
+    saveat: Optional[SaveAt] = None,
+    stepsize_controller=None,
+    max_steps: Optional[int] = 1_000_000,
+    throw: bool = True,
+    engine: Optional[HipEngine] = None,
+    args=None,
+):
+    """Integrate ``equation`` from ``t0`` to ``t1`` on the GPU.  ``y0`` is one field ``(nx, ny)``
+    or a batch ``(B, nx, ny)``; ``ys`` gains a leading save axis like ``solution.ys`` upstream."""
+    saveat = saveat or SaveAt(t1=True)
+    controller = stepsize_controller or ConstantStepSize()
+    t0, t1 = float(t0), float(t1)
+    eng, single = _prepare(equation, solver, y0, engine, t0)
+    take = (lambda a: a[0]) if single else (lambda a: a)
+
+    if isinstance(controller, PIDController):
+        return _solve_adaptive(eng, equation, solver, t0, t1, float(dt0), saveat, controller, max_steps, throw, take)
+
+    dt = float(dt0)
+    n_full, rem = constant_step_plan(t0, t1, dt)
+    total_steps = n_full + (1 if rem > 0 else 0)
+    if max_steps is not None and total_steps > max_steps:
+        if throw:
+            raise RuntimeError(f"max_steps={max_steps} reached ({total_steps} steps needed)")
+        total_steps = max_steps
+        n_full, rem = min(n_full, max_steps), 0.0
+
+    def advance_steps(first, count):
+        """advance `count` steps starting at step index `first`"""
+        full = max(0, min(first + count, n_full) - first)
+        if full:
+            eng.advance(solver.integrator, dt, full, t0 + first * dt)
+        if first + count > n_full and rem > 0:
+            eng.advance(solver.integrator, rem, 1, t0 + n_full * dt)
+
+    def edge(i):  # time at the end of step i-1 / start of step i
+        return t1 if i >= total_steps else t0 + i * dt
+
+    ts_out, ys_out = [], []
+    done = 0
+    if saveat.t0:
+        ts_out.append(t0)
+        ys_out.append(take(eng.get_state()))
+    if saveat.ts is not None:
+        for tq in [float(t) for t in saveat.ts]:
+            # step index k with edge(k) < tq <= edge(k+1)
+            if tq <= t0 or total_steps == 0:
+                k_end = 0
+            else:
+                k_end = min(total_steps, max(1, int(math.ceil((tq - t0) / dt - 1e-9))))
+            if k_end == 0 or abs(edge(k_end) - tq) <= 1e-12 * max(1.0, abs(tq)):
+                advance_steps(done, k_end - done)
+                done = k_end
+                ys_out.append(take(eng.get_state()))
+            else:
+                advance_steps(done, (k_end - 1) - done)
+                done = k_end - 1
+                eng.snapshot()
+                advance_steps(done, 1)
+                done = k_end
+                a, b = edge(k_end - 1), edge(k_end)
+                ys_out.append(take(eng.get_interpolated((tq - a) / (b - a))))
+            ts_out.append(tq)
+    if saveat.t1 or saveat.ts is None:
+        advance_steps(done, total_steps - done)
+        done = total_steps
+        ts_out.append(t1)
+        ys_out.append(take(eng.get_state()))
+    stats = {"num_steps": total_steps, "num_accepted_steps": total_steps, "num_rejected_steps": 0,
+             "kernel": eng.last_kernel}
+    return Solution(np.asarray(ts_out), np.stack(ys_out), stats)
+
+
+def _solve_adaptive(eng, equation, solver, t0, t1, dt0, saveat, c: PIDController, max_steps, throw, take):
+    if solver.integrator != L.INT_TSIT5:
+        raise ValueError("PIDController needs an embedded pair: use Tsit5")
+    order = 5.0
+    t, dt = t0, dt0
+    accepted = rejected = 0
+    ts_req = [float(v) for v in saveat.ts] if saveat.ts is not None else []
+    ts_out, ys_out = [], []
+    qi = 0
+    while qi < len(ts_req) and ts_req[qi] <= t0:
+        ts_out.append(ts_req[qi]); ys_out.append(take(eng.get_state())); qi += 1
+    if saveat.t0:
+        ts_out.append(t0); ys_out.append(take(eng.get_state()))
+    prev_inv = prev_prev_inv = 1.0
+    while t < t1:
+        if max_steps is not None and accepted + rejected >= max_steps:
+            if throw:
+                raise RuntimeError(f"max_steps={max_steps} reached at t={t}")
+            break
+        h = min(dt, t1 - t)
+        if qi < len(ts_req):
+            eng.snapshot()
+        err = float(np.max(eng.tsit5_trial(t, h, c.rtol, c.atol)))
+        keep = bool(err < 1.0)  # NaN error norm rejects
+        inv = 1.0 / err if err > 0 and math.isfinite(err) else (np.inf if err == 0 else 0.0)
+        k1 = (c.icoeff + c.pcoeff + c.dcoeff) / order
+        k2 = -(c.pcoeff + 2 * c.dcoeff) / order
+        k3 = c.dcoeff / order
+        f = 1.0
+        for base, expo in ((inv, k1), (prev_inv, k2), (prev_prev_inv, k3)):
+            if expo != 0.0:
+                f *= (base**expo) if math.isfinite(base) and base > 0 else (c.factormax if base > 0 else c.factormin)
+        f = min(c.factormax, max(c.factormin, c.safety * f))
+        if not keep:
+            f = min(1.0, f)
+        eng.tsit5_commit(keep)
+        if keep:
+            accepted += 1
+            t_new = t + h
+            # dense output: linear between accepted step end points (the reference's custom
+            # solvers declare LocalLinearInterpolation; diffrax.Tsit5 ships a 4th-order
+            # interpolant -- documented deviation, O(h^2) at interior save points only)
+            while qi < len(ts_req) and ts_req[qi] <= t_new + 1e-14 * max(1.0, abs(t_new)):
+                th = (ts_req[qi] - t) / h
+                ys_out.append(take(eng.get_interpolated(min(1.0, max(0.0, th)))))
+                ts_out.append(ts_req[qi]); qi += 1
+            t = t_new if t_new < t1 - 1e-14 * max(1.0, abs(t1)) else t1
+            prev_prev_inv, prev_inv = prev_inv, inv
+        else:
+            rejected += 1
+        dt = h * f
+        if c.dtmin is not None:
+            dt = max(dt, c.dtmin)
+        if c.dtmax is not None:
+            dt = min(dt, c.dtmax)
+    if saveat.t1 or saveat.ts is None:
+        ts_out.append(t); ys_out.append(take(eng.get_state()))
+    stats = {"num_steps": accepted + rejected, "num_accepted_steps": accepted, "num_rejected_steps": rejected,
+             "kernel": eng.last_kernel}
+    return Solution(np.asarray(ts_out), np.stack(ys_out), stats)

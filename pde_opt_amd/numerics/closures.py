@@ -1,0 +1,207 @@
+"""Pointwise closures mu(u), D(u), R(u): from Python callables to the in-kernel family.
+
+Upstream these are arbitrary Python callables traced by ``jax.jit`` into the RHS (dataclass
+fields pde_opt/numerics/equations/cahn_hilliard.py:51-54, allen_cahn.py:47-50).  A HIP kernel
+needs a closed family; the one implemented (include/pdeopt_hip.h) is
+
+    f(c) = series(c) [+ log(c / (1 - c))]  [then exp(.)]
+
+with ``series`` a polynomial in ``c`` or a Legendre series in ``2c - 1``.  ``as_closure`` turns a
+user callable into a descriptor by evaluating it once on a symbolic variable (sympy) and matching
+the result against that family; anything else (CNN / MLP-Mixer closures are not pointwise) is
+rejected with ``UnsupportedClosureError`` instead of silently running somewhere slower.
+"""
+
+from __future__ import annotations
+
+import dataclasses
+import numbers
+from typing import Callable, Sequence
+
+import numpy as np
+
+POLY, LEGENDRE = 0, 1
+LOGIT_PRIOR, EXP_WRAP = 1, 2
+MAX_COEF = 16
+
+
+class UnsupportedClosureError(ValueError):
+    pass
+
+
+@dataclasses.dataclass(frozen=True)
+class ClosureDesc:
+    """A member of the in-kernel closure family.  Callable on numpy arrays (host utility only)."""
+
+    kind: int = POLY
+    flags: int = 0
+    coef: tuple = (0.0,)
+
+    def __post_init__(self):
+        if not 1 <= len(self.coef) <= MAX_COEF:
+            raise UnsupportedClosureError(
+                f"closure needs 1..{MAX_COEF} coefficients, got {len(self.coef)}"
+            )
+
+    def __call__(self, c):
+        c = np.asarray(c)
+        if self.kind == POLY:
+            r = np.zeros_like(c) + self.coef[-1]
+            for a in self.coef[-2::-1]:
+                r = r * c + a
+        else:
+            r = np.polynomial.legendre.legval(2.0 * c - 1.0, np.asarray(self.coef))
+        if self.flags & LOGIT_PRIOR:
+            r = r + np.log(c / (1 - c))
+        if self.flags & EXP_WRAP:
+            r = np.exp(r)
+        return r
+
+    def with_coef(self, coef: Sequence[float]) -> "ClosureDesc":
+        return dataclasses.replace(self, coef=tuple(float(v) for v in coef))
+
+
+def polynomial(*coef: float, logit_prior: bool = False) -> ClosureDesc:
+    """``sum_k coef[k] c^k`` (+ ``log(c/(1-c))``)."""
+    return ClosureDesc(POLY, LOGIT_PRIOR if logit_prior else 0, tuple(float(v) for v in coef))
+
+
+def constant(v: float) -> ClosureDesc:
+    return polynomial(v)
+
+
+# ----------------------------------------------------------------------------------------------
+# symbolic tracing of user callables
+# ----------------------------------------------------------------------------------------------
+
+
+class _Sym:
+    """Stand-in for an array during tracing: arithmetic and numpy ufuncs build a sympy expr."""
+
+    __array_priority__ = 1000
+
+    def __init__(self, expr):
+        self.e = expr
+
+    @staticmethod
+    def _u(x):
+        return x.e if isinstance(x, _Sym) else x
+
+    def _bin(self, other, op):
+        import sympy as sp
+
+        o = self._u(other)
+        if isinstance(o, np.ndarray):
+            if o.ndim == 0:
+                o = float(o)
+            else:
+                raise UnsupportedClosureError("closures may only combine the field with scalars")
+        if isinstance(o, numbers.Real) and not isinstance(o, bool):
+            o = sp.Rational(float(o))  # exact value of the double: coefficients round-trip
+        return _Sym(op(self.e, o))
+
+    def __add__(self, o): return self._bin(o, lambda a, b: a + b)
+    def __radd__(self, o): return self._bin(o, lambda a, b: b + a)
+    def __sub__(self, o): return self._bin(o, lambda a, b: a - b)
+    def __rsub__(self, o): return self._bin(o, lambda a, b: b - a)
+    def __mul__(self, o): return self._bin(o, lambda a, b: a * b)
+    def __rmul__(self, o): return self._bin(o, lambda a, b: b * a)
+    def __truediv__(self, o): return self._bin(o, lambda a, b: a / b)
+    def __rtruediv__(self, o): return self._bin(o, lambda a, b: b / a)
+    def __pow__(self, o): return self._bin(o, lambda a, b: a**b)
+    def __neg__(self): return _Sym(-self.e)
+    def __pos__(self): return self
+
+    # numpy protocol: np.log(sym), np.exp(sym), np.ones_like(sym), ...
+    def __array_ufunc__(self, ufunc, method, *inputs, **kwargs):
+        import sympy as sp
+
+        if method != "__call__":
+            raise UnsupportedClosureError(f"numpy ufunc method {method} is not traceable")
+        name = ufunc.__name__
+        a = [self._u(x) for x in inputs]
+        table = {
+            "log": lambda x: sp.log(x), "exp": lambda x: sp.exp(x), "negative": lambda x: -x,
+            "square": lambda x: x**2, "sqrt": lambda x: sp.sqrt(x), "positive": lambda x: x,
+            "add": lambda x, y: x + y, "subtract": lambda x, y: x - y, "multiply": lambda x, y: x * y,
+            "divide": lambda x, y: x / y, "true_divide": lambda x, y: x / y, "power": lambda x, y: x**y,
+            "reciprocal": lambda x: 1 / x,
+        }
+        if name not in table:
+            raise UnsupportedClosureError(f"numpy.{name} is outside the supported closure family")
+        return _Sym(table[name](*a))
+
+    def __array_function__(self, func, types, args, kwargs):
+        import sympy as sp
+
+        if func is np.ones_like:
+            return _Sym(sp.Integer(1))
+        if func is np.zeros_like:
+            return _Sym(sp.Integer(0))
+        if func is np.full_like:
+            return _Sym(sp.Rational(float(args[1])))
+        raise UnsupportedClosureError(f"numpy.{func.__name__} is outside the supported closure family")
+
+    # jnp-style helpers commonly used inside closures
+    def log(self): return np.log(self)
+    def exp(self): return np.exp(self)
+
+
+def _match(expr, c):
+    import sympy as sp
+
+    flags = 0
+    e = sp.expand(sp.expand_log(sp.sympify(expr), force=True))
+    if e.has(sp.exp):
+        # exp(series): log of the expression must collapse to a polynomial
+        inner = sp.expand(sp.expand_log(sp.log(e), force=True))
+        if inner.is_polynomial(c) and not inner.has(sp.log) and not inner.has(sp.exp):
+            flags |= EXP_WRAP
+            e = inner
+    logit = sp.log(c) - sp.log(1 - c)
+    for candidate_flags, cand in ((0, e), (LOGIT_PRIOR, sp.expand(e - logit))):
+        # logs written as log(1 - c) or log(-(c - 1)) etc. must cancel exactly to count
+        if cand.is_polynomial(c) and not cand.has(sp.log):
+            poly = sp.Poly(cand, c)
+            coef = [float(v) for v in reversed(poly.all_coeffs())]
+            if len(coef) > MAX_COEF:
+                raise UnsupportedClosureError(
+                    f"polynomial degree {len(coef) - 1} exceeds the in-kernel limit {MAX_COEF - 1}"
+                )
+            return ClosureDesc(POLY, flags | candidate_flags, tuple(coef))
+    raise UnsupportedClosureError(
+        "closure is outside the in-kernel family  f(c) = poly(c) [+ log(c/(1-c))] [exp]  /  "
+        f"Legendre series; traced expression: {expr}.  Pass a ClosureDesc, a Legendre closure "
+        "object, or restructure the callable (non-pointwise closures such as CNNs are out of scope)."
+    )
+
+
+def as_closure(fn) -> ClosureDesc:
+    """Descriptor for a user closure: ``ClosureDesc``, number, Legendre object or callable."""
+    if isinstance(fn, ClosureDesc):
+        return fn
+    if hasattr(fn, "closure_desc"):
+        return fn.closure_desc()
+    if isinstance(fn, numbers.Real):
+        return constant(float(fn))
+    if not callable(fn):
+        raise UnsupportedClosureError(f"cannot interpret {fn!r} as a pointwise closure")
+    import sympy as sp
+
+    c = sp.Symbol("c", real=True)
+    try:
+        out = fn(_Sym(c))
+    except UnsupportedClosureError:
+        raise
+    except Exception as e:  # the callable did something the tracer cannot follow
+        raise UnsupportedClosureError(
+            f"could not trace closure {fn!r} symbolically ({type(e).__name__}: {e}); "
+            "use operators / numpy ufuncs (np.log, np.exp) on the argument, or pass a ClosureDesc"
+        ) from e
+    if isinstance(out, _Sym):
+        return _match(out.e, c)
+    if isinstance(out, numbers.Real):
+        return constant(float(out))
+    if isinstance(out, np.ndarray) and out.ndim == 0:
+        return constant(float(out))
+    raise UnsupportedClosureError(f"closure returned {type(out).__name__}, expected an array expression")

@@ -1,0 +1,15 @@
+"""PDE equation classes backed by the HIP engine."""
+
+from .advection_diffusion import AdvectionDiffusion2D
+from .base_eq import BaseEquation, TimeSplittingEquation
+from .gross_pitaevskii import GPE2DTSControl
+from .phase_field import AllenCahn2DPeriodic, CahnHilliard2DPeriodic
+
+__all__ = [
+    "BaseEquation",
+    "TimeSplittingEquation",
+    "AllenCahn2DPeriodic",
+    "CahnHilliard2DPeriodic",
+    "AdvectionDiffusion2D",
+    "GPE2DTSControl",
+]

@@ -1,0 +1,293 @@
+"""PDEEnv: the reference's Gymnasium environment (pde_opt/pde_env.py:22-317) on the HIP engine.
+
+Same constructor (16 arguments, same names and order), same ``reset(seed, options)`` /
+``step(action)`` contract, same attributes (``_state``, ``_time``, ``_control_value``,
+``observation_space``, ``action_space``) and the same quirks that are semantics rather than
+implementation: integration time restarts at 0 every environment step, the
+observation space is declared ``Box(0, 255, (1, *points), uint8)`` whatever the observation
+function returns, parameters may change every step.
+
+What is NOT reproduced is the cost model: upstream rebuilds the equation, the solver and a fresh
+``jax.jit`` closure per step (:286-294).  Here the equation object is rebuilt only when its
+parameters change (cheap: host dataclass) and ``diffeqsolve`` is one ``pdeopt_advance`` call.
+
+``VectorPDEEnv`` (new) advances B independent episodes in lock step in one batched kernel launch
+per Runge-Kutta stage; per-environment control parameters travel with the environment.
+"""
+
+from __future__ import annotations
+
+from typing import Any, Callable, Dict, Optional, Sequence, Type
+
+import numpy as np
+
+from . import _lib as L
+from .engine import HipEngine
+from .integrate import diffeqsolve
+from .numerics import domains
+from .numerics.equations import BaseEquation
+from .numerics.solvers import SaveAt
+from .spaces import HAVE_GYMNASIUM, Box, Discrete, EnvBase
+from .utils import check_equation_solver_compatibility, prepare_solver_params
+
+if HAVE_GYMNASIUM:  # pragma: no cover
+    from gymnasium.envs.registration import register, registry
+
+    if "PDEEnv-v0" not in registry:
+        register(id="PDEEnv-v0", entry_point="pde_opt_amd.pde_env:PDEEnv")
+
+
+class PDEEnv(EnvBase):
+    """Reinforcement-learning environment that controls one parameter of a PDE."""
+
+    def __init__(
+        self,
+        equation_type: Type[BaseEquation],
+        domain: domains.Domain,
+        solver_type,
+        end_time: float,
+        step_dt: float,
+        numeric_dt: float,
+        state_to_observation_func: Callable,
+        reward_function: Callable,
+        reset_func: Callable,
+        reset_control_value,
+        update_control_value: Callable,
+        update_control_parameter: Callable,
+        action_space_config: Dict[str, Any],
+        static_equation_parameters: Dict[str, Any],
+        control_equation_parameter_name: str,
+        solver_parameters: Dict[str, Any],
+        device: int = 0,
+    ):
+        if HAVE_GYMNASIUM:  # pragma: no cover
+            super().__init__()
+        self.equation_type = equation_type
+        self.domain = domain
+        self.solver_type = solver_type
+        check_equation_solver_compatibility(self.solver_type, self.equation_type)
+
+        self.end_time = end_time
+        self.step_dt = step_dt
+        self.numeric_dt = numeric_dt
+        self.reward_function = reward_function
+        self.reset_func = reset_func
+        self.state_to_observation_func = state_to_observation_func
+
+        self.observation_space = Box(low=0.0, high=255.0, shape=(1, *self.domain.points), dtype=np.uint8)
+        self._setup_action_space(action_space_config)
+
+        self.reset_control_value = reset_control_value
+        self.update_control_value = update_control_value
+        self.update_control_parameter = update_control_parameter
+        self.static_equation_parameters = static_equation_parameters
+        self.control_equation_parameter_name = control_equation_parameter_name
+        self.solver_parameters = solver_parameters
+
+        self._engine = HipEngine(device)  # raises HipUnavailableError without a GPU / library
+        self._state = None
+        self._time = 0.0
+        self._control_value = reset_control_value
+
+    # ------------------------------------------------------------------------------------
+    def _setup_action_space(self, config: Dict[str, Any]):
+        if config.get("type", "continuous") == "discrete":
+            self.action_space = Discrete(config.get("num_actions", 5))
+            self._action_to_direction = config.get("action_mapping", {})
+        else:
+            self.action_space = Box(
+                low=config.get("low", -1.0), high=config.get("high", 1.0), shape=config.get("shape", (2,))
+            )
+            self._action_to_direction = None
+
+    def _get_obs(self):
+        return self.state_to_observation_func(self._state)
+
+    def _get_info(self):
+        return {}
+
+    def _terminate(self):
+        return self._time >= self.end_time
+
+    # ------------------------------------------------------------------------------------
+    def reset(self, seed: Optional[int] = None, options: Optional[dict] = None):
+        if seed is not None:
+            self._state = np.asarray(self.reset_func(self.domain, seed=seed))
+        else:
+            self._state = np.asarray(self.reset_func(self.domain))
+        self._time = 0.0
+        self._control_value = self.reset_control_value
+        return self._get_obs(), self._get_info()
+
+    def step(self, action):
+        offset = action if not self._action_to_direction else self._action_to_direction[action]
+        old_control_value = self._control_value
+        self._control_value = self.update_control_value(offset, old_control_value)
+        control_parameter = self.update_control_parameter(old_control_value, self._control_value)
+
+        params = {**self.static_equation_parameters, self.control_equation_parameter_name: control_parameter}
+        eq = self.equation_type(domain=self.domain, **params)
+        solver = self.solver_type(**prepare_solver_params(self.solver_type, self.solver_parameters, eq))
+
+        # local time restarts at 0 every environment step, as upstream (pde_env.py:296-297)
+        solution = diffeqsolve(
+            eq, solver, t0=0.0, t1=self.step_dt, dt0=self.numeric_dt, y0=self._state,
+            saveat=SaveAt(t1=True), max_steps=1_000_000, engine=self._engine,
+        )
+        self._state = solution.ys[-1]
+        self._time += self.step_dt
+
+        obs = self._get_obs()
+        reward = self.reward_function(self._state)
+        return obs, reward, self._terminate(), False, self._get_info()
+
+    def close(self):
+        self._engine.close()
+
+
+class VectorPDEEnv:
+    """B independent PDEEnv episodes advanced in lock step on one GPU (new capability).
+
+    Semantics per environment are exactly ``PDEEnv``'s.  ``step(actions)`` takes one action per
+    environment; the control parameter of environment b must be a number or map onto closure
+    *coefficients* (same closure structure across the batch), so the whole batch runs in one
+    launch per stage with per-environment coefficient tables.
+
+    ``reward`` / observations: ``reward_function`` and ``state_to_observation_func`` are applied
+    per environment on host copies unless ``device_reward`` names an on-device reduction
+    (``"var"``, ``"mean"``, ``"min"``, ``"max"``), which avoids the D2H of full fields.
+    """
+
+    def __init__(
+        self,
+        num_envs: int,
+        equation_type,
+        domain,
+        solver_type,
+        end_time,
+        step_dt,
+        numeric_dt,
+        state_to_observation_func,
+        reward_function,
+        reset_func,
+        reset_control_value,
+        update_control_value,
+        update_control_parameter,
+        action_space_config,
+        static_equation_parameters,
+        control_equation_parameter_name,
+        solver_parameters,
+        device: int = 0,
+        device_reward: Optional[str] = None,
+        fetch_observations: bool = True,
+    ):
+        self.num_envs = int(num_envs)
+        self.equation_type, self.domain, self.solver_type = equation_type, domain, solver_type
+        check_equation_solver_compatibility(solver_type, equation_type)
+        self.end_time, self.step_dt, self.numeric_dt = end_time, step_dt, numeric_dt
+        self.state_to_observation_func = state_to_observation_func
+        self.reward_function = reward_function
+        self.reset_func = reset_func
+        self.reset_control_value = reset_control_value
+        self.update_control_value = update_control_value
+        self.update_control_parameter = update_control_parameter
+        self.static_equation_parameters = static_equation_parameters
+        self.control_equation_parameter_name = control_equation_parameter_name
+        self.solver_parameters = solver_parameters
+        self.device_reward = device_reward
+        self.fetch_observations = fetch_observations
+        self.single_observation_space = Box(low=0.0, high=255.0, shape=(1, *domain.points), dtype=np.uint8)
+        cfg = action_space_config
+        if cfg.get("type", "continuous") == "discrete":
+            self.single_action_space = Discrete(cfg.get("num_actions", 5))
+            self._action_to_direction = cfg.get("action_mapping", {})
+        else:
+            self.single_action_space = Box(low=cfg.get("low", -1.0), high=cfg.get("high", 1.0), shape=cfg.get("shape", (2,)))
+            self._action_to_direction = None
+        self._engine = HipEngine(device)
+        self._configured_key = None
+        self._time = np.zeros(self.num_envs)
+        self._control_value = [reset_control_value] * self.num_envs
+        self._state_host = None
+
+    _RED = {"mean": L.RED_MEAN, "var": L.RED_VAR, "min": L.RED_MIN, "max": L.RED_MAX}
+
+    def _equation_for(self, control_parameter):
+        params = {**self.static_equation_parameters, self.control_equation_parameter_name: control_parameter}
+        return self.equation_type(domain=self.domain, **params)
+
+    def reset(self, seed: Optional[int] = None, options=None):
+        states = []
+        for b in range(self.num_envs):
+            s = self.reset_func(self.domain, seed=seed + b) if seed is not None else self.reset_func(self.domain)
+            states.append(np.asarray(s))
+        self._y0 = np.stack(states)
+        self._time[:] = 0.0
+        self._control_value = [self.reset_control_value] * self.num_envs
+        self._configured_key = None
+        self._state_host = self._y0
+        obs = [self.state_to_observation_func(s) for s in self._y0]
+        return np.stack(obs), {}
+
+    def _configure(self, eqs):
+        eq0 = eqs[0]
+        prob = eq0._engine_problem()
+        y0 = self._y0 if self._y0.dtype in (np.float32, np.float64) else self._y0.astype(np.float64)
+        key = (prob["equation"], y0.dtype.str, prob["nx"], prob["ny"],
+               getattr(prob.get("mu"), "kind", None), getattr(prob.get("mu"), "flags", None),
+               len(getattr(prob.get("mu"), "coef", ())), getattr(prob.get("mob"), "kind", None),
+               getattr(prob.get("mob"), "flags", None), len(getattr(prob.get("mob"), "coef", ())))
+        if key != self._configured_key:
+            self._engine.configure(dtype=y0.dtype, batch=self.num_envs, **prob)
+            self._engine.set_state(y0)
+            self._configured_key = key
+        # per-environment parameter values
+        kappa = [e._engine_problem().get("kappa", 0.0) for e in eqs]
+        mu = [e._engine_problem()["mu"].coef for e in eqs] if prob.get("mu") is not None else None
+        mob = [e._engine_problem()["mob"].coef for e in eqs] if prob.get("mob") is not None else None
+        for e in eqs[1:]:
+            p = e._engine_problem()
+            for name in ("mu", "mob"):
+                a, b = prob.get(name), p.get(name)
+                if (a is None) != (b is None) or (a is not None and (a.kind, a.flags, len(a.coef)) != (b.kind, b.flags, len(b.coef))):
+                    raise ValueError("all environments of a VectorPDEEnv must share the closure structure")
+        self._engine.set_env_params(0, kappa=kappa, mu_coef=mu, mob_coef=mob)
+        return eq0
+
+    def step(self, actions: Sequence):
+        from .integrate import constant_step_plan
+
+        eqs = []
+        for b, action in enumerate(actions):
+            offset = action if not self._action_to_direction else self._action_to_direction[action]
+            old = self._control_value[b]
+            self._control_value[b] = self.update_control_value(offset, old)
+            eqs.append(self._equation_for(self.update_control_parameter(old, self._control_value[b])))
+        eq0 = self._configure(eqs)
+        eq0._engine_upload(self._engine, 0.0)
+        solver = self.solver_type(**prepare_solver_params(self.solver_type, self.solver_parameters, eq0))
+        solver.configure_engine(self._engine, eq0)
+        n_full, rem = constant_step_plan(0.0, self.step_dt, self.numeric_dt)
+        if n_full:
+            self._engine.advance(solver.integrator, self.numeric_dt, n_full, 0.0)
+        if rem > 0:
+            self._engine.advance(solver.integrator, rem, 1, n_full * self.numeric_dt)
+        self._time += self.step_dt
+        if self.device_reward is not None:
+            rewards = self._engine.reduce(self._RED[self.device_reward])
+        if self.fetch_observations or self.device_reward is None:
+            self._state_host = self._engine.get_state()
+            obs = np.stack([self.state_to_observation_func(s) for s in self._state_host])
+        else:
+            obs = None
+        if self.device_reward is None:
+            rewards = np.asarray([self.reward_function(s) for s in self._state_host])
+        terminated = self._time >= self.end_time
+        return obs, rewards, terminated, np.zeros(self.num_envs, dtype=bool), {}
+
+    @property
+    def states(self):
+        return self._engine.get_state()
+
+    def close(self):
+        self._engine.close()

@@ -1,0 +1,103 @@
+"""PDEEnv / VectorPDEEnv protocol on the GPU (the reference has zero PDEEnv coverage; the
+protocol is taken from pde_opt/pde_env.py:217-317)."""
+import numpy as np
+import pytest
+
+import pde_opt_amd as P
+from oracle import np_oracle as O
+from util import MOB, MU, rel_l2, std_domain
+
+pytestmark = pytest.mark.gpu
+
+
+def _reset(domain, seed=0):
+    rng = np.random.default_rng(seed)
+    return np.clip(0.5 + 0.01 * rng.standard_normal(domain.points), 0.05, 0.95)
+
+
+def _env_kwargs(dom, solver_type=None, solver_parameters=None, step_dt=2e-6, numeric_dt=2e-7):
+    return dict(
+        equation_type=P.CahnHilliard2DPeriodic,
+        domain=dom,
+        solver_type=solver_type or P.RK4,
+        end_time=3 * step_dt,
+        step_dt=step_dt,
+        numeric_dt=numeric_dt,
+        state_to_observation_func=lambda s: np.clip(s * 255, 0, 255).astype(np.uint8)[None],
+        reward_function=lambda s: float(np.var(s)),
+        reset_func=_reset,
+        reset_control_value=0.002,
+        update_control_value=lambda off, old: old + off,
+        update_control_parameter=lambda old, new: new,
+        action_space_config={"type": "discrete", "num_actions": 3, "action_mapping": {0: -0.0005, 1: 0.0, 2: 0.0005}},
+        static_equation_parameters={"mu": MU["regsol"], "D": MOB["c1mc"]},
+        control_equation_parameter_name="kappa",
+        solver_parameters=solver_parameters or {},
+    )
+
+
+def test_pdeenv_protocol_and_parity():
+    dom = std_domain(P, 64, 128)
+    env = P.PDEEnv(**_env_kwargs(dom))
+    assert env.observation_space.shape == (1, 64, 128) and env.observation_space.dtype == np.uint8
+    assert env.action_space.n == 3
+    obs, info = env.reset(seed=3)
+    assert obs.shape == (1, 64, 128) and info == {}
+    assert env._time == 0.0 and env._control_value == 0.002
+    y = _reset(dom, seed=3)
+    hx, hy = dom.dx
+    kappas = []
+    terminated = False
+    steps = 0
+    for action in (2, 1, 0):
+        obs, reward, terminated, truncated, info = env.step(action)
+        steps += 1
+        kappas.append(env._control_value)
+        f = lambda t, u, kk=env._control_value: O.ch_rhs_fd(u, hx, hy, kk, MU["regsol"], MOB["c1mc"])
+        y = O.integrate(lambda t, u, dt: O.rk4_step(f, t, u, dt), y, 0.0, 2e-6, 2e-7)
+        assert truncated is False and info == {}
+        assert abs(reward - np.var(y)) < 1e-12
+        assert np.max(np.abs(env._state - y)) < 1e-12
+    np.testing.assert_allclose(kappas, [0.0025, 0.0025, 0.002])
+    assert terminated is True and abs(env._time - 6e-6) < 1e-18
+    env.close()
+
+
+def test_pdeenv_imex_solver_params():
+    dom = std_domain(P, 64, 64)
+    env = P.PDEEnv(**_env_kwargs(dom, P.SemiImplicitFourierSpectral, {"A": 0.5}, step_dt=1e-5, numeric_dt=1e-6))
+    env.reset(seed=1)
+    _, reward, _, _, _ = env.step(1)
+    y = _reset(dom, seed=1)
+    hx, hy = dom.dx
+    sym = O.ch_fourier_symbol(64, 64, hx, hy, 0.002)
+    rhs = lambda t, u: O.ch_rhs_fd(u, hx, hy, 0.002, MU["regsol"], MOB["c1mc"])
+    y = O.integrate(lambda t, u, dt: O.imex_step(rhs, t, u, dt, 0.5, sym), y, 0.0, 1e-5, 1e-6)
+    assert np.max(np.abs(env._state - y)) < 1e-12
+    with pytest.raises(ValueError, match="missing required"):
+        P.PDEEnv(**{**_env_kwargs(dom), "solver_type": P.StrangSplitting})
+    env.close()
+
+
+def test_vector_env_matches_single_envs():
+    dom = std_domain(P, 64, 128)
+    kw = _env_kwargs(dom)
+    venv = P.VectorPDEEnv(3, **kw, device_reward="var")
+    obs, _ = venv.reset(seed=10)
+    assert obs.shape == (3, 1, 64, 128)
+    singles = []
+    for b in range(3):
+        e = P.PDEEnv(**kw)
+        e.reset(seed=10 + b)
+        singles.append(e)
+    for actions in ([0, 1, 2], [2, 2, 0]):
+        obs, rewards, term, trunc, _ = venv.step(actions)
+        states = venv.states
+        for b, e in enumerate(singles):
+            o, r, t, _, _ = e.step(actions[b])
+            np.testing.assert_array_equal(states[b], e._state)  # bitwise: batching changes nothing
+            assert abs(rewards[b] - r) < 1e-15
+            assert bool(term[b]) == t
+    venv.close()
+    for e in singles:
+        e.close()

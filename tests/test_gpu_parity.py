@@ -1,0 +1,422 @@
+"""GPU parity tests: the HIP path (through the Python shims -> ctypes -> C ABI) against
+  (1) the goldens generated from the reference's own source (tests/golden, oracle/gen_golden.py),
+  (2) the CPU oracle on seeded inputs at sizes it finishes in seconds,
+  (3) the reference's own known-answer tests (sympy slope, tanh profile, Thomas-Fermi).
+Tolerances are stated in tests/util.py."""
+import numpy as np
+import pytest
+
+import pde_opt_amd as P
+from oracle import np_oracle as O
+from pde_opt_amd import _lib as L
+from util import MOB, MU, TOL, rel_l2, std_domain, white_noise_state
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def engine():
+    return P.engine.default_engine()
+
+
+def _force(engine, path):
+    engine.set_kernel_path(path)
+
+
+# ------------------------------------------------------------------ RHS vs reference goldens
+@pytest.mark.parametrize("kind", ["ch_fd", "ac_fd"])
+@pytest.mark.parametrize("path", [L.PATH_GENERIC, L.PATH_AUTO])
+def test_rhs_against_reference_goldens(golden, engine, kind, path):
+    z = golden("rhs_cases.npz")
+    keys = sorted(k[:-4] for k in z.files if k.startswith(kind + "/") and k.endswith("/rhs"))
+    assert len(keys) >= 20
+    _force(engine, path)
+    try:
+        used = set()
+        for key in keys:
+            _, mu, mob, tag = key.split("/")
+            nx, ny = (int(v) for v in tag.split("_")[0].split("x"))
+            dom = std_domain(P, nx, ny)
+            cls = P.CahnHilliard2DPeriodic if kind == "ch_fd" else P.AllenCahn2DPeriodic
+            eq = cls(dom, 0.002, MU[mu], MOB[mob])
+            u, want = z[key + "/u"], z[key + "/rhs"]
+            got = eq.rhs(u, 0.0)
+            used.add(engine.last_kernel)
+            assert got.dtype == want.dtype and got.shape == want.shape
+            assert rel_l2(got, want) < TOL[want.dtype], (key, engine.last_kernel, rel_l2(got, want))
+        if path == L.PATH_AUTO:
+            assert any("tiled" in k for k in used), used  # the 128x128 cases take the LDS-tiled path
+        else:
+            assert all("generic" in k for k in used), used
+    finally:
+        _force(engine, L.PATH_AUTO)
+
+
+# ------------------------------------------------------------------ RHS vs oracle, tiled shapes
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("eqname", ["ch", "ac"])
+@pytest.mark.parametrize(
+    "mu,mob,kind",
+    [("cubic", "one_plus_sq", "sym"), ("regsol", "c1mc", "c"), ("legendre", "explegendre", "c")],
+)
+def test_rhs_tiled_vs_oracle(engine, dtype, eqname, mu, mob, kind):
+    rng = np.random.default_rng(7)
+    leg_mu = P.ChemicalPotentialLegendrePolynomials([0.3, 0.1, -0.2, -0.1, 0.45], prior_fn=lambda c: np.log(c / (1 - c)))
+    leg_d = P.DiffusionLegendrePolynomials([0.2, -0.1, 0.05, -0.02])
+    mu_fn = leg_mu if mu == "legendre" else MU[mu]
+    mob_fn = leg_d if mob == "explegendre" else MOB[mob]
+    for (nx, ny, batch) in ((64, 128, 3), (32, 256, 1), (96, 128, 2)):
+        dom = std_domain(P, nx, ny)
+        cls = P.CahnHilliard2DPeriodic if eqname == "ch" else P.AllenCahn2DPeriodic
+        eq = cls(dom, 0.002, mu_fn, mob_fn)
+        u = white_noise_state(rng, (batch, nx, ny), dtype, kind)
+        got = eq.rhs(u, 0.0)
+        assert "tiled" in engine.last_kernel, engine.last_kernel
+        hx, hy = dom.dx
+        fn = O.ch_rhs_fd if eqname == "ch" else O.ac_rhs_fd
+        for b in range(batch):
+            want = fn(u[b], hx, hy, 0.002, mu_fn, mob_fn)
+            assert rel_l2(got[b], want) < TOL[np.dtype(dtype)], (nx, ny, b, rel_l2(got[b], want))
+            want64 = fn(u[b].astype(np.float64), hx, hy, 0.002, mu_fn, mob_fn)
+            assert rel_l2(got[b], want64) < 2.5 * TOL[np.dtype(dtype)]
+        # tiled and generic kernels agree with each other
+        _force(engine, L.PATH_GENERIC)
+        try:
+            gen = eq.rhs(u, 0.0)
+        finally:
+            _force(engine, L.PATH_AUTO)
+        assert rel_l2(got, gen) < TOL[np.dtype(dtype)]
+
+
+def test_manufactured_solution_convergence():
+    """tests/test_rhs_convergence.py:14-77 re-expressed on the build's API: slope 2.0 +- 10 %."""
+    import sympy as sp
+    from sympy.utilities.lambdify import lambdify
+
+    x, y, t = sp.symbols("x y t", real=True)
+    u = sp.sin(2 * x) * sp.cos(3 * y) * sp.exp(-0.7 * t)
+    kappa = 1e-2
+    mu = u**3 - u - kappa * (sp.diff(u, x, 2) + sp.diff(u, y, 2))
+    D = 1 + u**2
+    exprs = {
+        "ch": sp.diff(D * sp.diff(mu, x), x) + sp.diff(D * sp.diff(mu, y), y),
+        "ac": -D * mu,
+    }
+    u_fn = lambdify((x, y, t), u, "numpy")
+    for name, cls in (("ch", P.CahnHilliard2DPeriodic), ("ac", P.AllenCahn2DPeriodic)):
+        ex_fn = lambdify((x, y, t), exprs[name], "numpy")
+        hs, errs = [], []
+        for n in (32, 64, 128, 256, 512):
+            Lb = 2 * np.pi
+            dom = P.Domain((n, n), ((-Lb / 2, Lb / 2), (-Lb / 2, Lb / 2)), "dimensionless")
+            X, Y = dom.mesh()
+            eq = cls(dom, kappa, lambda c: c**3 - c, lambda c: 1 + c**2, derivs="fd")
+            got = eq.rhs(u_fn(X, Y, 0.0), 0)
+            exact = ex_fn(X, Y, 0.0)
+            errs.append(np.sqrt(np.sum((got - exact) ** 2)) / np.sqrt(np.sum(exact**2)))
+            hs.append(dom.dx[0])
+        slope = np.polyfit(np.log(hs), np.log(errs), 1)[0]
+        np.testing.assert_allclose(slope, 2.0, rtol=0.1)
+
+
+# ------------------------------------------------------------------ explicit integrators
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("shape", [(64, 128), (48, 40), (256, 1)])
+@pytest.mark.parametrize("solver", ["euler", "rk4"])
+def test_explicit_trajectory_vs_oracle(engine, dtype, shape, solver):
+    rng = np.random.default_rng(3)
+    nx, ny = shape
+    dom = std_domain(P, nx, ny)
+    mu_fn, mob_fn = MU["regsol"], MOB["c1mc"]
+    eq = P.CahnHilliard2DPeriodic(dom, 0.002, mu_fn, mob_fn)
+    y0 = np.clip(0.5 + 0.05 * rng.standard_normal((2, nx, ny)), 0.05, 0.95).astype(dtype)
+    dt, n = 2e-7, 8
+    s = P.Euler() if solver == "euler" else P.RK4()
+    sol = P.diffeqsolve(eq, s, t0=0.0, t1=n * dt, dt0=dt, y0=y0)
+    hx, hy = dom.dx
+    f = lambda t, u: O.ch_rhs_fd(u, hx, hy, 0.002, mu_fn, mob_fn)
+    step = O.euler_step if solver == "euler" else O.rk4_step
+    for b in range(2):
+        ref = y0[b].astype(np.float64)
+        for i in range(n):
+            ref = step(f, i * dt, ref, dt)
+        inc_ref = ref - y0[b].astype(np.float64)
+        inc_got = sol.ys[-1][b].astype(np.float64) - y0[b].astype(np.float64)
+        # fp32: the state is O(1) and the increment O(1e-3): state rounding (6e-8) bounds the
+        # increment's relative accuracy at ~1e-4
+        tol = 1e-10 if dtype is np.float64 else 5e-4
+        assert rel_l2(inc_got, inc_ref) < tol, (shape, solver, rel_l2(inc_got, inc_ref))
+        assert np.max(np.abs(sol.ys[-1][b] - ref)) < (1e-13 if dtype is np.float64 else 5e-7)
+
+
+def test_allen_cahn_rk4_config2_slice(engine):
+    """BASELINE config 2 (AC 512^2 fp32 RK4, dt 5e-5) on 4 envs for 20 substeps vs the oracle."""
+    rng = np.random.default_rng(11)
+    nx = ny = 512
+    dom = std_domain(P, nx, ny)
+    eq = P.AllenCahn2DPeriodic(dom, 0.002, MU["cubic"], MOB["one"])
+    y0 = (0.01 * rng.standard_normal((4, nx, ny))).astype(np.float32)
+    dt, n = 5e-5, 20
+    sol = P.diffeqsolve(eq, P.RK4(), 0.0, n * dt, dt, y0)
+    assert "tiled" in sol.stats["kernel"]
+    hx, hy = dom.dx
+    f = lambda t, u: O.ac_rhs_fd(u, hx, hy, 0.002, MU["cubic"], MOB["one"])
+    ref = y0[1].astype(np.float64)
+    for i in range(n):
+        ref = O.rk4_step(f, 0.0, ref, dt)
+    assert rel_l2(sol.ys[-1][1], ref) < 5e-6
+
+
+def test_batch_equals_single_bitwise(engine):
+    """an environment's trajectory does not depend on which batch it rides in"""
+    rng = np.random.default_rng(5)
+    dom = std_domain(P, 64, 128)
+    eq = P.CahnHilliard2DPeriodic(dom, 0.002, MU["regsol"], MOB["c1mc"])
+    y0 = np.clip(0.5 + 0.05 * rng.standard_normal((5, 64, 128)), 0.05, 0.95).astype(np.float32)
+    batched = P.diffeqsolve(eq, P.RK4(), 0.0, 2e-6, 2e-7, y0).ys[-1]
+    for b in (0, 3):
+        single = P.diffeqsolve(eq, P.RK4(), 0.0, 2e-6, 2e-7, y0[b]).ys[-1]
+        np.testing.assert_array_equal(single, batched[b])
+    again = P.diffeqsolve(eq, P.RK4(), 0.0, 2e-6, 2e-7, y0).ys[-1]
+    np.testing.assert_array_equal(again, batched)  # run-to-run determinism
+
+
+def test_mass_conservation_full_size(engine):
+    """size-independent property at BASELINE's full grid: CH conserves the mean (flux form)."""
+    rng = np.random.default_rng(1)
+    dom = std_domain(P, 1024, 1024)
+    eq = P.CahnHilliard2DPeriodic(dom, 0.002, MU["regsol"], MOB["c1mc"])
+    y0 = np.clip(0.5 + 0.01 * rng.standard_normal((2, 1024, 1024)), 0.05, 0.95).astype(np.float32)
+    sol = P.diffeqsolve(eq, P.RK4(), 0.0, 100 * 2e-7, 2e-7, y0)
+    y1 = sol.ys[-1]
+    assert np.all(np.isfinite(y1))
+    for b in range(2):
+        assert abs(y1[b].astype(np.float64).mean() - y0[b].astype(np.float64).mean()) < 2e-7
+    assert np.linalg.norm(y1 - y0) > 0
+
+
+def test_per_env_parameters(engine):
+    """control parameters travel with the environment: per-env kappa == separate solves"""
+    rng = np.random.default_rng(9)
+    dom = std_domain(P, 64, 128)
+    y0 = np.clip(0.5 + 0.05 * rng.standard_normal((3, 64, 128)), 0.05, 0.95)
+    kappas = [0.001, 0.002, 0.004]
+    eq = P.CahnHilliard2DPeriodic(dom, kappas[0], MU["regsol"], MOB["c1mc"])
+    eng = P.HipEngine()
+    eng.configure(dtype=np.float64, batch=3, **eq._engine_problem())
+    eng.set_env_params(0, kappa=kappas)
+    eng.set_state(y0)
+    eng.advance(L.INT_RK4, 2e-7, 5)
+    got = eng.get_state()
+    for b, k in enumerate(kappas):
+        e = P.CahnHilliard2DPeriodic(dom, k, MU["regsol"], MOB["c1mc"])
+        want = P.diffeqsolve(e, P.RK4(), 0.0, 1e-6, 2e-7, y0[b]).ys[-1]
+        np.testing.assert_array_equal(got[b], want)
+    eng.close()
+
+
+def test_saveat_linear_interpolation(engine):
+    rng = np.random.default_rng(2)
+    dom = std_domain(P, 32, 32)
+    eq = P.AllenCahn2DPeriodic(dom, 0.002, MU["cubic"], MOB["one"])
+    y0 = 0.1 * rng.standard_normal((32, 32))
+    hx, hy = dom.dx
+    f = lambda t, u: O.ac_rhs_fd(u, hx, hy, 0.002, MU["cubic"], MOB["one"])
+    ts = [0.0, 1.3e-4, 2e-4, 4.9e-4, 5e-4]
+    model = P.PDEModel(P.AllenCahn2DPeriodic, dom, P.Euler)
+    ys = model.solve(dict(kappa=0.002, mu=MU["cubic"], R=MOB["one"]), y0, ts, dt0=1e-4)
+    want = O.solve_saveat(lambda t, y, dt: O.euler_step(f, t, y, dt), y0, ts, 1e-4)
+    assert ys.shape == (5, 32, 32)
+    np.testing.assert_allclose(ys, want, rtol=0, atol=1e-13)
+
+
+# ------------------------------------------------------------------ spectral integrators
+def test_imex_trajectory_vs_reference_golden(golden):
+    z = golden("trajectories.npz")
+    dom = P.Domain((64, 64), ((-0.32, 0.32), (-0.32, 0.32)), "dimensionless")
+    eq = P.CahnHilliard2DPeriodic(dom, 0.002, MU["regsol"], MOB["c1mc"])
+    solver = P.SemiImplicitFourierSpectral(0.5, eq.fourier_symbol, eq.fft, eq.ifft)
+    dt = float(z["imex/dt"])
+    model_ts = [i * dt for i in range(11)]
+    sol = P.diffeqsolve(eq, solver, 0.0, 10 * dt, dt, z["imex/y0"], saveat=P.SaveAt(ts=model_ts))
+    inc_ref = z["imex/ys"][-1] - z["imex/y0"]
+    assert rel_l2(sol.ys[-1] - z["imex/y0"], inc_ref) < 1e-9
+    np.testing.assert_allclose(sol.ys[1:], z["imex/ys"], rtol=0, atol=1e-13)
+
+
+def test_imex_1d_reference_golden(golden):
+    z = golden("trajectories.npz")
+    dom = P.Domain((256, 1), ((-1.28, 1.28), (-0.005, 0.005)), "dimensionless")
+    eq = P.CahnHilliard2DPeriodic(dom, 0.002, MU["cubic"], MOB["one"])
+    solver = P.SemiImplicitFourierSpectral(0.5, eq.fourier_symbol, eq.fft, eq.ifft)
+    sol = P.diffeqsolve(eq, solver, 0.0, 200 * 5e-5, 5e-5, z["imex1d/y0"])
+    np.testing.assert_allclose(sol.ys[-1], z["imex1d/y200"], rtol=0, atol=1e-10)
+
+
+@pytest.mark.parametrize("name,tscale,kinetic", [("zeroA_imag", -1j, False), ("realA_real", 1.0, True), ("realA_imag", -1j, True)])
+def test_strang_trajectory_vs_reference_golden(golden, name, tscale, kinetic):
+    z = golden("trajectories.npz")
+    dom = P.Domain((48, 48), ((-12.0, 12.0), (-12.0, 12.0)), "dimensionless")
+    eq = P.GPE2DTSControl(dom, 1000.0, 0.1, lambda t, x, y: 0.05 * x, trap_factor=1.0, kinetic=kinetic)
+    if kinetic:
+        np.testing.assert_allclose(eq.A_term, z["strang/A_real"], rtol=1e-14)
+    np.testing.assert_allclose(eq.B_terms(z["strang/y0"], 0.0), z["strang/b_terms"], rtol=1e-13, atol=1e-13)
+    solver = P.StrangSplitting(eq.A_term, eq.dx, eq.fft, eq.ifft, tscale)
+    ts = [i * 1e-3 for i in range(6)]
+    sol = P.diffeqsolve(eq, solver, 0.0, 5e-3, 1e-3, z["strang/y0"], saveat=P.SaveAt(ts=ts))
+    np.testing.assert_allclose(sol.ys[1:], z[f"strang/{name}/ys"], rtol=0, atol=2e-12)
+    # fp32 batch of 3 copies
+    y32 = np.repeat(z["strang/y0"][None].astype(np.float32), 3, axis=0)
+    sol32 = P.diffeqsolve(eq, solver, 0.0, 5e-3, 1e-3, y32)
+    for b in range(3):
+        assert rel_l2(sol32.ys[-1][b], z[f"strang/{name}/ys"][-1]) < 2e-5
+
+
+# ------------------------------------------------------------------ reference known-answer tests
+def test_1d_cahn_hilliard_tanh():
+    """tests/test_solvers.py:21-61 (and its PDEModel twin :208-251): IMEX -> tanh(x/sqrt(2 kappa))."""
+    nx, ny = 256, 1
+    dom = std_domain(P, nx, ny)
+    kappa = 0.002
+    u0 = np.ones((nx, ny))
+    u0[: nx // 2, :] = -1.0
+    model = P.PDEModel(P.CahnHilliard2DPeriodic, dom, P.SemiImplicitFourierSpectral)
+    ts = np.linspace(0.0, 10.0, 200)
+    ys = model.solve(
+        dict(kappa=kappa, mu=lambda c: c**3 - c, D=lambda c: np.ones_like(c), derivs="fd"),
+        u0, ts, solver_parameters={"A": 0.5}, dt0=0.00005,
+    )
+    assert ys.shape == (200, nx, ny)
+    analytic = np.tanh(dom.axes()[0] / np.sqrt(2 * kappa))
+    np.testing.assert_allclose(ys[-1].squeeze()[nx // 4: 3 * nx // 4], analytic[nx // 4: 3 * nx // 4], rtol=1e-3, atol=1e-3)
+
+
+def test_1d_allen_cahn_tanh_tsit5_pid():
+    """tests/test_solvers.py:64-104: Tsit5 + PIDController(rtol=1e-4, atol=1e-6) -> tanh."""
+    nx, ny = 256, 1
+    dom = std_domain(P, nx, ny)
+    kappa = 0.002
+    eq = P.AllenCahn2DPeriodic(dom, kappa, lambda c: c**3 - c, lambda c: np.ones_like(c), derivs="fd")
+    u0 = np.ones((nx, ny))
+    u0[: nx // 2, :] = -1.0
+    sol = P.diffeqsolve(
+        eq, P.Tsit5(), t0=0.0, t1=10.0, dt0=0.00005, y0=u0,
+        saveat=P.SaveAt(ts=np.linspace(0.0, 10.0, 200)),
+        stepsize_controller=P.PIDController(rtol=1e-4, atol=1e-6), max_steps=1000000,
+    )
+    analytic = np.tanh(dom.axes()[0] / np.sqrt(2 * kappa))
+    np.testing.assert_allclose(sol.ys[-1].squeeze()[nx // 4: 3 * nx // 4], analytic[nx // 4: 3 * nx // 4], rtol=1e-3, atol=1e-3)
+    assert sol.stats["num_accepted_steps"] > 10
+
+
+def test_tsit5_fixed_step_vs_oracle():
+    rng = np.random.default_rng(4)
+    dom = std_domain(P, 32, 32)
+    eq = P.AllenCahn2DPeriodic(dom, 0.002, MU["cubic"], MOB["one_plus_sq"])
+    y0 = 0.1 * rng.standard_normal((32, 32))
+    hx, hy = dom.dx
+    f = lambda t, u: O.ac_rhs_fd(u, hx, hy, 0.002, MU["cubic"], MOB["one_plus_sq"])
+    sol = P.diffeqsolve(eq, P.Tsit5(), 0.0, 5e-4, 1e-4, y0)
+    ref = y0
+    for i in range(5):
+        ref, _, _ = O.tsit5_step(f, 0.0, ref, 1e-4)
+    np.testing.assert_allclose(sol.ys[-1], ref, rtol=0, atol=1e-13)
+
+
+def test_2d_gross_pitaevskii_thomas_fermi():
+    """tests/test_solvers.py:107-205: imaginary-time Strang -> Thomas-Fermi density."""
+    atoms = 5e5
+    hbar = 1.05e-34
+    omega = 2 * np.pi * 10
+    omega_z = np.sqrt(8) * omega
+    mass = 3.8175406e-26
+    a0 = 5.29177210903e-11
+    a_s = 100 * a0
+    N = 128
+    x_s = np.sqrt(hbar / (mass * omega))
+    t_s = 1 / omega
+    Lx_ = 150e-6 / x_s
+    k = 4 * np.pi * a_s * atoms * np.sqrt((mass * omega_z) / (2 * np.pi * hbar))
+    t_final_ = 0.1 / t_s
+    dt_ = 1e-5 / t_s
+    dom = P.Domain((N, N), ((-Lx_ / 2, Lx_ / 2), (-Lx_ / 2, Lx_ / 2)), "dimensionless")
+    # initialize_Psi(N, width=100, vortexnumber=0): numerics/utils/initialization_utils.py:11-34
+    ii = np.arange(N) - N // 2
+    psi0 = np.exp(-((ii[:, None] / 100.0) ** 2) - (ii[None, :] / 100.0) ** 2).astype(complex) * x_s
+    psi0 /= np.sqrt(np.sum(np.abs(psi0) ** 2) * dom.dx[0] ** 2)
+    eq = P.GPE2DTSControl(dom, k, 0.0, lambda a, b, c: 0.0, trap_factor=1.0)
+    solver = P.StrangSplitting(eq.A_term, eq.domain.dx[0], eq.fft, eq.ifft, -1j)
+    sol = P.diffeqsolve(
+        eq, solver, t0=0.0, t1=t_final_, dt0=dt_, y0=np.stack([psi0.real, psi0.imag], axis=-1),
+        saveat=P.SaveAt(ts=np.linspace(0.0, t_final_, 100)), max_steps=1000000,
+    )
+    X, Y = dom.mesh()
+    g = k
+    mu_tf = np.sqrt((1.0 * g * np.sqrt(0.5) * np.sqrt(0.5)) / (2.0 * np.pi))
+    V = 0.5 * (0.5 * X**2 + 0.5 * Y**2)
+    n = np.clip((mu_tf - V) / g, 0.0, None)
+    n = n * (1.0 / (np.sum(n) * (X[1, 0] - X[0, 0]) * (Y[0, 1] - Y[0, 0]) + 1e-12))
+    dens = sol.ys[-1][..., 0] ** 2 + sol.ys[-1][..., 1] ** 2
+    np.testing.assert_allclose(n, dens, rtol=1e-3, atol=1e-3)
+
+
+# ------------------------------------------------------------------ advection-diffusion (unpinned)
+def test_advection_diffusion_vs_oracle_and_conservation():
+    rng = np.random.default_rng(6)
+    nx = ny = 128
+    dom = std_domain(P, nx, ny, h=0.02)
+
+    def vel(t, xs, ys):
+        r2 = ((xs - 0.4) ** 2 + (ys - 0.4) ** 2) / (2.0 * 0.01)
+        return -0.1 * (xs - 0.4) / 0.01 * np.exp(-r2), -0.1 * (ys - 0.4) / 0.01 * np.exp(-r2)
+
+    eq = P.AdvectionDiffusion2D(dom, vel, 0.1)
+    u0 = 0.5 + 0.01 * rng.standard_normal((nx, ny))
+    hx, hy = dom.dx
+    vx, vy = eq.face_velocities(0.0)
+    np.testing.assert_allclose(eq.rhs(u0, 0.0), O.ad_rhs_fd(u0, hx, hy, vx, vy, 0.1), rtol=0, atol=1e-9)
+    sol = P.diffeqsolve(eq, P.Euler(), 0.0, 0.05, 1e-4, u0)  # config 1: 500 Euler substeps
+    ref = O.integrate(lambda t, y, dt: O.euler_step(lambda tt, u: O.ad_rhs_fd(u, hx, hy, vx, vy, 0.1), t, y, dt), u0, 0.0, 0.05, 1e-4)
+    np.testing.assert_allclose(sol.ys[-1], ref, rtol=0, atol=1e-12)
+    assert abs(sol.ys[-1].mean() - u0.mean()) < 1e-14
+    assert sol.stats["num_steps"] == 500
+
+
+# ------------------------------------------------------------------ reductions
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_reductions(dtype):
+    rng = np.random.default_rng(8)
+    dom = std_domain(P, 96, 80)
+    eq = P.AllenCahn2DPeriodic(dom, 0.002, MU["cubic"], MOB["one"])
+    eng = P.HipEngine()
+    y = (0.5 + 0.01 * rng.standard_normal((4, 96, 80))).astype(dtype)
+    eng.configure(dtype=dtype, batch=4, **eq._engine_problem())
+    eng.set_state(y)
+    y64 = y.astype(np.float64)
+    np.testing.assert_allclose(eng.reduce(L.RED_MEAN), y64.mean(axis=(1, 2)), rtol=1e-13)
+    np.testing.assert_allclose(eng.reduce(L.RED_VAR), y64.var(axis=(1, 2)), rtol=1e-11)
+    np.testing.assert_array_equal(eng.reduce(L.RED_MIN), y64.min(axis=(1, 2)))
+    np.testing.assert_array_equal(eng.reduce(L.RED_MAX), y64.max(axis=(1, 2)))
+    np.testing.assert_array_equal(eng.reduce(L.RED_NONFINITE), np.zeros(4))
+    y[2, 5, 5] = np.nan
+    eng.set_state(y)
+    np.testing.assert_array_equal(eng.reduce(L.RED_NONFINITE), [0, 0, 1, 0])
+    eng.close()
+
+
+def test_error_codes():
+    eng = P.HipEngine()
+    with pytest.raises(P.PdeoptError):
+        eng.advance(L.INT_RK4, 1e-3, 1)  # not configured -> ESTATE
+    dom = std_domain(P, 32, 32)
+    eq = P.CahnHilliard2DPeriodic(dom, 0.002, MU["cubic"], MOB["one"])
+    eng.configure(dtype=np.float32, batch=1, **eq._engine_problem())
+    with pytest.raises(ValueError):
+        eng.advance(L.INT_STRANG, 1e-3, 1)  # Strang on CH -> EINVAL -> ValueError
+    with pytest.raises(ValueError):
+        eng.advance(99, 1e-3, 1)
+    with pytest.raises(P.PdeoptError):
+        eng.advance(L.INT_IMEX, 1e-3, 1)  # no symbol uploaded -> ESTATE
+    with pytest.raises(ValueError):
+        eng.set_state(np.zeros((1, 16, 16), np.float32))
+    eng.close()

@@ -1,0 +1,40 @@
+"""Shared helpers for the parity tests."""
+import numpy as np
+
+MU = {
+    "cubic": lambda c: c**3 - c,
+    "regsol": lambda c: np.log(c / (1 - c)) + 3 * (1 - 2 * c),
+}
+MOB = {
+    "one": lambda c: np.ones_like(c),
+    "c1mc": lambda c: c * (1 - c),
+    "one_plus_sq": lambda c: 1 + c**2,
+    "const015": lambda c: 0.15 * np.ones_like(c),
+}
+
+
+def rel_l2(got, want):
+    got = np.asarray(got, dtype=np.float64)
+    want = np.asarray(want, dtype=np.float64)
+    den = np.linalg.norm(want)
+    return np.linalg.norm(got - want) / (den if den > 0 else 1.0)
+
+
+def std_domain(P, nx, ny, h=0.01):
+    lx, ly = h * nx, h * ny
+    return P.Domain((nx, ny), ((-lx / 2, lx / 2), (-ly / 2, ly / 2)), "dimensionless")
+
+
+def white_noise_state(rng, shape, dtype, kind):
+    if kind == "sym":  # fields for the double-well potential, around 0
+        return (0.1 * rng.standard_normal(shape)).astype(dtype)
+    return np.clip(0.5 + 0.2 * rng.standard_normal(shape), 0.05, 0.95).astype(dtype)
+
+
+# Stated tolerances (relative L2 of the RHS / of the state increment):
+#   fp64: operations are re-associated and fused (FMA, reciprocal spacing) -> a few ulp,
+#         amplified by the (1/h^2)^2 cancellation of the biharmonic: 1e-11 is ~100x the observed.
+#   fp32: same effects at eps = 6e-8; measured fp32-vs-fp64 noise floor of the *reference's own*
+#         arithmetic is 2e-7..4e-7 on white noise, so kernels are held to
+#         2e-5 against the fp32 oracle and 5e-5 against fp64.
+TOL = {np.dtype(np.float64): 1e-11, np.dtype(np.float32): 2e-5}
