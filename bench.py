@@ -102,6 +102,9 @@ def main():
     ap.add_argument("--workload", default="ch_rk4_1024_f32", choices=sorted(WORKLOADS))
     ap.add_argument("--batch-per-gpu", type=int, default=0)
     ap.add_argument("--kernel-path", type=int, default=0, help="0 auto, 1 generic, 2 tiled")
+    ap.add_argument("--tile-rows", type=int, default=0, help="0 auto (16), 16 or 32")
+    ap.add_argument("--group-envs", type=int, default=0, help="environments per cache-resident group (0 auto, -1 whole batch)")
+    ap.add_argument("--ablate", type=int, default=0, help="TIMING ONLY (wrong results): kernel phase ablation bits")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
@@ -127,6 +130,10 @@ def main():
     eq, y0, dt, substeps = make_problem(P, args.workload, batch, rank)
     eng = P.HipEngine(local_rank)  # fails loudly without the HIP library / a GPU
     eng.set_kernel_path(args.kernel_path)
+    eng.set_tile_rows(args.tile_rows)
+    eng.set_group_envs(args.group_envs)
+    if args.ablate:
+        eng._check(eng._lib.pdeopt_set_option(eng._h, L.OPT_DEBUG_ABLATE, args.ablate))
     eng.configure(dtype=y0.dtype, batch=batch, **eq._engine_problem())
     eng.set_state(y0)  # inputs resident in HBM before the timed region
 
@@ -144,6 +151,7 @@ def main():
     for _ in range(args.warmup):
         env_step()
     barrier()
+    launches0 = eng.stage_launches()
     eng.timer_start()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -166,8 +174,9 @@ def main():
     if rank == 0:
         nx, ny = eq.domain.points
         esize = y0.dtype.itemsize
-        launches = args.steps * substeps * 4
-        bytes_per_launch = RK4_BYTES_PER_CELL_SUBSTEP[esize] / 4 * nx * ny * batch
+        launches = eng.stage_launches() - launches0  # fused stage launches in the timed region
+        total_bytes = RK4_BYTES_PER_CELL_SUBSTEP[esize] * nx * ny * batch * substeps * args.steps
+        bytes_per_launch = total_bytes / launches
         avg_launch_s = (dev_ms * 1e-3) / launches
         achieved = bytes_per_launch / avg_launch_s / 1e9
         traffic = None

@@ -116,7 +116,14 @@ typedef enum {
 
 /* kernel-selection knobs (pdeopt_set_option) */
 typedef enum {
-  PDEOPT_OPT_KERNEL_PATH = 0  /* 0 = auto, 1 = force the generic (untiled) kernels, 2 = force LDS-tiled */
+  PDEOPT_OPT_KERNEL_PATH = 0, /* 0 = auto, 1 = force the generic (untiled) kernels, 2 = force LDS-tiled */
+  PDEOPT_OPT_TILE_ROWS = 1,   /* rows per LDS tile: 0 = auto, 16 or 32 */
+  PDEOPT_OPT_GROUP_ENVS = 2,  /* explicit integrators: advance the batch in groups of this many
+                                 environments so a group's working set stays in the 256 MiB
+                                 Infinity Cache across stages and substeps (0 = auto, < 0 = whole
+                                 batch in one sweep) */
+  PDEOPT_OPT_DEBUG_ABLATE = 3 /* TIMING ONLY, results are wrong: bit0 skip the mu phase, bit1 skip
+                                 the flux phase of the tiled kernel (where does the time go?) */
 } pdeopt_option;
 
 /* ---- life cycle ------------------------------------------------------------------------- */
@@ -173,6 +180,8 @@ int pdeopt_tsit5_commit(pdeopt_ctx* ctx, int accept);
 int pdeopt_sync(pdeopt_ctx* ctx);
 int pdeopt_timer_start(pdeopt_ctx* ctx);           /* hipEventRecord on the ctx stream */
 int pdeopt_timer_stop(pdeopt_ctx* ctx, double* ms); /* record + synchronise + elapsed */
+typedef enum { PDEOPT_CNT_STAGE_LAUNCHES = 0 /* fused stencil+update kernel launches so far */ } pdeopt_counter;
+int pdeopt_get_counter(pdeopt_ctx* ctx, int which, int64_t* value);
 /* name of the kernel variant the last advance/rhs dispatched (for tests and profiles) */
 const char* pdeopt_last_kernel(const pdeopt_ctx* ctx);
 

@@ -27,6 +27,10 @@ CL_LOGIT_PRIOR, CL_EXP_WRAP = 1, 2
 AUX_VX_FACE, AUX_VY_FACE, AUX_IMEX_SYMBOL, AUX_GPE_A_TERM, AUX_GPE_POTENTIAL = 0, 1, 2, 3, 4
 RED_MEAN, RED_VAR, RED_MIN, RED_MAX, RED_SUMSQ, RED_NONFINITE = 0, 1, 2, 3, 4, 5
 OPT_KERNEL_PATH = 0
+OPT_TILE_ROWS = 1
+OPT_GROUP_ENVS = 2
+OPT_DEBUG_ABLATE = 3
+CNT_STAGE_LAUNCHES = 0
 PATH_AUTO, PATH_GENERIC, PATH_TILED = 0, 1, 2
 
 
@@ -90,6 +94,7 @@ _SIGNATURES = {
     "pdeopt_reduce": (C.c_int, [_VP, C.c_int, _VP]),
     "pdeopt_tsit5_trial": (C.c_int, [_VP, C.c_double, C.c_double, C.c_double, C.c_double, _VP]),
     "pdeopt_tsit5_commit": (C.c_int, [_VP, C.c_int]),
+    "pdeopt_get_counter": (C.c_int, [_VP, C.c_int, C.POINTER(C.c_int64)]),
     "pdeopt_sync": (C.c_int, [_VP]),
     "pdeopt_timer_start": (C.c_int, [_VP]),
     "pdeopt_timer_stop": (C.c_int, [_VP, C.POINTER(C.c_double)]),

@@ -180,6 +180,17 @@ int pdeopt_set_option(pdeopt_ctx* ctx, int option, int64_t value) {
       if (value < 0 || value > 2) return fail(ctx, PDEOPT_EINVAL, "kernel path %lld", (long long)value);
       ctx->opt_kernel_path = value;
       return PDEOPT_OK;
+    case PDEOPT_OPT_TILE_ROWS:
+      if (value != 0 && value != 16 && value != 32)
+        return fail(ctx, PDEOPT_EINVAL, "tile rows must be 0 (auto), 16 or 32");
+      ctx->opt_tile_rows = value;
+      return PDEOPT_OK;
+    case PDEOPT_OPT_DEBUG_ABLATE:
+      ctx->opt_debug_ablate = value;
+      return PDEOPT_OK;
+    case PDEOPT_OPT_GROUP_ENVS:
+      ctx->opt_group_envs = value;
+      return PDEOPT_OK;
     default:
       return fail(ctx, PDEOPT_EINVAL, "unknown option %d", option);
   }
@@ -217,6 +228,8 @@ int pdeopt_configure(pdeopt_ctx* ctx, const pdeopt_problem* pr) {
   else
     fill_env_params<double>(ctx);
   if ((rc = ensure_buffer(ctx, &ctx->env_params_dev, ctx->env_params_host.size()))) return rc;
+  ctx->win_lo = 0;
+  ctx->win_n = pr->batch;
   ctx->configured = true;
   return upload_env_params(ctx);
 }
@@ -404,6 +417,17 @@ int pdeopt_tsit5_commit(pdeopt_ctx* ctx, int accept) {
   if (!ctx->configured) return fail(ctx, PDEOPT_ESTATE, "pdeopt_configure has not been called");
   PDEOPT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   return tsit5_commit(ctx, accept);
+}
+
+int pdeopt_get_counter(pdeopt_ctx* ctx, int which, int64_t* value) {
+  if (!ctx || !value) return PDEOPT_EINVAL;
+  switch (which) {
+    case PDEOPT_CNT_STAGE_LAUNCHES:
+      *value = ctx->n_stage_launches;
+      return PDEOPT_OK;
+    default:
+      return fail(ctx, PDEOPT_EINVAL, "unknown counter %d", which);
+  }
 }
 
 int pdeopt_sync(pdeopt_ctx* ctx) {

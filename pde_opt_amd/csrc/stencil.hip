@@ -19,10 +19,12 @@ StageArgs<T> make_args(pdeopt_ctx* ctx, const void* in, const void* y, void* out
                        double a, double b, int out_mode, int acc_mode) {
   const pdeopt_problem& p = ctx->prob;
   StageArgs<T> s{};
-  s.in = static_cast<const T*>(in);
-  s.y = static_cast<const T*>(y);
-  s.out = static_cast<T*>(out);
-  s.acc = static_cast<T*>(acc);
+  // environment window [win_lo, win_lo + win_n): pointers are pre-offset, kernels see a batch of win_n
+  const int64_t woff = (int64_t)ctx->win_lo * p.nx * p.ny;
+  s.in = static_cast<const T*>(in) + woff;
+  s.y = static_cast<const T*>(y) + woff;
+  s.out = out ? static_cast<T*>(out) + woff : nullptr;
+  s.acc = acc ? static_cast<T*>(acc) + woff : nullptr;
   s.a = T(a);
   s.b = T(b);
   s.rhx = T(1.0 / p.hx);
@@ -35,14 +37,17 @@ StageArgs<T> make_args(pdeopt_ctx* ctx, const void* in, const void* y, void* out
   s.g.off = 0;
   s.g.bstride = (int64_t)p.nx * p.ny;
   s.g.periodic = 1;
-  s.ep = static_cast<const EnvParams<T>*>(ctx->env_params_dev);
+  s.ep = static_cast<const EnvParams<T>*>(ctx->env_params_dev) + ctx->win_lo;
   s.mu = ClosureSpec{p.mu.kind, p.mu.flags, p.mu.n};
   s.mob = ClosureSpec{p.mob.kind, p.mob.flags, p.mob.n};
+  s.vstride = ctx->aux[PDEOPT_AUX_VX_FACE].per_env ? (int64_t)p.nx * p.ny : 0;
   s.vx = static_cast<const T*>(ctx->aux[PDEOPT_AUX_VX_FACE].dev);
   s.vy = static_cast<const T*>(ctx->aux[PDEOPT_AUX_VY_FACE].dev);
-  s.vstride = ctx->aux[PDEOPT_AUX_VX_FACE].per_env ? (int64_t)p.nx * p.ny : 0;
+  if (s.vx) s.vx += ctx->win_lo * s.vstride;
+  if (s.vy) s.vy += ctx->win_lo * s.vstride;
   s.out_mode = out_mode;
   s.acc_mode = acc_mode;
+  s.dbg = (int)ctx->opt_debug_ablate;
   return s;
 }
 
@@ -50,7 +55,7 @@ template <typename T>
 int launch_generic(pdeopt_ctx* ctx, const StageArgs<T>& s) {
   const pdeopt_problem& p = ctx->prob;
   dim3 block(64, 4, 1);
-  dim3 grid((p.ny + 63) / 64, (p.nx + 3) / 4, p.batch);
+  dim3 grid((p.ny + 63) / 64, (p.nx + 3) / 4, ctx->win_n);
   if (grid.y > 65535u || grid.z > 65535u)
     return fail(ctx, PDEOPT_EINVAL, "grid too large for the generic kernel (nx=%d batch=%d)", p.nx,
                 p.batch);
@@ -84,7 +89,8 @@ template <typename T>
 int launch_stage_t(pdeopt_ctx* ctx, const void* in, const void* y, void* out, void* acc, double a,
                    double b, int out_mode, int acc_mode) {
   StageArgs<T> s = make_args<T>(ctx, in, y, out, acc, a, b, out_mode, acc_mode);
-  if (ctx->opt_kernel_path != 1 && tiled_supported<T>(ctx->prob)) {
+  ctx->n_stage_launches++;
+  if (ctx->opt_kernel_path != 1 && tiled_supported<T>(ctx)) {
     return launch_tiled<T>(ctx, s);
   }
   if (ctx->opt_kernel_path == 2)
@@ -117,34 +123,62 @@ int launch_rhs(pdeopt_ctx* ctx, const void* in, void* out, double) {
 int advance_explicit(pdeopt_ctx* ctx, int integrator, double, double dt, int64_t n) {
   int rc;
   if ((rc = ensure_buffer(ctx, &ctx->TA, ctx->total_bytes))) return rc;
-  if (integrator == PDEOPT_INT_EULER) {
-    for (int64_t s = 0; s < n; ++s) {
-      if ((rc = launch_stage(ctx, ctx->Y, ctx->Y, ctx->TA, nullptr, dt, 0.0, OUT_Y_PLUS_AK, ACC_NONE)))
-        return rc;
-      std::swap(ctx->Y, ctx->TA);
-    }
-    return PDEOPT_OK;
-  }
   if (integrator == PDEOPT_INT_RK4) {
     if ((rc = ensure_buffer(ctx, &ctx->TB, ctx->total_bytes))) return rc;
     if ((rc = ensure_buffer(ctx, &ctx->ACC, ctx->total_bytes))) return rc;
-    for (int64_t s = 0; s < n; ++s) {
-      // stage 1: k1 = f(y);        TA = y + dt/2 k1;  ACC = y + dt/6 k1
-      if ((rc = launch_stage(ctx, ctx->Y, ctx->Y, ctx->TA, ctx->ACC, dt / 2, dt / 6, OUT_Y_PLUS_AK, ACC_INIT)))
-        return rc;
-      // stage 2: k2 = f(TA);       TB = y + dt/2 k2;  ACC += dt/3 k2
-      if ((rc = launch_stage(ctx, ctx->TA, ctx->Y, ctx->TB, ctx->ACC, dt / 2, dt / 3, OUT_Y_PLUS_AK, ACC_ADD)))
-        return rc;
-      // stage 3: k3 = f(TB);       TA = y + dt k3;    ACC += dt/3 k3
-      if ((rc = launch_stage(ctx, ctx->TB, ctx->Y, ctx->TA, ctx->ACC, dt, dt / 3, OUT_Y_PLUS_AK, ACC_ADD)))
-        return rc;
-      // stage 4: k4 = f(TA);       y  = ACC + dt/6 k4   (in place: y is only touched pointwise)
-      if ((rc = launch_stage(ctx, ctx->TA, ctx->Y, ctx->Y, ctx->ACC, 0.0, dt / 6, OUT_ACC_PLUS_BK, ACC_NONE)))
-        return rc;
-    }
-    return PDEOPT_OK;
+  } else if (integrator != PDEOPT_INT_EULER) {
+    return fail(ctx, PDEOPT_EINVAL, "integrator %d is not an explicit fixed-step integrator", integrator);
   }
-  return fail(ctx, PDEOPT_EINVAL, "integrator %d is not an explicit fixed-step integrator", integrator);
+  // Environments are independent, so the substep loop may run group by group: a group whose
+  // working set (4 fields x group x nx x ny) fits the 256 MiB Infinity Cache keeps every stage's
+  // reads and writes on-die for all n substeps instead of streaming the whole batch through HBM
+  // once per stage.
+  const int batch = ctx->prob.batch;
+  int group = batch;
+  if (ctx->opt_group_envs > 0) {
+    group = (int)std::min<int64_t>(ctx->opt_group_envs, batch);
+  } else if (ctx->opt_group_envs == 0) {
+    // auto: largest balanced group whose 4 fields fit the Infinity Cache (measured on MI355X:
+    // 32 x 1024^2 fp32 runs 13-16 % faster as 2 groups of 16 = 256 MiB than as one 512 MiB sweep;
+    // smaller groups lose more to per-launch ramp/tail than they gain)
+    const size_t field = ctx->env_elems * ctx->esize;
+    const int64_t fit = std::max<int64_t>(1, (int64_t)((256ull << 20) / (4 * field)));
+    if (fit < batch && n > 1) {
+      const int ngroups = (int)((batch + fit - 1) / fit);
+      group = (batch + ngroups - 1) / ngroups;
+    }
+  }
+  void* y_final = ctx->Y;
+  void* ta_final = ctx->TA;
+  for (int lo = 0; lo < batch; lo += group) {
+    ctx->win_lo = lo;
+    ctx->win_n = std::min(group, batch - lo);
+    void* Y = ctx->Y;
+    void* TA = ctx->TA;
+    for (int64_t s = 0; s < n && !rc; ++s) {
+      if (integrator == PDEOPT_INT_EULER) {
+        rc = launch_stage(ctx, Y, Y, TA, nullptr, dt, 0.0, OUT_Y_PLUS_AK, ACC_NONE);
+        std::swap(Y, TA);
+        continue;
+      }
+      // stage 1: k1 = f(y);        TA = y + dt/2 k1;  ACC = y + dt/6 k1
+      rc = launch_stage(ctx, Y, Y, TA, ctx->ACC, dt / 2, dt / 6, OUT_Y_PLUS_AK, ACC_INIT);
+      // stage 2: k2 = f(TA);       TB = y + dt/2 k2;  ACC += dt/3 k2
+      if (!rc) rc = launch_stage(ctx, TA, Y, ctx->TB, ctx->ACC, dt / 2, dt / 3, OUT_Y_PLUS_AK, ACC_ADD);
+      // stage 3: k3 = f(TB);       TA = y + dt k3;    ACC += dt/3 k3
+      if (!rc) rc = launch_stage(ctx, ctx->TB, Y, TA, ctx->ACC, dt, dt / 3, OUT_Y_PLUS_AK, ACC_ADD);
+      // stage 4: k4 = f(TA);       y  = ACC + dt/6 k4   (in place: y is only touched pointwise)
+      if (!rc) rc = launch_stage(ctx, TA, Y, Y, ctx->ACC, 0.0, dt / 6, OUT_ACC_PLUS_BK, ACC_NONE);
+    }
+    y_final = Y;  // every group performs the same number of swaps
+    ta_final = TA;
+    if (rc) break;
+  }
+  ctx->win_lo = 0;
+  ctx->win_n = batch;
+  ctx->Y = y_final;
+  ctx->TA = ta_final;
+  return rc;
 }
 
 // ------------------------------------------------------------------------------------------

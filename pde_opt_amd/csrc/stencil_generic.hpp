@@ -34,6 +34,7 @@ struct StageArgs {
   const T* vy;
   int64_t vstride;
   int out_mode, acc_mode;
+  int dbg;  // timing ablations (PDEOPT_OPT_DEBUG_ABLATE): bit0 skip mu phase, bit1 skip flux phase
 };
 
 __device__ __forceinline__ int wrap_idx(int i, int n) {

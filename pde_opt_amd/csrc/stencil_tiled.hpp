@@ -39,28 +39,28 @@ struct VecOf<double> {
   static constexpr int V = 2;
 };
 
-constexpr int kTileRows = 32;      // TX
 constexpr int kLanesPerRow = 32;   // vectors per tile row
-constexpr int kRowsPerThread = 4;
 constexpr int kPV = kLanesPerRow + 2;  // vectors per LDS row (one halo vector each side)
+// RPT = rows per thread; a tile has TX = 8 * RPT rows (8 row groups of 32 lanes = 256 threads)
 
-template <typename T, int EQ>
+template <typename T, int EQ, int RPT>
 constexpr size_t tiled_lds_bytes() {
   constexpr int V = VecOf<T>::V;
   constexpr int HR = (EQ == PDEOPT_EQ_CAHN_HILLIARD) ? 2 : 1;
-  size_t su = (size_t)(kTileRows + 2 * HR) * kPV * V + 2 * V;
-  size_t smu = (EQ == PDEOPT_EQ_CAHN_HILLIARD) ? (size_t)(kTileRows + 2) * kPV * V + 2 * V : 0;
+  size_t su = (size_t)(8 * RPT + 2 * HR) * kPV * V + 2 * V;
+  size_t smu = (EQ == PDEOPT_EQ_CAHN_HILLIARD) ? (size_t)(8 * RPT + 2) * kPV * V + 2 * V : 0;
   return (su + smu) * sizeof(T);
 }
 
-template <typename T, int EQ, int CL, int OUT_MODE, int ACC_MODE, bool Y_FROM_TILE>
+template <typename T, int EQ, int CL, int OUT_MODE, int ACC_MODE, bool Y_FROM_TILE, int RPT>
 __global__ __launch_bounds__(256) void stage_tiled_kernel(const StageArgs<T> a, const int tiles_i,
                                                           const int tiles_j, const int nblk,
                                                           const int xcd_remap) {
   using Vec = typename VecOf<T>::type;
   constexpr int V = VecOf<T>::V;
   constexpr int HR = (EQ == PDEOPT_EQ_CAHN_HILLIARD) ? 2 : 1;
-  constexpr int TX = kTileRows;
+  constexpr int TX = 8 * RPT;
+  constexpr int kRowsPerThread = RPT;
   constexpr int PV = kPV;
   constexpr int P = PV * V;  // LDS row pitch in elements
   constexpr bool kIsCH = (EQ == PDEOPT_EQ_CAHN_HILLIARD);
@@ -126,7 +126,7 @@ __global__ __launch_bounds__(256) void stage_tiled_kernel(const StageArgs<T> a, 
 
   const T kap = p.kappa;
 
-  if constexpr (kIsCH) {
+  if (kIsCH && !(a.dbg & 1)) {
     // ---- phase 2: mu on the tile + 1 ring (rows -1..TX), one closure evaluation per point
     constexpr int kMuVecs = (TX + 2) * PV;
 #pragma unroll 1
@@ -169,7 +169,11 @@ __global__ __launch_bounds__(256) void stage_tiled_kernel(const StageArgs<T> a, 
   const int cofs = (lx + 1) * V;  // array column of this thread's first cell
   Vec kout[kRowsPerThread];
 
-  if constexpr (kIsCH) {
+  if (a.dbg & 2) {
+#pragma unroll
+    for (int r = 0; r < kRowsPerThread; ++r)
+      kout[r] = *reinterpret_cast<const Vec*>(su + (r0 + r + HR) * P + cofs);
+  } else if constexpr (kIsCH) {
     auto mob_vec = [&](const T* ptr) -> Vec {
       Vec d = *reinterpret_cast<const Vec*>(ptr);
       if constexpr (!kMobInPlace) {
@@ -260,29 +264,45 @@ __global__ __launch_bounds__(256) void stage_tiled_kernel(const StageArgs<T> a, 
 // host side
 // ---------------------------------------------------------------------------------------------
 
+// rows per thread for a problem: 4 (32-row tiles) unless the grid only divides by 16
+inline int tiled_rpt(const pdeopt_ctx* ctx) {
+  const int want = ctx->opt_tile_rows > 0 ? (int)ctx->opt_tile_rows / 8 : 2;  // 16-row tiles measured fastest
+  if (ctx->prob.nx % (8 * want) == 0) return want;
+  return (ctx->prob.nx % 16 == 0) ? 2 : 0;  // 32-row request on a grid that only divides by 16
+}
+
 template <typename T>
-bool tiled_supported(const pdeopt_problem& p) {
+bool tiled_supported(const pdeopt_ctx* ctx) {
   constexpr int V = VecOf<T>::V;
+  const pdeopt_problem& p = ctx->prob;
   if (p.equation != PDEOPT_EQ_CAHN_HILLIARD && p.equation != PDEOPT_EQ_ALLEN_CAHN) return false;
-  if (p.nx % kTileRows != 0 || p.ny % (kLanesPerRow * V) != 0) return false;
+  if (tiled_rpt(ctx) == 0 || p.ny % (kLanesPerRow * V) != 0) return false;
   return true;
 }
 
-template <typename T, int EQ, int CL, int OUT_MODE, int ACC_MODE, bool Y_FROM_TILE>
-int launch_tiled_inst(pdeopt_ctx* ctx, const StageArgs<T>& s) {
+template <typename T, int EQ, int CL, int OUT_MODE, int ACC_MODE, bool Y_FROM_TILE, int RPT>
+int launch_tiled_rpt(pdeopt_ctx* ctx, const StageArgs<T>& s) {
   constexpr int V = VecOf<T>::V;
+  constexpr int kTileRows = 8 * RPT;
   const pdeopt_problem& p = ctx->prob;
   const int tiles_i = p.nx / kTileRows;
   const int tiles_j = p.ny / (kLanesPerRow * V);
-  const int64_t nblk64 = (int64_t)tiles_i * tiles_j * p.batch;
+  const int64_t nblk64 = (int64_t)tiles_i * tiles_j * ctx->win_n;
   if (nblk64 > 0x7fffffffLL) return fail(ctx, PDEOPT_EINVAL, "too many tiles");
   const int nblk = (int)nblk64;
-  const size_t lds = tiled_lds_bytes<T, EQ>();
-  hipLaunchKernelGGL((stage_tiled_kernel<T, EQ, CL, OUT_MODE, ACC_MODE, Y_FROM_TILE>), dim3(nblk),
+  const size_t lds = tiled_lds_bytes<T, EQ, RPT>();
+  hipLaunchKernelGGL((stage_tiled_kernel<T, EQ, CL, OUT_MODE, ACC_MODE, Y_FROM_TILE, RPT>), dim3(nblk),
                      dim3(256), lds, ctx->stream, s, tiles_i, tiles_j, nblk,
                      (nblk % 8 == 0) ? 1 : 0);
   PDEOPT_HIP_CHECK(ctx, hipGetLastError());
   return PDEOPT_OK;
+}
+
+template <typename T, int EQ, int CL, int OUT_MODE, int ACC_MODE, bool Y_FROM_TILE>
+int launch_tiled_inst(pdeopt_ctx* ctx, const StageArgs<T>& s) {
+  if (tiled_rpt(ctx) == 2)
+    return launch_tiled_rpt<T, EQ, CL, OUT_MODE, ACC_MODE, Y_FROM_TILE, 2>(ctx, s);
+  return launch_tiled_rpt<T, EQ, CL, OUT_MODE, ACC_MODE, Y_FROM_TILE, 4>(ctx, s);
 }
 
 template <typename T, int EQ, int CL>
@@ -327,8 +347,9 @@ int launch_tiled(pdeopt_ctx* ctx, const StageArgs<T>& s) {
   const int cl = classify_closures(ctx->prob.mu, ctx->prob.mob);
   static const char* kClName[] = {"generic", "poly", "logit"};
   char name[96];
-  snprintf(name, sizeof(name), "stage_tiled<%s,%s,%s>", sizeof(T) == 4 ? "f32" : "f64",
-           ctx->prob.equation == PDEOPT_EQ_CAHN_HILLIARD ? "CH" : "AC", kClName[cl]);
+  snprintf(name, sizeof(name), "stage_tiled<%s,%s,%s,rows%d>", sizeof(T) == 4 ? "f32" : "f64",
+           ctx->prob.equation == PDEOPT_EQ_CAHN_HILLIARD ? "CH" : "AC", kClName[cl],
+           8 * tiled_rpt(ctx));
   ctx->last_kernel = name;
   if (ctx->prob.equation == PDEOPT_EQ_CAHN_HILLIARD)
     return launch_tiled_cl<T, PDEOPT_EQ_CAHN_HILLIARD>(ctx, s);

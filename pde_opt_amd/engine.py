@@ -78,6 +78,12 @@ class HipEngine:
     def set_kernel_path(self, path: int):
         self._check(self._lib.pdeopt_set_option(self._h, L.OPT_KERNEL_PATH, int(path)))
 
+    def set_tile_rows(self, rows: int):
+        self._check(self._lib.pdeopt_set_option(self._h, L.OPT_TILE_ROWS, int(rows)))
+
+    def set_group_envs(self, n: int):
+        self._check(self._lib.pdeopt_set_option(self._h, L.OPT_GROUP_ENVS, int(n)))
+
     # -- problem ----------------------------------------------------------------------------
     def configure(
         self,
@@ -205,6 +211,11 @@ class HipEngine:
 
     def tsit5_commit(self, accept: bool):
         self._check(self._lib.pdeopt_tsit5_commit(self._h, int(bool(accept))))
+
+    def stage_launches(self) -> int:
+        v = C.c_int64()
+        self._check(self._lib.pdeopt_get_counter(self._h, L.CNT_STAGE_LAUNCHES, C.byref(v)))
+        return v.value
 
     def sync(self):
         self._check(self._lib.pdeopt_sync(self._h))
