@@ -61,8 +61,14 @@ def make_problem(P, name, batch, rank):
 
 
 def cpu_baseline(name, budget_s=15.0):
-    """The oracle (numpy port of the reference's roll-form arithmetic) timed on the host cores,
-    on a bounded sample of the same workload: one environment, as many RK4 substeps as fit."""
+    """The oracle timed on the host cores, on a bounded sample of the same workload (one
+    environment, as many RK4 substeps as fit the budget):
+      * value: the C restatement (oracle/c_oracle.c, fused loops, OpenMP) on min(16, cores) threads
+        -- the stronger CPU baseline, so the GPU ratio is not inflated by a slow one;
+      * the numpy roll-form port (oracle/np_oracle.py, what the reference's arithmetic costs when
+        executed op for op, single thread) is quoted in `sample`.
+    Neither is JAX-on-CPU: JAX is not installable here (no network); see BASELINE.md section 3."""
+    from oracle import c_oracle as CO
     from oracle import np_oracle as O
 
     kind, nx, ny, dtype, dt, substeps, _ = WORKLOADS[name]
@@ -73,24 +79,40 @@ def cpu_baseline(name, budget_s=15.0):
         mob = lambda c: c * (1 - c)
         y = np.clip(0.5 + 0.01 * rng.standard_normal((nx, ny)), 0.05, 0.95).astype(dtype)
         f = lambda t, u: O.ch_rhs_fd(u, hx, hy, 0.002, mu, mob)
+        eq, cmu, cmob = 0, CO.closure(0, 1, (3.0, -6.0)), CO.closure(0, 0, (0.0, 1.0, -1.0))
     else:
         y = (0.01 * rng.standard_normal((nx, ny))).astype(dtype)
         f = lambda t, u: O.ac_rhs_fd(u, hx, hy, 0.002, lambda c: c**3 - c, lambda c: np.ones_like(c))
+        eq, cmu, cmob = 1, CO.closure(0, 0, (0.0, -1.0, 0.0, 1.0)), CO.closure(0, 0, (1.0,))
     dtc = dtype(dt)
-    O.rk4_step(f, 0.0, y, dtc)  # warm-up
+    # numpy roll-form port, single thread
+    O.rk4_step(f, 0.0, y, dtc)
     t0 = time.perf_counter()
-    n = 0
-    while time.perf_counter() - t0 < budget_s:
-        y = O.rk4_step(f, 0.0, y, dtc)
-        n += 1
-    el = time.perf_counter() - t0
+    n_np = 0
+    yy = y
+    while time.perf_counter() - t0 < budget_s * 0.4:
+        yy = O.rk4_step(f, 0.0, yy, dtc)
+        n_np += 1
+    el_np = time.perf_counter() - t0
+    # C / OpenMP port
+    threads = max(1, min(16, os.cpu_count() or 1))
+    CO.rk4(eq, y, hx, hy, 0.002, cmu, cmob, dt, 2, threads=threads)  # warm-up
+    chunk, n_c = 8, 0
+    t0 = time.perf_counter()
+    yy = y
+    while time.perf_counter() - t0 < budget_s * 0.6:
+        yy = CO.rk4(eq, yy, hx, hy, 0.002, cmu, cmob, dt, chunk, threads=threads)
+        n_c += chunk
+    el_c = time.perf_counter() - t0
     return {
-        "value": (n / el) / substeps,
+        "value": (n_c / el_c) / substeps,
         "unit": "env-steps/s",
-        "cores": 1,
+        "cores": threads,
         "kind": "port",
-        "sample": f"1 env x {n} RK4 substeps of {name} in {el:.1f} s, single-threaded numpy oracle "
-                  f"(oracle/np_oracle.py); {n / el:.2f} substeps/s; host has {os.cpu_count()} cores",
+        "sample": f"1 env of {name}: C/OpenMP oracle (oracle/c_oracle.c) {n_c} RK4 substeps in {el_c:.1f} s on "
+                  f"{threads} threads = {n_c / el_c:.1f} substeps/s; numpy roll-form oracle "
+                  f"(oracle/np_oracle.py) {n_np} substeps in {el_np:.1f} s on 1 thread = "
+                  f"{n_np / el_np:.1f} substeps/s; host reports {os.cpu_count()} cores",
     }
 
 
