@@ -126,6 +126,7 @@ def main():
     ap.add_argument("--kernel-path", type=int, default=0, help="0 auto, 1 generic, 2 tiled")
     ap.add_argument("--tile-rows", type=int, default=0, help="0 auto (16), 16 or 32")
     ap.add_argument("--group-envs", type=int, default=0, help="environments per cache-resident group (0 auto, -1 whole batch)")
+    ap.add_argument("--fuse", type=int, default=0, help="RK4 stage-pair fusion: 0 auto, -1 off")
     ap.add_argument("--ablate", type=int, default=0, help="TIMING ONLY (wrong results): kernel phase ablation bits")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
@@ -154,6 +155,7 @@ def main():
     eng.set_kernel_path(args.kernel_path)
     eng.set_tile_rows(args.tile_rows)
     eng.set_group_envs(args.group_envs)
+    eng.set_fuse_stages(args.fuse)
     if args.ablate:
         eng._check(eng._lib.pdeopt_set_option(eng._h, L.OPT_DEBUG_ABLATE, args.ablate))
     eng.configure(dtype=y0.dtype, batch=batch, **eq._engine_problem())

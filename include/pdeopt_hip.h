@@ -122,6 +122,8 @@ typedef enum {
                                  environments so a group's working set stays in the 256 MiB
                                  Infinity Cache across stages and substeps (0 = auto, < 0 = whole
                                  batch in one sweep) */
+  PDEOPT_OPT_FUSE_STAGES = 4, /* RK4: temporally fused stage pairs (1+2, 3+4): 0 = auto (on where a
+                                 fused kernel exists), -1 = off (one launch per stage) */
   PDEOPT_OPT_DEBUG_ABLATE = 3 /* TIMING ONLY, results are wrong: bit0 skip the mu phase, bit1 skip
                                  the flux phase of the tiled kernel (where does the time go?) */
 } pdeopt_option;

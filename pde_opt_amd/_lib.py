@@ -30,6 +30,7 @@ OPT_KERNEL_PATH = 0
 OPT_TILE_ROWS = 1
 OPT_GROUP_ENVS = 2
 OPT_DEBUG_ABLATE = 3
+OPT_FUSE_STAGES = 4
 CNT_STAGE_LAUNCHES = 0
 PATH_AUTO, PATH_GENERIC, PATH_TILED = 0, 1, 2
 

@@ -185,6 +185,9 @@ int pdeopt_set_option(pdeopt_ctx* ctx, int option, int64_t value) {
         return fail(ctx, PDEOPT_EINVAL, "tile rows must be 0 (auto), 16 or 32");
       ctx->opt_tile_rows = value;
       return PDEOPT_OK;
+    case PDEOPT_OPT_FUSE_STAGES:
+      ctx->opt_fuse_stages = value;
+      return PDEOPT_OK;
     case PDEOPT_OPT_DEBUG_ABLATE:
       ctx->opt_debug_ablate = value;
       return PDEOPT_OK;

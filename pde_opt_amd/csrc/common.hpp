@@ -83,6 +83,7 @@ struct pdeopt_ctx {
   int64_t opt_tile_rows = 0;  // 0 auto, 16 or 32
   int64_t opt_group_envs = 0; // explicit integrators: envs per cache-resident group (0 auto, <0 whole batch)
   int64_t n_stage_launches = 0;  // fused stencil+update launches issued so far
+  int64_t opt_fuse_stages = 0;   // RK4 stage-pair fusion: 0 auto (on where supported), -1 off
   int64_t opt_debug_ablate = 0;  // timing-only ablations, results are wrong when set
   int win_lo = 0, win_n = 0;  // environment window the stage launchers operate on
   double imex_A = 0.5, ts_re = 1.0, ts_im = 0.0, strang_dx = 1.0;

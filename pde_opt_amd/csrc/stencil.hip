@@ -9,6 +9,7 @@
 
 #include "stencil_generic.hpp"
 #include "stencil_tiled.hpp"
+#include "stencil_fused.hpp"
 
 namespace pdeopt {
 
@@ -106,6 +107,13 @@ int launch_stage(pdeopt_ctx* ctx, const void* in, const void* y, void* out, void
   return launch_stage_t<double>(ctx, in, y, out, acc, a, b, out_mode, acc_mode);
 }
 
+int launch_pair_dt(pdeopt_ctx* ctx, int pair, const void* in, const void* y, const void* acc, void* out,
+                   void* acc_out, double aA, double bA, double aB, double bB) {
+  if (ctx->prob.dtype == PDEOPT_F32)
+    return launch_pair<float>(ctx, pair, in, y, acc, out, acc_out, aA, bA, aB, bB);
+  return launch_pair<double>(ctx, pair, in, y, acc, out, acc_out, aA, bA, aB, bB);
+}
+
 template <typename T>
 __global__ void lerp_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ out,
                             T theta, int64_t n) {
@@ -148,6 +156,8 @@ int advance_explicit(pdeopt_ctx* ctx, int integrator, double, double dt, int64_t
       group = (batch + ngroups - 1) / ngroups;
     }
   }
+  const bool fused = integrator == PDEOPT_INT_RK4 && ctx->opt_kernel_path != 1 &&
+                     (ctx->prob.dtype == PDEOPT_F32 ? fused_supported<float>(ctx) : fused_supported<double>(ctx));
   void* y_final = ctx->Y;
   void* ta_final = ctx->TA;
   for (int lo = 0; lo < batch; lo += group) {
@@ -158,6 +168,13 @@ int advance_explicit(pdeopt_ctx* ctx, int integrator, double, double dt, int64_t
     for (int64_t s = 0; s < n && !rc; ++s) {
       if (integrator == PDEOPT_INT_EULER) {
         rc = launch_stage(ctx, Y, Y, TA, nullptr, dt, 0.0, OUT_Y_PLUS_AK, ACC_NONE);
+        std::swap(Y, TA);
+        continue;
+      }
+      if (fused) {
+        // stages 1+2 and 3+4 as two temporally fused launches (7 words/cell instead of 16)
+        rc = launch_pair_dt(ctx, PAIR_12, Y, nullptr, nullptr, ctx->TB, ctx->ACC, dt / 2, dt / 6, dt / 2, dt / 3);
+        if (!rc) rc = launch_pair_dt(ctx, PAIR_34, ctx->TB, Y, ctx->ACC, TA, nullptr, dt, dt / 3, 0.0, dt / 6);
         std::swap(Y, TA);
         continue;
       }

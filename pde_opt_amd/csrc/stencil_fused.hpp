@@ -1,0 +1,337 @@
+// Temporally fused Runge-Kutta stage PAIRS for Cahn-Hilliard (gfx950).
+//
+// The per-stage kernel (stencil_tiled.hpp) moves the compulsory 16 words/cell of a classical RK4
+// substep (3+5+5+3).  Two consecutive stages can share one pass over HBM if the
+// intermediate stage input never leaves the chip: a workgroup loads its tile with a 4-cell halo,
+// evaluates stage A on the tile + 2 ring, keeps  w = base + a_A k_A  in LDS only, and evaluates
+// stage B on the tile from it.
+//
+//   PAIR_12:  k1 = f(y);  w = y + dt/2 k1;  k2 = f(w)
+//             TB  = y + dt/2 k2                       reads y            (1 word)
+//             ACC = y + dt/6 k1 + dt/3 k2             writes TB, ACC     (2 words)
+//   PAIR_34:  k3 = f(TB); w = y + dt k3;    k4 = f(w)
+//             Y'  = ACC + dt/3 k3 + dt/6 k4           reads TB, y, ACC   (3 words)
+//             (Y' is a different buffer: neighbours still read y on their ring)  writes Y' (1 word)
+//
+// = 7 words/cell/substep instead of 16, at the price of re-evaluating stage A on the 2-cell ring
+// (x1.33 at 16-row tiles, x1.2 at 32-row tiles) -- the halo re-reads are L2 hits (XCD-aware map).
+// Same arithmetic as the per-stage kernels (cahn_hilliard.py:89-109); the ring
+// and the interior go through one flux routine so a cell's value does not depend on which
+// workgroup computed it.
+//
+// Phases per tile (barrier between each):
+//   P1 stage-A input on tile+4            HBM -> LDS sU        (16-byte loads, wrap by index)
+//   P2 mu_A on tile+3                     sU  -> LDS sMu       (one closure evaluation per point)
+//   P3 k_A on own micro-tile + one ring vector per thread      -> registers
+//   P4 w on tile+2                        registers -> sU (in place)
+//   P5 mu_B on tile+1                     sU  -> sMu
+//   P6 k_B on own micro-tile, stage updates, 16-byte stores    -> HBM
+#pragma once
+
+#include "stencil_tiled.hpp"
+
+namespace pdeopt {
+
+enum { PAIR_12 = 0, PAIR_34 = 1 };
+
+template <typename T>
+struct PairArgs {
+  const T* in;    // stage-A input (PAIR_12: y;  PAIR_34: TB)
+  const T* y;     // substep base state (PAIR_34 only; PAIR_12 takes it from the tile)
+  const T* acc;   // PAIR_34: running accumulator (read)
+  T* out;         // PAIR_12: TB;  PAIR_34: Y'
+  T* acc_out;     // PAIR_12: ACC (write)
+  T aA, bA;       // w = base + aA kA ;  accp = (y | acc) + bA kA
+  T aB, bB;       // PAIR_12: out = y + aB kB, acc_out = accp + bB kB ;  PAIR_34: out = accp + bB kB
+  T rhx, rhy, rhx2, rhy2;
+  Geo g;
+  const EnvParams<T>* ep;
+  ClosureSpec mu, mob;
+};
+
+// k = div(D grad mu) for one vector of cells, given the three mu / u rows around it and the scalar
+// neighbours left and right of the centre row (derivatives.py:24-61, cahn_hilliard.py:105-109)
+template <typename T, int CL, typename Vec, int V>
+__device__ __forceinline__ Vec flux_divergence(const ClosureSpec& ms, const T* __restrict__ mcoef,
+                                               Vec m_dn, Vec m_c, Vec m_up, Vec u_dn, Vec u_c, Vec u_up,
+                                               T ml, T mr, T ul, T ur, T rhx, T rhy) {
+  Vec d_dn, d_c, d_up, k;
+#pragma unroll
+  for (int e = 0; e < V; ++e) {
+    d_dn[e] = eval_mob<T, CL>(ms, mcoef, u_dn[e]);
+    d_c[e] = eval_mob<T, CL>(ms, mcoef, u_c[e]);
+    d_up[e] = eval_mob<T, CL>(ms, mcoef, u_up[e]);
+  }
+  const T dl = eval_mob<T, CL>(ms, mcoef, ul), dr = eval_mob<T, CL>(ms, mcoef, ur);
+  T fy[V + 1];
+  fy[0] = (T(0.5) * (dl + d_c[0])) * ((m_c[0] - ml) * rhy);
+#pragma unroll
+  for (int e = 1; e < V; ++e) fy[e] = (T(0.5) * (d_c[e - 1] + d_c[e])) * ((m_c[e] - m_c[e - 1]) * rhy);
+  fy[V] = (T(0.5) * (d_c[V - 1] + dr)) * ((mr - m_c[V - 1]) * rhy);
+#pragma unroll
+  for (int e = 0; e < V; ++e) {
+    const T fx_hi = (T(0.5) * (d_c[e] + d_up[e])) * ((m_up[e] - m_c[e]) * rhx);
+    const T fx_lo = (T(0.5) * (d_dn[e] + d_c[e])) * ((m_c[e] - m_dn[e]) * rhx);
+    k[e] = (fx_hi - fx_lo) * rhx + (fy[e + 1] - fy[e]) * rhy;
+  }
+  return k;
+}
+
+template <typename T, int RPT>
+constexpr size_t fused_lds_bytes() {
+  constexpr int V = VecOf<T>::V;
+  constexpr int HV = 4 / V;            // halo vectors per side (4 columns)
+  constexpr int PV = kLanesPerRow + 2 * HV;
+  return ((size_t)(8 * RPT + 8) * PV * V + (size_t)(8 * RPT + 6) * PV * V + 4 * V) * sizeof(T);
+}
+
+template <typename T, int CL, int PAIR, int RPT>
+__global__ __launch_bounds__(256) void stage_pair_kernel(const PairArgs<T> a, const int tiles_i,
+                                                         const int tiles_j, const int nblk,
+                                                         const int xcd_remap) {
+  using Vec = typename VecOf<T>::type;
+  constexpr int V = VecOf<T>::V;
+  constexpr int HV = 4 / V;
+  constexpr int TX = 8 * RPT;
+  constexpr int PV = kLanesPerRow + 2 * HV;
+  constexpr int P = PV * V;
+  constexpr int TY = kLanesPerRow * V;
+
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  T* const sU = reinterpret_cast<T*>(smem_raw) + V;   // rows: tile row + 4, cols: tile col + HV*V
+  T* const sMu = sU + (TX + 8) * P + V;               // rows: tile row + 3
+
+  int t = blockIdx.x;
+  if (xcd_remap) t = (t & 7) * (nblk >> 3) + (t >> 3);
+  const int tj = t % tiles_j;
+  const int ti = (t / tiles_j) % tiles_i;
+  const int b = t / (tiles_j * tiles_i);
+  const int i0 = ti * TX;
+  const int j0 = tj * TY;
+
+  const Geo& g = a.g;
+  const int64_t ld = g.ld;
+  const int64_t base = (int64_t)b * g.bstride + g.off;
+  const EnvParams<T>& p = a.ep[b];
+  const T* __restrict__ in = a.in + base;
+  const T kap = p.kappa;
+
+  const int tid = threadIdx.x;
+  const int lx = tid & 31;
+  const int ly = tid >> 5;
+  const int r0 = ly * RPT;
+  const int cvo = lx + HV;  // this thread's vector column in the LDS arrays
+
+  // ring vector of this thread (tile + 2 ring minus the tile): 4 full rows + 2 side vectors per row
+  constexpr int kRingRowVecs = kLanesPerRow + 2;
+  constexpr int kRingTop = 4 * kRingRowVecs;
+  constexpr int kRing = kRingTop + 2 * TX;
+  static_assert(kRing <= 256, "ring must fit one pass");
+  int ring_r = 0, ring_cv = 0;  // tile row / LDS vector column
+  const bool has_ring = tid < kRing;
+  if (tid < kRingTop) {
+    const int q = tid / kRingRowVecs;
+    ring_r = (q < 2) ? (q - 2) : (TX + q - 2);
+    ring_cv = HV - 1 + (tid - q * kRingRowVecs);
+  } else if (has_ring) {
+    const int t2 = tid - kRingTop;
+    ring_r = t2 >> 1;
+    ring_cv = (t2 & 1) ? (HV + kLanesPerRow) : (HV - 1);
+  }
+
+  auto wrap_row = [&](int gi) {
+    if (g.periodic) {
+      if (gi < 0) gi += g.nx;
+      if (gi >= g.nx) gi -= g.nx;
+    }
+    return gi;
+  };
+  auto wrap_col = [&](int gj) {
+    if (g.periodic) {
+      if (gj < 0) gj += g.ny;
+      if (gj >= g.ny) gj -= g.ny;
+    }
+    return gj;
+  };
+
+  // ---- prefetch pointwise operands (PAIR_34: y on own cells + ring, acc on own cells)
+  const int64_t pidx0 = base + (int64_t)(i0 + r0) * ld + (j0 + lx * V);
+  Vec ybase[RPT], accp[RPT], yring;
+  if constexpr (PAIR == PAIR_34) {
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) {
+      ybase[r] = *reinterpret_cast<const Vec*>(a.y + pidx0 + r * ld);
+      accp[r] = *reinterpret_cast<const Vec*>(a.acc + pidx0 + r * ld);
+    }
+    if (has_ring) {
+      const int gi = wrap_row(i0 + ring_r);
+      const int gj = wrap_col(j0 + (ring_cv - HV) * V);
+      yring = *reinterpret_cast<const Vec*>(a.y + base + (int64_t)gi * ld + gj);
+    }
+  }
+
+  // ---- P1: stage-A input, tile + 4
+  constexpr int kLoadVecs = (TX + 8) * PV;
+#pragma unroll
+  for (int it = 0; it < (kLoadVecs + 255) / 256; ++it) {
+    const int idx = tid + it * 256;
+    if (idx < kLoadVecs) {
+      const int row = idx / PV;
+      const int cv = idx - row * PV;
+      const int gi = wrap_row(i0 - 4 + row);
+      const int gj = wrap_col(j0 - HV * V + cv * V);
+      *reinterpret_cast<Vec*>(sU + row * P + cv * V) = *reinterpret_cast<const Vec*>(in + (int64_t)gi * ld + gj);
+    }
+  }
+  __syncthreads();
+
+  // mu on `nrows` rows starting at mu-row `rm0` (mu row rm <-> sU row rm + 1)
+  auto mu_pass = [&](const int rm0, const int nrows) {
+    const int nvec = nrows * PV;
+#pragma unroll 1
+    for (int idx = tid; idx < nvec; idx += 256) {
+      const int rr = idx / PV;
+      const int cv = idx - rr * PV;
+      const int rm = rm0 + rr;
+      const T* c_ = sU + (rm + 1) * P + cv * V;
+      const Vec c = *reinterpret_cast<const Vec*>(c_);
+      const Vec xp = *reinterpret_cast<const Vec*>(c_ + P);
+      const Vec xm = *reinterpret_cast<const Vec*>(c_ - P);
+      const T left = c_[-1], right = c_[V];
+      Vec m;
+#pragma unroll
+      for (int e = 0; e < V; ++e) {
+        const T ym = (e == 0) ? left : c[e - 1];
+        const T yp = (e == V - 1) ? right : c[e + 1];
+        m[e] = eval_mu<T, CL>(a.mu, p.mu, c[e]) - kap * lap_at<T>(c[e], xp[e], xm[e], yp, ym, a.rhx2, a.rhy2);
+      }
+      *reinterpret_cast<Vec*>(sMu + rm * P + cv * V) = m;
+    }
+  };
+
+  // k at one vector: tile row r, LDS vector column cv
+  auto k_at = [&](const int r, const int cv, Vec* centre) -> Vec {
+    const T* mp = sMu + (r + 3) * P + cv * V;
+    const T* up = sU + (r + 4) * P + cv * V;
+    const Vec u_c = *reinterpret_cast<const Vec*>(up);
+    if (centre) *centre = u_c;
+    return flux_divergence<T, CL, Vec, V>(
+        a.mob, p.mob, *reinterpret_cast<const Vec*>(mp - P), *reinterpret_cast<const Vec*>(mp),
+        *reinterpret_cast<const Vec*>(mp + P), *reinterpret_cast<const Vec*>(up - P), u_c,
+        *reinterpret_cast<const Vec*>(up + P), mp[-1], mp[V], up[-1], up[V], a.rhx, a.rhy);
+  };
+
+  // ---- P2: mu_A on tile + 3 (mu rows 0 .. TX+5)
+  mu_pass(0, TX + 6);
+  __syncthreads();
+
+  // ---- P3: k_A on the own micro-tile and on one ring vector
+  Vec w_own[RPT], yown[RPT], w_ring;
+#pragma unroll
+  for (int r = 0; r < RPT; ++r) {
+    Vec uc;
+    const Vec kA = k_at(r0 + r, cvo, &uc);
+    if constexpr (PAIR == PAIR_12) {
+      yown[r] = uc;                 // the stage-A input IS y
+      w_own[r] = uc + a.aA * kA;
+      accp[r] = uc + a.bA * kA;
+    } else {
+      w_own[r] = ybase[r] + a.aA * kA;
+      accp[r] = accp[r] + a.bA * kA;
+    }
+  }
+  if (has_ring) {
+    Vec uc;
+    const Vec kA = k_at(ring_r, ring_cv, &uc);
+    if constexpr (PAIR == PAIR_12)
+      w_ring = uc + a.aA * kA;
+    else
+      w_ring = yring + a.aA * kA;
+  }
+  __syncthreads();
+
+  // ---- P4: w -> sU in place (tile + 2)
+#pragma unroll
+  for (int r = 0; r < RPT; ++r) *reinterpret_cast<Vec*>(sU + (r0 + r + 4) * P + cvo * V) = w_own[r];
+  if (has_ring) *reinterpret_cast<Vec*>(sU + (ring_r + 4) * P + ring_cv * V) = w_ring;
+  __syncthreads();
+
+  // ---- P5: mu_B on tile + 1 (mu rows 2 .. TX+3)
+  mu_pass(2, TX + 2);
+  __syncthreads();
+
+  // ---- P6: k_B, stage updates, stores
+#pragma unroll
+  for (int r = 0; r < RPT; ++r) {
+    const Vec kB = k_at(r0 + r, cvo, nullptr);
+    const int64_t idx = pidx0 + r * ld;
+    if constexpr (PAIR == PAIR_12) {
+      *reinterpret_cast<Vec*>(a.out + idx) = yown[r] + a.aB * kB;
+      *reinterpret_cast<Vec*>(a.acc_out + idx) = accp[r] + a.bB * kB;
+    } else {
+      *reinterpret_cast<Vec*>(a.out + idx) = accp[r] + a.bB * kB;
+    }
+  }
+}
+
+// --------------------------------------------------------------------------------------------- host
+
+template <typename T>
+bool fused_supported(const pdeopt_ctx* ctx) {
+  if (ctx->opt_fuse_stages < 0) return false;
+  if (ctx->prob.equation != PDEOPT_EQ_CAHN_HILLIARD) return false;
+  if (!tiled_supported<T>(ctx)) return false;
+  return classify_closures(ctx->prob.mu, ctx->prob.mob) != CL_GENERIC;
+}
+
+template <typename T, int CL, int PAIR, int RPT>
+int launch_pair_inst(pdeopt_ctx* ctx, const PairArgs<T>& s) {
+  constexpr int V = VecOf<T>::V;
+  const pdeopt_problem& p = ctx->prob;
+  const int tiles_i = p.nx / (8 * RPT);
+  const int tiles_j = p.ny / (kLanesPerRow * V);
+  const int64_t nblk64 = (int64_t)tiles_i * tiles_j * ctx->win_n;
+  if (nblk64 > 0x7fffffffLL) return fail(ctx, PDEOPT_EINVAL, "too many tiles");
+  const int nblk = (int)nblk64;
+  const size_t lds = fused_lds_bytes<T, RPT>();
+  hipLaunchKernelGGL((stage_pair_kernel<T, CL, PAIR, RPT>), dim3(nblk), dim3(256), lds, ctx->stream,
+                     s, tiles_i, tiles_j, nblk, (nblk % 8 == 0) ? 1 : 0);
+  PDEOPT_HIP_CHECK(ctx, hipGetLastError());
+  return PDEOPT_OK;
+}
+
+template <typename T>
+int launch_pair(pdeopt_ctx* ctx, int pair, const void* in, const void* y, const void* acc, void* out,
+                void* acc_out, double aA, double bA, double aB, double bB) {
+  const pdeopt_problem& p = ctx->prob;
+  PairArgs<T> s{};
+  const int64_t woff = (int64_t)ctx->win_lo * p.nx * p.ny;
+  s.in = static_cast<const T*>(in) + woff;
+  s.y = y ? static_cast<const T*>(y) + woff : nullptr;
+  s.acc = acc ? static_cast<const T*>(acc) + woff : nullptr;
+  s.out = static_cast<T*>(out) + woff;
+  s.acc_out = acc_out ? static_cast<T*>(acc_out) + woff : nullptr;
+  s.aA = T(aA); s.bA = T(bA); s.aB = T(aB); s.bB = T(bB);
+  s.rhx = T(1.0 / p.hx); s.rhy = T(1.0 / p.hy);
+  s.rhx2 = T(1.0 / (p.hx * p.hx)); s.rhy2 = T(1.0 / (p.hy * p.hy));
+  s.g.nx = p.nx; s.g.ny = p.ny; s.g.ld = p.ny; s.g.off = 0;
+  s.g.bstride = (int64_t)p.nx * p.ny; s.g.periodic = 1;
+  s.ep = static_cast<const EnvParams<T>*>(ctx->env_params_dev) + ctx->win_lo;
+  s.mu = ClosureSpec{p.mu.kind, p.mu.flags, p.mu.n};
+  s.mob = ClosureSpec{p.mob.kind, p.mob.flags, p.mob.n};
+  ctx->n_stage_launches++;
+  const int cl = classify_closures(p.mu, p.mob);
+  const int rpt = tiled_rpt(ctx);
+  char name[96];
+  snprintf(name, sizeof(name), "stage_pair<%s,CH,%s,rows%d>", sizeof(T) == 4 ? "f32" : "f64",
+           cl == CL_LOGIT ? "logit" : "poly", 8 * rpt);
+  ctx->last_kernel = name;
+#define PDEOPT_PAIR_DISPATCH(CLV, PAIRV)                                             \
+  (rpt == 2 ? launch_pair_inst<T, CLV, PAIRV, 2>(ctx, s) : launch_pair_inst<T, CLV, PAIRV, 4>(ctx, s))
+  if (cl == CL_LOGIT)
+    return pair == PAIR_12 ? PDEOPT_PAIR_DISPATCH(CL_LOGIT, PAIR_12) : PDEOPT_PAIR_DISPATCH(CL_LOGIT, PAIR_34);
+  return pair == PAIR_12 ? PDEOPT_PAIR_DISPATCH(CL_POLY, PAIR_12) : PDEOPT_PAIR_DISPATCH(CL_POLY, PAIR_34);
+#undef PDEOPT_PAIR_DISPATCH
+}
+
+}  // namespace pdeopt

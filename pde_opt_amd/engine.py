@@ -81,6 +81,9 @@ class HipEngine:
     def set_tile_rows(self, rows: int):
         self._check(self._lib.pdeopt_set_option(self._h, L.OPT_TILE_ROWS, int(rows)))
 
+    def set_fuse_stages(self, v: int):
+        self._check(self._lib.pdeopt_set_option(self._h, L.OPT_FUSE_STAGES, int(v)))
+
     def set_group_envs(self, n: int):
         self._check(self._lib.pdeopt_set_option(self._h, L.OPT_GROUP_ENVS, int(n)))
 
