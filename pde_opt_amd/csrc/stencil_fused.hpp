@@ -49,30 +49,54 @@ struct PairArgs {
   ClosureSpec mu, mob;
 };
 
+// flux through the face between cells a and b (b = a + 1 along the axis with spacing 1/rh):
+// avg_face(D) * grad_face(mu)  (derivatives.py:24-31,39-46; cahn_hilliard.py:105-106).  Every face
+// value in this file goes through this one expression so that a face shared by two rows, two
+// threads or two workgroups evaluates to the same bits.
+template <typename T>
+__device__ __forceinline__ T face_flux(T d_a, T d_b, T m_a, T m_b, T rh) {
+  return (T(0.5) * (d_a + d_b)) * ((m_b - m_a) * rh);
+}
+
+// y-divergence of the face fluxes of one vector of cells (needs the scalar neighbours left / right)
+template <typename T, typename Vec, int V>
+__device__ __forceinline__ Vec div_y(Vec m_c, Vec d_c, T ml, T mr, T dl, T dr, T rhy) {
+  T fy[V + 1];
+  fy[0] = face_flux<T>(dl, d_c[0], ml, m_c[0], rhy);
+#pragma unroll
+  for (int e = 1; e < V; ++e) fy[e] = face_flux<T>(d_c[e - 1], d_c[e], m_c[e - 1], m_c[e], rhy);
+  fy[V] = face_flux<T>(d_c[V - 1], dr, m_c[V - 1], mr, rhy);
+  Vec r;
+#pragma unroll
+  for (int e = 0; e < V; ++e) r[e] = (fy[e + 1] - fy[e]) * rhy;
+  return r;
+}
+
+template <typename T, int CL, typename Vec, int V>
+__device__ __forceinline__ Vec mob_vec(const ClosureSpec& ms, const T* __restrict__ mcoef, Vec u) {
+  Vec d;
+#pragma unroll
+  for (int e = 0; e < V; ++e) d[e] = eval_mob<T, CL>(ms, mcoef, u[e]);
+  return d;
+}
+
 // k = div(D grad mu) for one vector of cells, given the three mu / u rows around it and the scalar
-// neighbours left and right of the centre row (derivatives.py:24-61, cahn_hilliard.py:105-109)
+// neighbours left and right of the centre row (derivatives.py:54-61, cahn_hilliard.py:109)
 template <typename T, int CL, typename Vec, int V>
 __device__ __forceinline__ Vec flux_divergence(const ClosureSpec& ms, const T* __restrict__ mcoef,
                                                Vec m_dn, Vec m_c, Vec m_up, Vec u_dn, Vec u_c, Vec u_up,
                                                T ml, T mr, T ul, T ur, T rhx, T rhy) {
-  Vec d_dn, d_c, d_up, k;
-#pragma unroll
-  for (int e = 0; e < V; ++e) {
-    d_dn[e] = eval_mob<T, CL>(ms, mcoef, u_dn[e]);
-    d_c[e] = eval_mob<T, CL>(ms, mcoef, u_c[e]);
-    d_up[e] = eval_mob<T, CL>(ms, mcoef, u_up[e]);
-  }
+  const Vec d_dn = mob_vec<T, CL, Vec, V>(ms, mcoef, u_dn);
+  const Vec d_c = mob_vec<T, CL, Vec, V>(ms, mcoef, u_c);
+  const Vec d_up = mob_vec<T, CL, Vec, V>(ms, mcoef, u_up);
   const T dl = eval_mob<T, CL>(ms, mcoef, ul), dr = eval_mob<T, CL>(ms, mcoef, ur);
-  T fy[V + 1];
-  fy[0] = (T(0.5) * (dl + d_c[0])) * ((m_c[0] - ml) * rhy);
-#pragma unroll
-  for (int e = 1; e < V; ++e) fy[e] = (T(0.5) * (d_c[e - 1] + d_c[e])) * ((m_c[e] - m_c[e - 1]) * rhy);
-  fy[V] = (T(0.5) * (d_c[V - 1] + dr)) * ((mr - m_c[V - 1]) * rhy);
+  const Vec dy = div_y<T, Vec, V>(m_c, d_c, ml, mr, dl, dr, rhy);
+  Vec k;
 #pragma unroll
   for (int e = 0; e < V; ++e) {
-    const T fx_hi = (T(0.5) * (d_c[e] + d_up[e])) * ((m_up[e] - m_c[e]) * rhx);
-    const T fx_lo = (T(0.5) * (d_dn[e] + d_c[e])) * ((m_c[e] - m_dn[e]) * rhx);
-    k[e] = (fx_hi - fx_lo) * rhx + (fy[e + 1] - fy[e]) * rhy;
+    const T fx_hi = face_flux<T>(d_c[e], d_up[e], m_c[e], m_up[e], rhx);
+    const T fx_lo = face_flux<T>(d_dn[e], d_c[e], m_dn[e], m_c[e], rhx);
+    k[e] = (fx_hi - fx_lo) * rhx + dy[e];
   }
   return k;
 }
@@ -221,23 +245,63 @@ __global__ __launch_bounds__(256) void stage_pair_kernel(const PairArgs<T> a, co
         *reinterpret_cast<const Vec*>(up + P), mp[-1], mp[V], up[-1], up[V], a.rhx, a.rhy);
   };
 
+  // k on the own micro-tile (RPT rows x 1 vector), marching down the rows so every mu / u row is
+  // read once and every x-face flux is formed once
+  auto march = [&](Vec* kout, Vec* centre) {
+    const T* mp = sMu + (r0 + 2) * P + cvo * V;  // row r0 - 1
+    const T* up = sU + (r0 + 3) * P + cvo * V;
+    Vec m_lo = *reinterpret_cast<const Vec*>(mp);
+    Vec d_lo = mob_vec<T, CL, Vec, V>(a.mob, p.mob, *reinterpret_cast<const Vec*>(up));
+    mp += P;
+    up += P;
+    Vec m_c = *reinterpret_cast<const Vec*>(mp);
+    Vec u_c = *reinterpret_cast<const Vec*>(up);
+    Vec d_c = mob_vec<T, CL, Vec, V>(a.mob, p.mob, u_c);
+    Vec fx_lo;
+#pragma unroll
+    for (int e = 0; e < V; ++e) fx_lo[e] = face_flux<T>(d_lo[e], d_c[e], m_lo[e], m_c[e], a.rhx);
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) {
+      const Vec m_hi = *reinterpret_cast<const Vec*>(mp + P);
+      const Vec u_hi = *reinterpret_cast<const Vec*>(up + P);
+      const Vec d_hi = mob_vec<T, CL, Vec, V>(a.mob, p.mob, u_hi);
+      const T dl = eval_mob<T, CL>(a.mob, p.mob, up[-1]), dr = eval_mob<T, CL>(a.mob, p.mob, up[V]);
+      const Vec dy = div_y<T, Vec, V>(m_c, d_c, mp[-1], mp[V], dl, dr, a.rhy);
+      Vec fx_hi, k;
+#pragma unroll
+      for (int e = 0; e < V; ++e) {
+        fx_hi[e] = face_flux<T>(d_c[e], d_hi[e], m_c[e], m_hi[e], a.rhx);
+        k[e] = (fx_hi[e] - fx_lo[e]) * a.rhx + dy[e];
+      }
+      kout[r] = k;
+      if (centre) centre[r] = u_c;
+      m_c = m_hi;
+      u_c = u_hi;
+      d_c = d_hi;
+      fx_lo = fx_hi;
+      mp += P;
+      up += P;
+    }
+  };
+
   // ---- P2: mu_A on tile + 3 (mu rows 0 .. TX+5)
   mu_pass(0, TX + 6);
   __syncthreads();
 
   // ---- P3: k_A on the own micro-tile and on one ring vector
   Vec w_own[RPT], yown[RPT], w_ring;
+  {
+    Vec kA[RPT];
+    march(kA, yown);  // PAIR_12: the stage-A input IS y
 #pragma unroll
-  for (int r = 0; r < RPT; ++r) {
-    Vec uc;
-    const Vec kA = k_at(r0 + r, cvo, &uc);
-    if constexpr (PAIR == PAIR_12) {
-      yown[r] = uc;                 // the stage-A input IS y
-      w_own[r] = uc + a.aA * kA;
-      accp[r] = uc + a.bA * kA;
-    } else {
-      w_own[r] = ybase[r] + a.aA * kA;
-      accp[r] = accp[r] + a.bA * kA;
+    for (int r = 0; r < RPT; ++r) {
+      if constexpr (PAIR == PAIR_12) {
+        w_own[r] = yown[r] + a.aA * kA[r];
+        accp[r] = yown[r] + a.bA * kA[r];
+      } else {
+        w_own[r] = ybase[r] + a.aA * kA[r];
+        accp[r] = accp[r] + a.bA * kA[r];
+      }
     }
   }
   if (has_ring) {
@@ -261,15 +325,16 @@ __global__ __launch_bounds__(256) void stage_pair_kernel(const PairArgs<T> a, co
   __syncthreads();
 
   // ---- P6: k_B, stage updates, stores
+  Vec kB[RPT];
+  march(kB, nullptr);
 #pragma unroll
   for (int r = 0; r < RPT; ++r) {
-    const Vec kB = k_at(r0 + r, cvo, nullptr);
     const int64_t idx = pidx0 + r * ld;
     if constexpr (PAIR == PAIR_12) {
-      *reinterpret_cast<Vec*>(a.out + idx) = yown[r] + a.aB * kB;
-      *reinterpret_cast<Vec*>(a.acc_out + idx) = accp[r] + a.bB * kB;
+      *reinterpret_cast<Vec*>(a.out + idx) = yown[r] + a.aB * kB[r];
+      *reinterpret_cast<Vec*>(a.acc_out + idx) = accp[r] + a.bB * kB[r];
     } else {
-      *reinterpret_cast<Vec*>(a.out + idx) = accp[r] + a.bB * kB;
+      *reinterpret_cast<Vec*>(a.out + idx) = accp[r] + a.bB * kB[r];
     }
   }
 }
