@@ -138,7 +138,7 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     dist = None
-    if world > 1:
+    if world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ):  # launched by torchrun
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         import torch
         import torch.distributed as dist

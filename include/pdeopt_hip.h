@@ -122,6 +122,9 @@ typedef enum {
                                  environments so a group's working set stays in the 256 MiB
                                  Infinity Cache across stages and substeps (0 = auto, < 0 = whole
                                  batch in one sweep) */
+  PDEOPT_OPT_HALO_LAYOUT = 5, /* layout of the NEXT pdeopt_configure: 0 = periodic field (wrap by index),
+                                 4 = rank-local tile padded by a 4-cell halo on every side, no wrap
+                                 (domain decomposition; halos filled by pdeopt_halo_unpack) */
   PDEOPT_OPT_FUSE_STAGES = 4, /* RK4: temporally fused stage pairs (1+2, 3+4): 0 = auto (on where a
                                  fused kernel exists), -1 = off (one launch per stage) */
   PDEOPT_OPT_DEBUG_ABLATE = 3 /* TIMING ONLY, results are wrong: bit0 skip the mu phase, bit1 skip
@@ -169,6 +172,31 @@ int pdeopt_get_interpolated(pdeopt_ctx* ctx, double theta, int env_first, int en
                             void* host_out);
 /* per-environment reductions of the state (reward helpers); out is [batch] doubles. */
 int pdeopt_reduce(pdeopt_ctx* ctx, int op, double* out_per_env);
+
+/* ---- domain decomposition of one large field (BASELINE config 5; no reference counterpart) -----
+ * With PDEOPT_OPT_HALO_LAYOUT = 4 a ctx holds one rank's tile.  Per RK4 substep the caller runs
+ *     for phase in 0..nphases-1:  pack(fields[phase]) -> all-gather strips -> unpack -> rk4_phase(phase)
+ * fields[] / nphases come from pdeopt_rk4_phase_plan (2 phases with fused stage pairs, else 4).
+ * Field ids: 0 = state Y, 1 = TA, 2 = TB, 3 = ACC.  A strip is pdeopt_halo_strip_elems() elements of
+ * the problem dtype: [top h rows][bottom h rows][left h cols][right h cols][TL][TR][BL][BR] of the
+ * tile INTERIOR.  dev_send / dev_recv are DEVICE pointers (e.g. torch tensors handed to RCCL);
+ * dev_recv holds the strips of all ranks, rank-major.  neighbours[8] = ranks of
+ * {up, down, left, right, up-left, up-right, down-left, down-right} (up = smaller x index).
+ * NULL dev_send / dev_recv selects an internal loop-back buffer (single rank, every neighbour 0). */
+int pdeopt_halo_strip_elems(pdeopt_ctx* ctx, int64_t* elems);
+int pdeopt_halo_pack(pdeopt_ctx* ctx, int field, void* dev_send);
+int pdeopt_halo_unpack(pdeopt_ctx* ctx, int field, const void* dev_recv, const int* neighbours);
+int pdeopt_rk4_phase_plan(pdeopt_ctx* ctx, int* fields /* [4] */, int* nphases);
+int pdeopt_rk4_phase(pdeopt_ctx* ctx, int phase, double dt);
+/* ctx whose work is ordered on a caller-owned HIP stream (e.g. torch's current stream, so RCCL
+ * collectives issued through torch.distributed order with the kernels without host syncs) */
+int pdeopt_ctx_create_on_stream(int device, void* hip_stream, pdeopt_ctx** out);
+
+/* caller-owned device buffers (halo strips when no tensor library is at hand) */
+typedef enum { PDEOPT_COPY_H2D = 0, PDEOPT_COPY_D2H = 1, PDEOPT_COPY_D2D = 2 } pdeopt_copy_kind;
+int pdeopt_buffer_alloc(pdeopt_ctx* ctx, int64_t bytes, void** dev);
+int pdeopt_buffer_free(pdeopt_ctx* ctx, void* dev);
+int pdeopt_buffer_copy(pdeopt_ctx* ctx, void* dst, const void* src, int64_t bytes, int kind);
 
 /* ---- Tsit5 building blocks for host-driven adaptive stepping (row f1) ----------------------- */
 /* one trial step of size dt from the current state: on return err_norm[batch] holds the

@@ -31,7 +31,10 @@ OPT_TILE_ROWS = 1
 OPT_GROUP_ENVS = 2
 OPT_DEBUG_ABLATE = 3
 OPT_FUSE_STAGES = 4
+OPT_HALO_LAYOUT = 5
 CNT_STAGE_LAUNCHES = 0
+COPY_H2D, COPY_D2H, COPY_D2D = 0, 1, 2
+FIELD_Y, FIELD_TA, FIELD_TB, FIELD_ACC = 0, 1, 2, 3
 PATH_AUTO, PATH_GENERIC, PATH_TILED = 0, 1, 2
 
 
@@ -95,6 +98,15 @@ _SIGNATURES = {
     "pdeopt_reduce": (C.c_int, [_VP, C.c_int, _VP]),
     "pdeopt_tsit5_trial": (C.c_int, [_VP, C.c_double, C.c_double, C.c_double, C.c_double, _VP]),
     "pdeopt_tsit5_commit": (C.c_int, [_VP, C.c_int]),
+    "pdeopt_halo_strip_elems": (C.c_int, [_VP, C.POINTER(C.c_int64)]),
+    "pdeopt_halo_pack": (C.c_int, [_VP, C.c_int, _VP]),
+    "pdeopt_halo_unpack": (C.c_int, [_VP, C.c_int, _VP, C.POINTER(C.c_int)]),
+    "pdeopt_rk4_phase_plan": (C.c_int, [_VP, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "pdeopt_rk4_phase": (C.c_int, [_VP, C.c_int, C.c_double]),
+    "pdeopt_ctx_create_on_stream": (C.c_int, [C.c_int, _VP, C.POINTER(_VP)]),
+    "pdeopt_buffer_alloc": (C.c_int, [_VP, C.c_int64, C.POINTER(_VP)]),
+    "pdeopt_buffer_free": (C.c_int, [_VP, _VP]),
+    "pdeopt_buffer_copy": (C.c_int, [_VP, _VP, _VP, C.c_int64, C.c_int]),
     "pdeopt_get_counter": (C.c_int, [_VP, C.c_int, C.POINTER(C.c_int64)]),
     "pdeopt_sync": (C.c_int, [_VP]),
     "pdeopt_timer_start": (C.c_int, [_VP]),

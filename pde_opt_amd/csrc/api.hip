@@ -162,7 +162,8 @@ int pdeopt_ctx_destroy(pdeopt_ctx* ctx) {
   if (ctx->red_mean_dev) (void)hipFree(ctx->red_mean_dev);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
-  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  if (ctx->stream && !ctx->stream_borrowed) (void)hipStreamDestroy(ctx->stream);
+  if (ctx->halo_scratch) (void)hipFree(ctx->halo_scratch);
   delete ctx;
   return PDEOPT_OK;
 }
@@ -184,6 +185,11 @@ int pdeopt_set_option(pdeopt_ctx* ctx, int option, int64_t value) {
       if (value != 0 && value != 16 && value != 32)
         return fail(ctx, PDEOPT_EINVAL, "tile rows must be 0 (auto), 16 or 32");
       ctx->opt_tile_rows = value;
+      return PDEOPT_OK;
+    case PDEOPT_OPT_HALO_LAYOUT:
+      if (value != 0 && value != 4)
+        return fail(ctx, PDEOPT_EINVAL, "halo layout must be 0 (periodic) or 4 (padded tiles)");
+      ctx->opt_halo = value;
       return PDEOPT_OK;
     case PDEOPT_OPT_FUSE_STAGES:
       ctx->opt_fuse_stages = value;
@@ -221,7 +227,10 @@ int pdeopt_configure(pdeopt_ctx* ctx, const pdeopt_problem* pr) {
   if (ctx->prob.mob.n < 1) ctx->prob.mob.n = 1;
   ctx->esize = pr->dtype == PDEOPT_F32 ? 4 : 8;
   ctx->comps = pr->equation == PDEOPT_EQ_GPE ? 2 : 1;
-  ctx->env_elems = (size_t)pr->nx * pr->ny * ctx->comps;
+  ctx->halo = (int)ctx->opt_halo;
+  if (ctx->halo && pr->equation != PDEOPT_EQ_CAHN_HILLIARD && pr->equation != PDEOPT_EQ_ALLEN_CAHN)
+    return fail(ctx, PDEOPT_EINVAL, "the padded (domain-decomposition) layout covers CH / AC only");
+  ctx->env_elems = (size_t)(pr->nx + 2 * ctx->halo) * (pr->ny + 2 * ctx->halo) * ctx->comps;
   ctx->total_bytes = ctx->env_elems * pr->batch * ctx->esize;
   int rc;
   if ((rc = ensure_buffer(ctx, &ctx->Y, ctx->total_bytes))) return rc;
@@ -279,8 +288,17 @@ int pdeopt_set_state(pdeopt_ctx* ctx, int env_first, int env_count, const void* 
   if (rc) return rc;
   PDEOPT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   const size_t eb = ctx->env_elems * ctx->esize;
-  PDEOPT_HIP_CHECK(ctx, hipMemcpyAsync((char*)ctx->Y + eb * env_first, host, eb * env_count,
-                                       hipMemcpyHostToDevice, ctx->stream));
+  if (ctx->halo) {
+    // interior of each padded tile; halo cells are filled by pdeopt_halo_unpack
+    const size_t h = ctx->halo, pny = ctx->prob.ny + 2 * h, row = (size_t)ctx->prob.ny * ctx->esize;
+    for (int e = 0; e < env_count; ++e)
+      PDEOPT_HIP_CHECK(ctx, hipMemcpy2DAsync((char*)ctx->Y + eb * (env_first + e) + (h * pny + h) * ctx->esize,
+                                             pny * ctx->esize, (const char*)host + (size_t)e * row * ctx->prob.nx,
+                                             row, row, ctx->prob.nx, hipMemcpyHostToDevice, ctx->stream));
+  } else {
+    PDEOPT_HIP_CHECK(ctx, hipMemcpyAsync((char*)ctx->Y + eb * env_first, host, eb * env_count,
+                                         hipMemcpyHostToDevice, ctx->stream));
+  }
   PDEOPT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   ctx->tsit5_fsal_valid = false;
   ctx->tsit5_pending = false;
@@ -293,8 +311,17 @@ int pdeopt_get_state(pdeopt_ctx* ctx, int env_first, int env_count, void* host) 
   if (rc) return rc;
   PDEOPT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   const size_t eb = ctx->env_elems * ctx->esize;
-  PDEOPT_HIP_CHECK(ctx, hipMemcpyAsync(host, (char*)ctx->Y + eb * env_first, eb * env_count,
-                                       hipMemcpyDeviceToHost, ctx->stream));
+  if (ctx->halo) {
+    const size_t h = ctx->halo, pny = ctx->prob.ny + 2 * h, row = (size_t)ctx->prob.ny * ctx->esize;
+    for (int e = 0; e < env_count; ++e)
+      PDEOPT_HIP_CHECK(ctx, hipMemcpy2DAsync((char*)host + (size_t)e * row * ctx->prob.nx, row,
+                                             (const char*)ctx->Y + eb * (env_first + e) + (h * pny + h) * ctx->esize,
+                                             pny * ctx->esize, row, ctx->prob.nx, hipMemcpyDeviceToHost,
+                                             ctx->stream));
+  } else {
+    PDEOPT_HIP_CHECK(ctx, hipMemcpyAsync(host, (char*)ctx->Y + eb * env_first, eb * env_count,
+                                         hipMemcpyDeviceToHost, ctx->stream));
+  }
   PDEOPT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   return PDEOPT_OK;
 }
@@ -342,6 +369,8 @@ int pdeopt_advance(pdeopt_ctx* ctx, int integrator, double t0, double dt, int64_
   PDEOPT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   ctx->tsit5_fsal_valid = false;
   ctx->tsit5_pending = false;
+  if (ctx->halo)
+    return fail(ctx, PDEOPT_EINVAL, "padded layout: drive the substep with pdeopt_rk4_phase + halo exchange");
   const int eq = ctx->prob.equation;
   switch (integrator) {
     case PDEOPT_INT_EULER:
@@ -401,6 +430,7 @@ int pdeopt_get_interpolated(pdeopt_ctx* ctx, double theta, int env_first, int en
 int pdeopt_reduce(pdeopt_ctx* ctx, int op, double* out_per_env) {
   if (!ctx || !out_per_env) return PDEOPT_EINVAL;
   if (!ctx->configured) return fail(ctx, PDEOPT_ESTATE, "pdeopt_configure has not been called");
+  if (ctx->halo) return fail(ctx, PDEOPT_EINVAL, "reductions are not available in the padded layout");
   PDEOPT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   return reduce_state(ctx, op, out_per_env);
 }
@@ -431,6 +461,81 @@ int pdeopt_get_counter(pdeopt_ctx* ctx, int which, int64_t* value) {
     default:
       return fail(ctx, PDEOPT_EINVAL, "unknown counter %d", which);
   }
+}
+
+int pdeopt_halo_strip_elems(pdeopt_ctx* ctx, int64_t* elems) {
+  if (!ctx || !elems) return PDEOPT_EINVAL;
+  if (!ctx->configured || !ctx->halo) return fail(ctx, PDEOPT_ESTATE, "no padded layout is configured");
+  *elems = (int64_t)halo_strip_elems(ctx);
+  return PDEOPT_OK;
+}
+
+int pdeopt_halo_pack(pdeopt_ctx* ctx, int field, void* dev_send) {
+  if (!ctx) return PDEOPT_EINVAL;
+  if (!ctx->configured || !ctx->halo) return fail(ctx, PDEOPT_ESTATE, "no padded layout is configured");
+  PDEOPT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  return halo_pack(ctx, field, dev_send);
+}
+
+int pdeopt_halo_unpack(pdeopt_ctx* ctx, int field, const void* dev_recv, const int* neighbours) {
+  if (!ctx || !neighbours) return PDEOPT_EINVAL;
+  if (!ctx->configured || !ctx->halo) return fail(ctx, PDEOPT_ESTATE, "no padded layout is configured");
+  PDEOPT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  return halo_unpack(ctx, field, dev_recv, neighbours);
+}
+
+int pdeopt_rk4_phase_plan(pdeopt_ctx* ctx, int* fields, int* nphases) {
+  if (!ctx || !fields || !nphases) return PDEOPT_EINVAL;
+  if (!ctx->configured) return fail(ctx, PDEOPT_ESTATE, "pdeopt_configure has not been called");
+  return rk4_phase_plan(ctx, fields, nphases);
+}
+
+int pdeopt_rk4_phase(pdeopt_ctx* ctx, int phase, double dt) {
+  if (!ctx) return PDEOPT_EINVAL;
+  if (!ctx->configured) return fail(ctx, PDEOPT_ESTATE, "pdeopt_configure has not been called");
+  PDEOPT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  return rk4_phase(ctx, phase, dt);
+}
+
+int pdeopt_ctx_create_on_stream(int device, void* hip_stream, pdeopt_ctx** out) {
+  int rc = pdeopt_ctx_create(device, out);
+  if (rc) return rc;
+  if (hip_stream) {
+    (void)hipStreamDestroy((*out)->stream);
+    (*out)->stream = static_cast<hipStream_t>(hip_stream);
+    (*out)->stream_borrowed = true;
+  }
+  return PDEOPT_OK;
+}
+
+int pdeopt_buffer_alloc(pdeopt_ctx* ctx, int64_t bytes, void** dev) {
+  if (!ctx || !dev || bytes <= 0) return PDEOPT_EINVAL;
+  PDEOPT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  *dev = nullptr;
+  return ensure_buffer(ctx, dev, (size_t)bytes);
+}
+
+int pdeopt_buffer_free(pdeopt_ctx* ctx, void* dev) {
+  if (!ctx) return PDEOPT_EINVAL;
+  PDEOPT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  PDEOPT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  if (dev) PDEOPT_HIP_CHECK(ctx, hipFree(dev));
+  return PDEOPT_OK;
+}
+
+int pdeopt_buffer_copy(pdeopt_ctx* ctx, void* dst, const void* src, int64_t bytes, int kind) {
+  if (!ctx || !dst || !src || bytes < 0) return PDEOPT_EINVAL;
+  PDEOPT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  hipMemcpyKind k;
+  switch (kind) {
+    case PDEOPT_COPY_H2D: k = hipMemcpyHostToDevice; break;
+    case PDEOPT_COPY_D2H: k = hipMemcpyDeviceToHost; break;
+    case PDEOPT_COPY_D2D: k = hipMemcpyDeviceToDevice; break;
+    default: return fail(ctx, PDEOPT_EINVAL, "unknown copy kind %d", kind);
+  }
+  PDEOPT_HIP_CHECK(ctx, hipMemcpyAsync(dst, src, (size_t)bytes, k, ctx->stream));
+  PDEOPT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return PDEOPT_OK;
 }
 
 int pdeopt_sync(pdeopt_ctx* ctx) {

@@ -20,12 +20,13 @@ ROOT = os.path.dirname(PKG)
 LIB = os.path.join(PKG, "libpdeopt_hip.so")
 OBJ_DIR = os.path.join(HERE, "build")
 
-SOURCES = ["api.hip", "stencil.hip", "reduce.hip", "spectral.hip"]
+SOURCES = ["api.hip", "stencil.hip", "reduce.hip", "spectral.hip", "halo.hip"]
 HEADERS = [
     "common.hpp",
     "closures.hpp",
     "stencil_generic.hpp",
     "stencil_tiled.hpp",
+    "stencil_fused.hpp",
     os.path.join(ROOT, "include", "pdeopt_hip.h"),
 ]
 ARCH = "gfx950"

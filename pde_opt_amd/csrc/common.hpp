@@ -58,6 +58,7 @@ struct Spectral;  // rocFFT plans + work buffers (spectral.hip)
 struct pdeopt_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
+  bool stream_borrowed = false;  // stream belongs to the caller (pdeopt_ctx_create_on_stream)
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   std::string err;
   std::string last_kernel;
@@ -83,6 +84,10 @@ struct pdeopt_ctx {
   int64_t opt_tile_rows = 0;  // 0 auto, 16 or 32
   int64_t opt_group_envs = 0; // explicit integrators: envs per cache-resident group (0 auto, <0 whole batch)
   int64_t n_stage_launches = 0;  // fused stencil+update launches issued so far
+  int64_t opt_halo = 0;          // requested halo width of the NEXT configure (0 periodic, 4 padded)
+  int halo = 0;                  // halo width of the configured layout
+  void* halo_scratch = nullptr;  // single-rank loop-back buffer for pack/unpack
+  size_t halo_scratch_bytes = 0;
   int64_t opt_fuse_stages = 0;   // RK4 stage-pair fusion: 0 auto (on where supported), -1 off
   int64_t opt_debug_ablate = 0;  // timing-only ablations, results are wrong when set
   int win_lo = 0, win_n = 0;  // environment window the stage launchers operate on
@@ -94,6 +99,19 @@ struct pdeopt_ctx {
 };
 
 namespace pdeopt {
+
+// field geometry of the configured layout: periodic, or padded by ctx->halo cells on every side
+inline Geo make_geo(const pdeopt_ctx* ctx) {
+  Geo g;
+  const int h = ctx->halo;
+  g.nx = ctx->prob.nx;
+  g.ny = ctx->prob.ny;
+  g.ld = ctx->prob.ny + 2 * h;
+  g.off = (int64_t)h * g.ld + h;
+  g.bstride = (int64_t)(ctx->prob.nx + 2 * h) * g.ld;
+  g.periodic = h == 0 ? 1 : 0;
+  return g;
+}
 
 int fail(pdeopt_ctx* ctx, int code, const char* fmt, ...);
 
@@ -114,6 +132,13 @@ int tsit5_trial(pdeopt_ctx* ctx, double t, double dt, double rtol, double atol, 
 int tsit5_commit(pdeopt_ctx* ctx, int accept);
 int launch_lerp(pdeopt_ctx* ctx, const void* a, const void* b, void* out, double theta,
                 size_t env_first, size_t env_count);
+// halo.hip (domain decomposition: padded, non-periodic layout)
+int halo_pack(pdeopt_ctx* ctx, int field, void* dev_send);
+int halo_unpack(pdeopt_ctx* ctx, int field, const void* dev_recv, const int* nbr);
+size_t halo_strip_elems(const pdeopt_ctx* ctx);
+int rk4_phase(pdeopt_ctx* ctx, int phase, double dt);
+int rk4_phase_plan(pdeopt_ctx* ctx, int* fields, int* nphases);
+void* field_ptr(pdeopt_ctx* ctx, int field);
 // reduce.hip
 int reduce_state(pdeopt_ctx* ctx, int op, double* out);
 // spectral.hip

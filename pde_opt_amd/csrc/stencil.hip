@@ -21,7 +21,8 @@ StageArgs<T> make_args(pdeopt_ctx* ctx, const void* in, const void* y, void* out
   const pdeopt_problem& p = ctx->prob;
   StageArgs<T> s{};
   // environment window [win_lo, win_lo + win_n): pointers are pre-offset, kernels see a batch of win_n
-  const int64_t woff = (int64_t)ctx->win_lo * p.nx * p.ny;
+  s.g = make_geo(ctx);
+  const int64_t woff = (int64_t)ctx->win_lo * s.g.bstride;
   s.in = static_cast<const T*>(in) + woff;
   s.y = static_cast<const T*>(y) + woff;
   s.out = out ? static_cast<T*>(out) + woff : nullptr;
@@ -32,12 +33,6 @@ StageArgs<T> make_args(pdeopt_ctx* ctx, const void* in, const void* y, void* out
   s.rhy = T(1.0 / p.hy);
   s.rhx2 = T(1.0 / (p.hx * p.hx));
   s.rhy2 = T(1.0 / (p.hy * p.hy));
-  s.g.nx = p.nx;
-  s.g.ny = p.ny;
-  s.g.ld = p.ny;
-  s.g.off = 0;
-  s.g.bstride = (int64_t)p.nx * p.ny;
-  s.g.periodic = 1;
   s.ep = static_cast<const EnvParams<T>*>(ctx->env_params_dev) + ctx->win_lo;
   s.mu = ClosureSpec{p.mu.kind, p.mu.flags, p.mu.n};
   s.mob = ClosureSpec{p.mob.kind, p.mob.flags, p.mob.n};
@@ -196,6 +191,48 @@ int advance_explicit(pdeopt_ctx* ctx, int integrator, double, double dt, int64_t
   ctx->Y = y_final;
   ctx->TA = ta_final;
   return rc;
+}
+
+// One phase of an RK4 substep for callers that interleave their own work between phases (the
+// domain-decomposed driver exchanges halos of `fields[phase]` before `rk4_phase(phase)`).
+int rk4_phase_plan(pdeopt_ctx* ctx, int* fields, int* nphases) {
+  const bool fused = ctx->opt_kernel_path != 1 &&
+                     (ctx->prob.dtype == PDEOPT_F32 ? fused_supported<float>(ctx) : fused_supported<double>(ctx));
+  if (fused) {
+    *nphases = 2;
+    fields[0] = 0;  // Y  (stage pair 1+2 differentiates y)
+    fields[1] = 2;  // TB (stage pair 3+4 differentiates y + dt/2 k2)
+  } else {
+    *nphases = 4;
+    fields[0] = 0; fields[1] = 1; fields[2] = 2; fields[3] = 1;  // Y, TA, TB, TA
+  }
+  return PDEOPT_OK;
+}
+
+int rk4_phase(pdeopt_ctx* ctx, int phase, double dt) {
+  if (ctx->prob.equation == PDEOPT_EQ_GPE) return fail(ctx, PDEOPT_EINVAL, "no explicit RHS for the GPE");
+  int rc;
+  if ((rc = ensure_buffer(ctx, &ctx->TA, ctx->total_bytes))) return rc;
+  if ((rc = ensure_buffer(ctx, &ctx->TB, ctx->total_bytes))) return rc;
+  if ((rc = ensure_buffer(ctx, &ctx->ACC, ctx->total_bytes))) return rc;
+  int fields[4], n = 0;
+  rk4_phase_plan(ctx, fields, &n);
+  if (phase < 0 || phase >= n) return fail(ctx, PDEOPT_EINVAL, "phase %d outside 0..%d", phase, n - 1);
+  ctx->win_lo = 0;
+  ctx->win_n = ctx->prob.batch;
+  if (n == 2) {
+    if (phase == 0)
+      return launch_pair_dt(ctx, PAIR_12, ctx->Y, nullptr, nullptr, ctx->TB, ctx->ACC, dt / 2, dt / 6, dt / 2, dt / 3);
+    rc = launch_pair_dt(ctx, PAIR_34, ctx->TB, ctx->Y, ctx->ACC, ctx->TA, nullptr, dt, dt / 3, 0.0, dt / 6);
+    std::swap(ctx->Y, ctx->TA);
+    return rc;
+  }
+  switch (phase) {
+    case 0: return launch_stage(ctx, ctx->Y, ctx->Y, ctx->TA, ctx->ACC, dt / 2, dt / 6, OUT_Y_PLUS_AK, ACC_INIT);
+    case 1: return launch_stage(ctx, ctx->TA, ctx->Y, ctx->TB, ctx->ACC, dt / 2, dt / 3, OUT_Y_PLUS_AK, ACC_ADD);
+    case 2: return launch_stage(ctx, ctx->TB, ctx->Y, ctx->TA, ctx->ACC, dt, dt / 3, OUT_Y_PLUS_AK, ACC_ADD);
+    default: return launch_stage(ctx, ctx->TA, ctx->Y, ctx->Y, ctx->ACC, 0.0, dt / 6, OUT_ACC_PLUS_BK, ACC_NONE);
+  }
 }
 
 // ------------------------------------------------------------------------------------------

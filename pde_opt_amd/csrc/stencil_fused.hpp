@@ -370,7 +370,8 @@ int launch_pair(pdeopt_ctx* ctx, int pair, const void* in, const void* y, const 
                 void* acc_out, double aA, double bA, double aB, double bB) {
   const pdeopt_problem& p = ctx->prob;
   PairArgs<T> s{};
-  const int64_t woff = (int64_t)ctx->win_lo * p.nx * p.ny;
+  s.g = make_geo(ctx);
+  const int64_t woff = (int64_t)ctx->win_lo * s.g.bstride;
   s.in = static_cast<const T*>(in) + woff;
   s.y = y ? static_cast<const T*>(y) + woff : nullptr;
   s.acc = acc ? static_cast<const T*>(acc) + woff : nullptr;
@@ -379,8 +380,6 @@ int launch_pair(pdeopt_ctx* ctx, int pair, const void* in, const void* y, const 
   s.aA = T(aA); s.bA = T(bA); s.aB = T(aB); s.bB = T(bB);
   s.rhx = T(1.0 / p.hx); s.rhy = T(1.0 / p.hy);
   s.rhx2 = T(1.0 / (p.hx * p.hx)); s.rhy2 = T(1.0 / (p.hy * p.hy));
-  s.g.nx = p.nx; s.g.ny = p.ny; s.g.ld = p.ny; s.g.off = 0;
-  s.g.bstride = (int64_t)p.nx * p.ny; s.g.periodic = 1;
   s.ep = static_cast<const EnvParams<T>*>(ctx->env_params_dev) + ctx->win_lo;
   s.mu = ClosureSpec{p.mu.kind, p.mu.flags, p.mu.n};
   s.mob = ClosureSpec{p.mob.kind, p.mob.flags, p.mob.n};

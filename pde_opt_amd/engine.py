@@ -32,7 +32,9 @@ def _closure_struct(desc: Optional[ClosureDesc]) -> L.Closure:
 class HipEngine:
     """Owns a device context and the field buffers of one batched problem."""
 
-    def __init__(self, device: int = 0):
+    def __init__(self, device: int = 0, stream: Optional[int] = None):
+        """``stream``: optional HIP stream handle (e.g. ``torch.cuda.current_stream().cuda_stream``)
+        to order this engine's work on a caller-owned stream."""
         self._lib = L.load_library()
         n = L.device_count()
         if n <= 0:
@@ -41,7 +43,10 @@ class HipEngine:
                 "(there is no CPU fallback)"
             )
         h = C.c_void_p()
-        rc = self._lib.pdeopt_ctx_create(int(device), C.byref(h))
+        if stream:
+            rc = self._lib.pdeopt_ctx_create_on_stream(int(device), C.c_void_p(int(stream)), C.byref(h))
+        else:
+            rc = self._lib.pdeopt_ctx_create(int(device), C.byref(h))
         if rc != L.OK:
             raise L.PdeoptError(rc, self._lib.pdeopt_last_error(None).decode())
         self._h = h
@@ -214,6 +219,44 @@ class HipEngine:
 
     def tsit5_commit(self, accept: bool):
         self._check(self._lib.pdeopt_tsit5_commit(self._h, int(bool(accept))))
+
+    # -- domain decomposition (padded layout) ---------------------------------------------------
+    def set_halo_layout(self, halo: int):
+        """0 = periodic field, 4 = rank-local tile padded by a 4-cell halo (takes effect at the next configure)"""
+        self._check(self._lib.pdeopt_set_option(self._h, L.OPT_HALO_LAYOUT, int(halo)))
+
+    def halo_strip_elems(self) -> int:
+        v = C.c_int64()
+        self._check(self._lib.pdeopt_halo_strip_elems(self._h, C.byref(v)))
+        return v.value
+
+    def halo_pack(self, field: int, dev_send: Optional[int] = None):
+        self._check(self._lib.pdeopt_halo_pack(self._h, int(field), C.c_void_p(dev_send) if dev_send else None))
+
+    def halo_unpack(self, field: int, dev_recv: Optional[int], neighbours: Sequence[int]):
+        nb = (C.c_int * 8)(*[int(v) for v in neighbours])
+        self._check(self._lib.pdeopt_halo_unpack(self._h, int(field), C.c_void_p(dev_recv) if dev_recv else None, nb))
+
+    def rk4_phase_plan(self):
+        f = (C.c_int * 4)()
+        n = C.c_int()
+        self._check(self._lib.pdeopt_rk4_phase_plan(self._h, f, C.byref(n)))
+        return [f[i] for i in range(n.value)]
+
+    def rk4_phase(self, phase: int, dt: float):
+        self._check(self._lib.pdeopt_rk4_phase(self._h, int(phase), float(dt)))
+
+    def buffer_alloc(self, nbytes: int) -> int:
+        p = C.c_void_p()
+        self._check(self._lib.pdeopt_buffer_alloc(self._h, int(nbytes), C.byref(p)))
+        return p.value
+
+    def buffer_free(self, ptr: int):
+        self._check(self._lib.pdeopt_buffer_free(self._h, C.c_void_p(ptr)))
+
+    def buffer_copy(self, dst, src, nbytes: int, kind: int):
+        as_ptr = lambda v: v.ctypes.data_as(C.c_void_p) if isinstance(v, np.ndarray) else C.c_void_p(int(v))
+        self._check(self._lib.pdeopt_buffer_copy(self._h, as_ptr(dst), as_ptr(src), int(nbytes), int(kind)))
 
     def stage_launches(self) -> int:
         v = C.c_int64()

@@ -1,0 +1,125 @@
+"""Domain decomposition on the GPU: a decomposed periodic field must reproduce the monolithic
+periodic solve BITWISE (explicit FD: same arithmetic per cell)."""
+import numpy as np
+import pytest
+
+import pde_opt_amd as P
+from decomp_util import InProcessComm, gather_all
+from pde_opt_amd import _lib as L
+from pde_opt_amd.decomp import CartesianGrid, DecomposedSolver, HipTileBackend
+from util import MOB, MU, std_domain
+
+pytestmark = pytest.mark.gpu
+
+
+def _monolithic(eq, y0, dt, n, fuse):
+    eng = P.HipEngine()
+    eng.set_fuse_stages(fuse)
+    out = P.diffeqsolve(eq, P.RK4(), 0.0, n * dt, dt, y0, engine=eng).ys[-1]
+    kern = eng.last_kernel
+    eng.close()
+    return out, kern
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("fuse", [0, -1])
+def test_single_rank_loopback_equals_periodic(dtype, fuse):
+    rng = np.random.default_rng(0)
+    dom = std_domain(P, 64, 128)
+    eq = P.CahnHilliard2DPeriodic(dom, 0.002, MU["regsol"], MOB["c1mc"])
+    y0 = np.clip(0.5 + 0.05 * rng.standard_normal((64, 128)), 0.05, 0.95).astype(dtype)
+    want, kern = _monolithic(eq, y0, 2e-7, 6, fuse)
+    assert ("pair" in kern) == (fuse == 0)
+    backend = HipTileBackend(eq, (64, 128), dtype)
+    backend.engine.set_fuse_stages(fuse)
+    s = DecomposedSolver(eq, CartesianGrid(1, 1, 0), dtype=dtype, backend=backend)
+    assert len(backend.phase_plan()) == (2 if fuse == 0 else 4)
+    s.set_global_state(y0)
+    s.advance(2e-7, 6)
+    np.testing.assert_array_equal(s.local_state(), want)
+    assert s.exchanges == 6 * len(backend.phase_plan())
+
+
+@pytest.mark.parametrize("grid", [(2, 2), (2, 1), (1, 4)])
+@pytest.mark.parametrize("fuse", [0, -1])
+def test_multi_tile_on_one_gpu_equals_monolithic(grid, fuse):
+    """px x py ranks played by px*py engines on one GPU; strips cross between engines through the
+    same pack / unpack kernels and neighbour tables the RCCL path uses."""
+    px, py = grid
+    rng = np.random.default_rng(1)
+    nx, ny = 64 * px, 128 * py
+    dom = std_domain(P, nx, ny)
+    eq = P.CahnHilliard2DPeriodic(dom, 0.002, MU["regsol"], MOB["c1mc"])
+    y0 = np.clip(0.5 + 0.05 * rng.standard_normal((nx, ny)), 0.05, 0.95).astype(np.float32)
+    want, _ = _monolithic(eq, y0, 2e-7, 4, fuse)
+    comm = InProcessComm(px * py)
+    solvers = []
+    for r in range(px * py):
+        be = HipTileBackend(eq, (64, 128), np.float32)
+        be.engine.set_fuse_stages(fuse)
+        s = DecomposedSolver(eq, CartesianGrid(px, py, r), comm=comm.view(r), dtype=np.float32, backend=be)
+        s.set_global_state(y0)
+        solvers.append(s)
+    plan = solvers[0].backend.phase_plan()
+    for _ in range(4):
+        for phase, field in enumerate(plan):
+            for s in solvers:
+                s.backend.pack(field, s.send)
+            gather_all(comm)
+            for s in solvers:
+                s.backend.unpack(field, s.recv, s.neighbours)
+                s.backend.phase(phase, 2e-7)
+    got = np.empty_like(want)
+    for s in solvers:
+        si, sj = s.grid.tile_slices(nx, ny)
+        got[si, sj] = s.local_state()
+    np.testing.assert_array_equal(got, want)
+
+
+def test_config5_tile_size_smoke():
+    """one 2048^2 tile of BASELINE config 5 (4096^2 over 2x2) with self-neighbours: finite + mass"""
+    rng = np.random.default_rng(2)
+    dom = std_domain(P, 2048, 2048)
+    eq = P.CahnHilliard2DPeriodic(dom, 0.002, MU["regsol"], MOB["c1mc"])
+    y0 = np.clip(0.5 + 0.01 * rng.standard_normal((2048, 2048)), 0.05, 0.95).astype(np.float32)
+    s = DecomposedSolver(eq, CartesianGrid(1, 1, 0), dtype=np.float32)
+    s.set_global_state(y0)
+    s.advance(2e-7, 10)
+    y1 = s.local_state()
+    assert np.all(np.isfinite(y1))
+    assert abs(y1.astype(np.float64).mean() - y0.astype(np.float64).mean()) < 2e-7
+
+
+def test_rccl_allgather_path_single_rank():
+    """the production exchange path: strips in torch device tensors, all-gathered by RCCL
+    (torch.distributed backend 'nccl'), engine work ordered on torch's current stream"""
+    import os
+    import socket
+
+    import torch
+    import torch.distributed as dist
+
+    from pde_opt_amd.decomp import TorchComm
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        rng = np.random.default_rng(4)
+        dom = std_domain(P, 64, 128)
+        eq = P.CahnHilliard2DPeriodic(dom, 0.002, MU["regsol"], MOB["c1mc"])
+        y0 = np.clip(0.5 + 0.05 * rng.standard_normal((64, 128)), 0.05, 0.95).astype(np.float32)
+        want, _ = _monolithic(eq, y0, 2e-7, 5, 0)
+        stream = torch.cuda.current_stream().cuda_stream
+        sol = DecomposedSolver(eq, CartesianGrid(1, 1, 0), comm=TorchComm(), dtype=np.float32, stream=stream)
+        sol.set_global_state(y0)
+        sol.advance(2e-7, 5)
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(sol.local_state(), want)
+        assert sol.send.is_cuda and sol.recv.numel() == sol.backend.strip_elems
+    finally:
+        dist.destroy_process_group()
