@@ -82,12 +82,17 @@ typedef struct {
   double coef[PDEOPT_CLOSURE_MAX_COEF];
 } pdeopt_closure;
 
+typedef enum {
+  PDEOPT_DERIVS_FD = 0,      /* rhs_fd:      cahn_hilliard.py:89-109, allen_cahn.py:81-84 (stencil kernels) */
+  PDEOPT_DERIVS_FOURIER = 1  /* rhs_fourier: cahn_hilliard.py:82-87,  allen_cahn.py:74-79 (rocFFT)          */
+} pdeopt_derivs;
+
 typedef struct {
   int32_t equation;   /* pdeopt_equation */
   int32_t dtype;      /* pdeopt_dtype: arithmetic type of the whole path */
   int32_t nx, ny;     /* Domain.points (domains.py:24) */
   int32_t batch;      /* independent environments advanced in lock step (new; >= 1) */
-  int32_t reserved;
+  int32_t derivs;     /* pdeopt_derivs: "fd" | "fourier" switch of the equations (cahn_hilliard.py:75-80) */
   double hx, hy;      /* Domain.dx (domains.py:30-33) */
   double kappa;       /* gradient-energy coefficient (CH/AC); diffusion coefficient D (AD) */
   pdeopt_closure mu;  /* mu_h (CH/AC) */

@@ -20,6 +20,7 @@ MAX_COEF = 16
 # enums (mirror include/pdeopt_hip.h)
 OK, EINVAL, EHIP, EFFT, ENONFINITE, ENOMEM, ESTATE = range(7)
 F32, F64 = 0, 1
+DERIVS_FD, DERIVS_FOURIER = 0, 1
 EQ_CAHN_HILLIARD, EQ_ALLEN_CAHN, EQ_ADVECTION_DIFFUSION, EQ_GPE = 0, 1, 2, 3
 INT_EULER, INT_RK4, INT_IMEX, INT_STRANG, INT_TSIT5 = 0, 1, 2, 3, 4
 CL_POLY, CL_LEGENDRE = 0, 1
@@ -65,7 +66,7 @@ class Problem(C.Structure):
         ("nx", C.c_int32),
         ("ny", C.c_int32),
         ("batch", C.c_int32),
-        ("reserved", C.c_int32),
+        ("derivs", C.c_int32),
         ("hx", C.c_double),
         ("hy", C.c_double),
         ("kappa", C.c_double),

@@ -36,7 +36,7 @@ int ensure_buffer(pdeopt_ctx* ctx, void** p, size_t bytes) {
 namespace {
 
 void free_fields(pdeopt_ctx* ctx) {
-  void** bufs[] = {&ctx->Y, &ctx->TA, &ctx->TB, &ctx->ACC, &ctx->SNAP, &ctx->env_params_dev};
+  void** bufs[] = {&ctx->Y, &ctx->TA, &ctx->TB, &ctx->ACC, &ctx->SNAP, &ctx->KS, &ctx->env_params_dev};
   for (void** b : bufs) {
     if (*b) (void)hipFree(*b);
     *b = nullptr;
@@ -222,6 +222,11 @@ int pdeopt_configure(pdeopt_ctx* ctx, const pdeopt_problem* pr) {
     if ((rc = check_closure(ctx, pr->mu, "mu"))) return rc;
     if ((rc = check_closure(ctx, pr->mob, "mob"))) return rc;
   }
+  if (pr->derivs != PDEOPT_DERIVS_FD && pr->derivs != PDEOPT_DERIVS_FOURIER)
+    return fail(ctx, PDEOPT_EINVAL, "Invalid derivative type: %d", pr->derivs);
+  if (pr->derivs == PDEOPT_DERIVS_FOURIER && pr->equation != PDEOPT_EQ_CAHN_HILLIARD &&
+      pr->equation != PDEOPT_EQ_ALLEN_CAHN)
+    return fail(ctx, PDEOPT_EINVAL, "the pseudo-spectral RHS exists for Cahn-Hilliard / Allen-Cahn only");
   ctx->prob = *pr;
   if (ctx->prob.mu.n < 1) ctx->prob.mu.n = 1;
   if (ctx->prob.mob.n < 1) ctx->prob.mob.n = 1;

@@ -74,6 +74,7 @@ struct pdeopt_ctx {
   void* TB = nullptr;
   void* ACC = nullptr;
   void* SNAP = nullptr;
+  void* KS = nullptr;  // slope scratch of the spectral-RHS stage path
   void* K[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // Tsit5 slopes
   bool tsit5_pending = false;
   bool tsit5_fsal_valid = false;
@@ -143,6 +144,7 @@ void* field_ptr(pdeopt_ctx* ctx, int field);
 int reduce_state(pdeopt_ctx* ctx, int op, double* out);
 // spectral.hip
 int advance_imex(pdeopt_ctx* ctx, double t0, double dt, int64_t n);
+int rhs_fourier(pdeopt_ctx* ctx, const void* in, void* out);
 int advance_strang(pdeopt_ctx* ctx, double t0, double dt, int64_t n);
 void spectral_destroy(pdeopt_ctx* ctx);
 

@@ -15,6 +15,7 @@
 #include <complex>
 #include <mutex>
 
+#include "closures.hpp"
 #include "common.hpp"
 
 namespace pdeopt {
@@ -25,7 +26,9 @@ struct Spectral {
   rocfft_execution_info info = nullptr;
   void* work = nullptr;
   size_t work_bytes = 0;
-  void* cbuf = nullptr;    // complex work field (IMEX)
+  void* cbuf = nullptr;    // complex work field (IMEX, rhs_fourier)
+  void* cbuf2 = nullptr;   // rhs_fourier work fields
+  void* cbuf3 = nullptr;
   void* mult = nullptr;    // complex spectral multiplier, shared [nx][ny]
   void* dens = nullptr;    // real |psi0|^2 (Strang)
   double* partial = nullptr;  // [batch][kNormBlocks]
@@ -332,7 +335,146 @@ int strang_t(pdeopt_ctx* ctx, double dt, int64_t n) {
   return PDEOPT_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// pseudo-spectral right-hand sides (cahn_hilliard.py:82-87, allen_cahn.py:74-79)
+//   t_hat = F[mu_h(u)] - kappa K2 F[u],   K2 = (2 pi i kx)^2 + (2 pi i ky)^2
+//   CH:  rhs = Re F^-1[ ikx F[D(u) F^-1[ikx t_hat]] + iky F[D(u) F^-1[iky t_hat]] ]     (7 FFTs)
+//   AC:  rhs = -R(u) Re F^-1[t_hat]                                                     (3 FFTs)
+// wave numbers are formed in-kernel from the index (fftfreq(n, h), domains.py:44-47).
+// ---------------------------------------------------------------------------------------------
+
+template <typename T>
+__device__ __forceinline__ T wavenumber_2pi(int idx, int n, T inv_len) {
+  // 2 pi * fftfreq(n, h)[idx], inv_len = 1 / (n h)
+  const int k = (idx < (n + 1) / 2) ? idx : idx - n;
+  return T(6.283185307179586476925286766559) * T(k) * inv_len;
+}
+
+// a = (u, 0), b = (mu_h(u), 0)
+template <typename T>
+__global__ void fourier_embed_kernel(const T* __restrict__ u, C2<T>* __restrict__ a, C2<T>* __restrict__ b,
+                                     const EnvParams<T>* __restrict__ ep, ClosureSpec mu, int64_t cells) {
+  const int env = blockIdx.y;
+  const EnvParams<T>& p = ep[env];
+  const int64_t o = (int64_t)env * cells;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cells; i += (int64_t)gridDim.x * blockDim.x) {
+    const T c = u[o + i];
+    a[o + i] = C2<T>{c, T(0)};
+    b[o + i] = C2<T>{closure_generic<T>(mu, p.mu, c), T(0)};
+  }
+}
+
+// t_hat = b - kappa K2 a ;  CH: a <- ikx t_hat, b <- iky t_hat ;  AC: b <- t_hat
+template <typename T, bool CH>
+__global__ void fourier_that_kernel(C2<T>* __restrict__ a, C2<T>* __restrict__ b,
+                                    const EnvParams<T>* __restrict__ ep, int nx, int ny, T inv_lx, T inv_ly) {
+  const int env = blockIdx.y;
+  const T kap = ep[env].kappa;
+  const int64_t cells = (int64_t)nx * ny, o = (int64_t)env * cells;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cells; i += (int64_t)gridDim.x * blockDim.x) {
+    const int ix = (int)(i / ny), iy = (int)(i % ny);
+    const T kx = wavenumber_2pi<T>(ix, nx, inv_lx), ky = wavenumber_2pi<T>(iy, ny, inv_ly);
+    const T k2 = -(kx * kx + ky * ky);  // (i kx)^2 + (i ky)^2
+    const C2<T> ua = a[o + i], mb = b[o + i];
+    const C2<T> t{mb.re - kap * k2 * ua.re, mb.im - kap * k2 * ua.im};
+    if (CH) {
+      a[o + i] = C2<T>{-kx * t.im, kx * t.re};  // i kx t
+      b[o + i] = C2<T>{-ky * t.im, ky * t.re};
+    } else {
+      b[o + i] = t;
+    }
+  }
+}
+
+// a *= D(u)/N, b *= D(u)/N   (the 1/N of the preceding inverse transform folded in)
+template <typename T>
+__global__ void fourier_mob_kernel(const T* __restrict__ u, C2<T>* __restrict__ a, C2<T>* __restrict__ b,
+                                   const EnvParams<T>* __restrict__ ep, ClosureSpec mob, int64_t cells, T inv_n) {
+  const int env = blockIdx.y;
+  const EnvParams<T>& p = ep[env];
+  const int64_t o = (int64_t)env * cells;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cells; i += (int64_t)gridDim.x * blockDim.x) {
+    const T d = closure_generic<T>(mob, p.mob, u[o + i]) * inv_n;
+    C2<T> va = a[o + i], vb = b[o + i];
+    a[o + i] = C2<T>{va.re * d, va.im * d};
+    b[o + i] = C2<T>{vb.re * d, vb.im * d};
+  }
+}
+
+// a <- ikx a + iky b
+template <typename T>
+__global__ void fourier_div_kernel(C2<T>* __restrict__ a, const C2<T>* __restrict__ b, int nx, int ny,
+                                   T inv_lx, T inv_ly) {
+  const int env = blockIdx.y;
+  const int64_t cells = (int64_t)nx * ny, o = (int64_t)env * cells;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cells; i += (int64_t)gridDim.x * blockDim.x) {
+    const int ix = (int)(i / ny), iy = (int)(i % ny);
+    const T kx = wavenumber_2pi<T>(ix, nx, inv_lx), ky = wavenumber_2pi<T>(iy, ny, inv_ly);
+    const C2<T> va = a[o + i], vb = b[o + i];
+    a[o + i] = C2<T>{-kx * va.im - ky * vb.im, kx * va.re + ky * vb.re};
+  }
+}
+
+// CH: out = Re(a)/N ;  AC: out = -R(u) Re(b)/N
+template <typename T, bool CH>
+__global__ void fourier_out_kernel(const T* __restrict__ u, const C2<T>* __restrict__ c, T* __restrict__ out,
+                                   const EnvParams<T>* __restrict__ ep, ClosureSpec mob, int64_t cells, T inv_n) {
+  const int env = blockIdx.y;
+  const EnvParams<T>& p = ep[env];
+  const int64_t o = (int64_t)env * cells;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cells; i += (int64_t)gridDim.x * blockDim.x) {
+    const T r = c[o + i].re * inv_n;
+    out[o + i] = CH ? r : -closure_generic<T>(mob, p.mob, u[o + i]) * r;
+  }
+}
+
+template <typename T>
+int rhs_fourier_t(pdeopt_ctx* ctx, const void* in, void* out) {
+  Spectral& sp = *ctx->spectral;
+  const pdeopt_problem& p = ctx->prob;
+  const int64_t cells = (int64_t)p.nx * p.ny, total = cells * p.batch;
+  int rc;
+  if ((rc = ensure_buffer(ctx, &sp.cbuf2, (size_t)total * 2 * sizeof(T)))) return rc;
+  if ((rc = ensure_buffer(ctx, &sp.cbuf3, (size_t)total * 2 * sizeof(T)))) return rc;
+  C2<T>* a = (C2<T>*)sp.cbuf2;
+  C2<T>* b = (C2<T>*)sp.cbuf3;
+  const T* u = (const T*)in;
+  const auto* ep = (const EnvParams<T>*)ctx->env_params_dev;
+  const ClosureSpec mu{p.mu.kind, p.mu.flags, p.mu.n}, mob{p.mob.kind, p.mob.flags, p.mob.n};
+  const dim3 grid(grid_for(cells), p.batch), blk(256);
+  const T inv_lx = T(1.0 / (p.nx * p.hx)), inv_ly = T(1.0 / (p.ny * p.hy)), inv_n = T(1.0 / (double)cells);
+  const bool ch = p.equation == PDEOPT_EQ_CAHN_HILLIARD;
+  hipLaunchKernelGGL(fourier_embed_kernel<T>, grid, blk, 0, ctx->stream, u, a, b, ep, mu, cells);
+  if ((rc = fft_exec(ctx, true, a))) return rc;
+  if ((rc = fft_exec(ctx, true, b))) return rc;
+  if (ch) {
+    hipLaunchKernelGGL((fourier_that_kernel<T, true>), grid, blk, 0, ctx->stream, a, b, ep, p.nx, p.ny, inv_lx, inv_ly);
+    if ((rc = fft_exec(ctx, false, a))) return rc;
+    if ((rc = fft_exec(ctx, false, b))) return rc;
+    hipLaunchKernelGGL(fourier_mob_kernel<T>, grid, blk, 0, ctx->stream, u, a, b, ep, mob, cells, inv_n);
+    if ((rc = fft_exec(ctx, true, a))) return rc;
+    if ((rc = fft_exec(ctx, true, b))) return rc;
+    hipLaunchKernelGGL(fourier_div_kernel<T>, grid, blk, 0, ctx->stream, a, (const C2<T>*)b, p.nx, p.ny, inv_lx, inv_ly);
+    if ((rc = fft_exec(ctx, false, a))) return rc;
+    hipLaunchKernelGGL((fourier_out_kernel<T, true>), grid, blk, 0, ctx->stream, u, (const C2<T>*)a, (T*)out, ep, mob, cells, inv_n);
+  } else {
+    hipLaunchKernelGGL((fourier_that_kernel<T, false>), grid, blk, 0, ctx->stream, a, b, ep, p.nx, p.ny, inv_lx, inv_ly);
+    if ((rc = fft_exec(ctx, false, b))) return rc;
+    hipLaunchKernelGGL((fourier_out_kernel<T, false>), grid, blk, 0, ctx->stream, u, (const C2<T>*)b, (T*)out, ep, mob, cells, inv_n);
+  }
+  PDEOPT_HIP_CHECK(ctx, hipGetLastError());
+  ctx->last_kernel = ch ? "rhs_fourier<CH>(rocfft x7)" : "rhs_fourier<AC>(rocfft x3)";
+  return PDEOPT_OK;
+}
+
 }  // namespace
+
+int rhs_fourier(pdeopt_ctx* ctx, const void* in, void* out) {
+  if (ctx->halo) return fail(ctx, PDEOPT_EINVAL, "the pseudo-spectral RHS needs the periodic layout");
+  int rc = ensure_plans(ctx);
+  if (rc) return rc;
+  return ctx->prob.dtype == PDEOPT_F32 ? rhs_fourier_t<float>(ctx, in, out) : rhs_fourier_t<double>(ctx, in, out);
+}
 
 int advance_imex(pdeopt_ctx* ctx, double, double dt, int64_t n) {
   if (!ctx->aux[PDEOPT_AUX_IMEX_SYMBOL].dev)
@@ -356,7 +498,7 @@ void spectral_destroy(pdeopt_ctx* ctx) {
   if (sp->fwd) rocfft_plan_destroy(sp->fwd);
   if (sp->inv) rocfft_plan_destroy(sp->inv);
   if (sp->info) rocfft_execution_info_destroy(sp->info);
-  void* bufs[] = {sp->work, sp->cbuf, sp->mult, sp->dens, sp->partial, sp->scale};
+  void* bufs[] = {sp->work, sp->cbuf, sp->cbuf2, sp->cbuf3, sp->mult, sp->dens, sp->partial, sp->scale};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   delete sp;

@@ -80,12 +80,36 @@ int launch_generic(pdeopt_ctx* ctx, const StageArgs<T>& s) {
   return PDEOPT_OK;
 }
 
+// pointwise stage update for RHS evaluations that are not fused into a stencil kernel
+template <typename T>
+__global__ void stage_update_kernel(const StageArgs<T> a, const T* __restrict__ k, int64_t total) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t st = (int64_t)gridDim.x * blockDim.x;
+  for (; i < total; i += st) stage_update<T>(a, i, k[i]);
+}
+
+template <typename T>
+int launch_stage_fourier(pdeopt_ctx* ctx, const StageArgs<T>& s, const void* in, void* out) {
+  if (ctx->win_lo != 0 || ctx->win_n != ctx->prob.batch)
+    return fail(ctx, PDEOPT_EINVAL, "spectral RHS works on the whole batch");
+  int rc;
+  if (s.out_mode == OUT_K && s.acc_mode == ACC_NONE) return rhs_fourier(ctx, in, out);
+  if ((rc = ensure_buffer(ctx, &ctx->KS, ctx->total_bytes))) return rc;
+  if ((rc = rhs_fourier(ctx, in, ctx->KS))) return rc;
+  const int64_t total = (int64_t)(ctx->env_elems * ctx->prob.batch);
+  const int blocks = (int)std::min<int64_t>((total + 255) / 256, 4096);
+  hipLaunchKernelGGL(stage_update_kernel<T>, dim3(blocks), dim3(256), 0, ctx->stream, s, (const T*)ctx->KS, total);
+  PDEOPT_HIP_CHECK(ctx, hipGetLastError());
+  return PDEOPT_OK;
+}
+
 // One fused stage: k = rhs(in); out/acc updated per (out_mode, acc_mode).
 template <typename T>
 int launch_stage_t(pdeopt_ctx* ctx, const void* in, const void* y, void* out, void* acc, double a,
                    double b, int out_mode, int acc_mode) {
   StageArgs<T> s = make_args<T>(ctx, in, y, out, acc, a, b, out_mode, acc_mode);
   ctx->n_stage_launches++;
+  if (ctx->prob.derivs == PDEOPT_DERIVS_FOURIER) return launch_stage_fourier<T>(ctx, s, in, out);
   if (ctx->opt_kernel_path != 1 && tiled_supported<T>(ctx)) {
     return launch_tiled<T>(ctx, s);
   }
@@ -138,7 +162,9 @@ int advance_explicit(pdeopt_ctx* ctx, int integrator, double, double dt, int64_t
   // once per stage.
   const int batch = ctx->prob.batch;
   int group = batch;
-  if (ctx->opt_group_envs > 0) {
+  if (ctx->prob.derivs == PDEOPT_DERIVS_FOURIER) {
+    group = batch;  // batched rocFFT plans cover the whole batch
+  } else if (ctx->opt_group_envs > 0) {
     group = (int)std::min<int64_t>(ctx->opt_group_envs, batch);
   } else if (ctx->opt_group_envs == 0) {
     // auto: largest balanced group whose 4 fields fit the Infinity Cache (measured on MI355X:
@@ -152,6 +178,7 @@ int advance_explicit(pdeopt_ctx* ctx, int integrator, double, double dt, int64_t
     }
   }
   const bool fused = integrator == PDEOPT_INT_RK4 && ctx->opt_kernel_path != 1 &&
+                     ctx->prob.derivs == PDEOPT_DERIVS_FD &&
                      (ctx->prob.dtype == PDEOPT_F32 ? fused_supported<float>(ctx) : fused_supported<double>(ctx));
   void* y_final = ctx->Y;
   void* ta_final = ctx->TA;
@@ -196,7 +223,7 @@ int advance_explicit(pdeopt_ctx* ctx, int integrator, double, double dt, int64_t
 // One phase of an RK4 substep for callers that interleave their own work between phases (the
 // domain-decomposed driver exchanges halos of `fields[phase]` before `rk4_phase(phase)`).
 int rk4_phase_plan(pdeopt_ctx* ctx, int* fields, int* nphases) {
-  const bool fused = ctx->opt_kernel_path != 1 &&
+  const bool fused = ctx->opt_kernel_path != 1 && ctx->prob.derivs == PDEOPT_DERIVS_FD &&
                      (ctx->prob.dtype == PDEOPT_F32 ? fused_supported<float>(ctx) : fused_supported<double>(ctx));
   if (fused) {
     *nphases = 2;

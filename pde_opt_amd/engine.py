@@ -106,8 +106,10 @@ class HipEngine:
         mu: Optional[ClosureDesc] = None,
         mob: Optional[ClosureDesc] = None,
         gpe_k: float = 0.0,
+        derivs: int = 0,
     ):
         p = L.Problem()
+        p.derivs = int(derivs)
         p.equation, p.dtype = int(equation), L.dtype_code(dtype)
         p.nx, p.ny, p.batch = int(nx), int(ny), int(batch)
         p.hx, p.hy, p.kappa, p.gpe_k = float(hx), float(hy), float(kappa), float(gpe_k)

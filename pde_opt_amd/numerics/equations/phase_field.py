@@ -6,7 +6,8 @@ allen_cahn.py:27-84): fields ``domain, kappa, mu, D|R, derivs``; published attri
 ``rhs(state, t)``.  ``mu`` / ``D`` / ``R`` may be any callable the closure tracer understands
 (numerics/closures.py), a Legendre closure object, a number, or a ``ClosureDesc``.
 
-``rhs`` runs the fused stencil kernel (csrc/stencil_*.hpp), not numpy.
+``rhs`` runs on the GPU: the fused stencil kernels (csrc/stencil_*.hpp) for ``derivs="fd"``, batched
+rocFFT transforms + pointwise kernels (csrc/spectral.hip) for ``derivs="fourier"``.
 """
 
 from __future__ import annotations
@@ -74,16 +75,14 @@ class CahnHilliard2DPeriodic(BaseEquation):
         nx, ny = self.domain.points
         hx, hy = self.domain.dx
         return dict(equation=L.EQ_CAHN_HILLIARD, nx=nx, ny=ny, hx=hx, hy=hy, kappa=float(self.kappa),
-                    mu=self._mu_desc, mob=self._mob_desc)
+                    mu=self._mu_desc, mob=self._mob_desc,
+                    derivs=L.DERIVS_FOURIER if self.derivs == "fourier" else L.DERIVS_FD)
 
     def rhs_fd(self, state, t):
         return self._run_rhs(state, t)
 
     def rhs_fourier(self, state, t):
-        raise NotImplementedError(
-            "the pseudo-spectral RHS (7 FFTs, cahn_hilliard.py:82-87) is not on the HIP path yet "
-            "(SURVEY section 8 row f4); use derivs='fd'"
-        )
+        return self._run_rhs(state, t)  # 7 batched rocFFT transforms (cahn_hilliard.py:82-87)
 
 
 @dataclasses.dataclass
@@ -111,13 +110,11 @@ class AllenCahn2DPeriodic(BaseEquation):
         nx, ny = self.domain.points
         hx, hy = self.domain.dx
         return dict(equation=L.EQ_ALLEN_CAHN, nx=nx, ny=ny, hx=hx, hy=hy, kappa=float(self.kappa),
-                    mu=self._mu_desc, mob=self._mob_desc)
+                    mu=self._mu_desc, mob=self._mob_desc,
+                    derivs=L.DERIVS_FOURIER if self.derivs == "fourier" else L.DERIVS_FD)
 
     def rhs_fd(self, state, t):
         return self._run_rhs(state, t)
 
     def rhs_fourier(self, state, t):
-        raise NotImplementedError(
-            "the pseudo-spectral RHS (allen_cahn.py:74-79) is not on the HIP path yet "
-            "(SURVEY section 8 row f4); use derivs='fd'"
-        )
+        return self._run_rhs(state, t)  # 3 batched rocFFT transforms (allen_cahn.py:74-79)

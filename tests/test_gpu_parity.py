@@ -420,3 +420,64 @@ def test_error_codes():
     with pytest.raises(ValueError):
         eng.set_state(np.zeros((1, 16, 16), np.float32))
     eng.close()
+
+
+# ------------------------------------------------------------------ pseudo-spectral RHS
+def test_rhs_fourier_against_reference_goldens(golden, engine):
+    z = golden("rhs_cases.npz")
+    n = 0
+    for kind, cls in (("ch_fourier", P.CahnHilliard2DPeriodic), ("ac_fourier", P.AllenCahn2DPeriodic)):
+        for key in sorted(k[:-4] for k in z.files if k.startswith(kind + "/") and k.endswith("/rhs")):
+            _, mu, mob, tag = key.split("/")
+            nx, ny = (int(v) for v in tag.split("_")[0].split("x"))
+            eq = cls(std_domain(P, nx, ny), 0.002, MU[mu], MOB[mob], derivs="fourier")
+            got = eq.rhs(z[key + "/u"], 0.0)
+            assert "rhs_fourier" in engine.last_kernel
+            # 7 (CH) / 3 (AC) FFT round trips with the (2 pi k)^4 ~ 1e10 amplification of the biharmonic
+            assert rel_l2(got, z[key + "/rhs"]) < 1e-9, (key, rel_l2(got, z[key + "/rhs"]))
+            n += 1
+    assert n >= 4
+
+
+def test_rhs_fourier_spectral_accuracy_and_batch():
+    """spectral RHS of the manufactured solution is exact to rounding (reference: 6.8e-10 at N=512)"""
+    import sympy as sp
+    from sympy.utilities.lambdify import lambdify
+
+    x, y, t = sp.symbols("x y t", real=True)
+    u = sp.sin(2 * x) * sp.cos(3 * y)
+    kappa = 1e-2
+    mu = u**3 - u - kappa * (sp.diff(u, x, 2) + sp.diff(u, y, 2))
+    D = 1 + u**2
+    ch = lambdify((x, y), sp.diff(D * sp.diff(mu, x), x) + sp.diff(D * sp.diff(mu, y), y), "numpy")
+    ac = lambdify((x, y), -D * mu, "numpy")
+    Lb = 2 * np.pi
+    dom = P.Domain((64, 64), ((-Lb / 2, Lb / 2), (-Lb / 2, Lb / 2)), "dimensionless")
+    X, Y = dom.mesh()
+    ue = lambdify((x, y), u, "numpy")(X, Y)
+    for cls, exact in ((P.CahnHilliard2DPeriodic, ch(X, Y)), (P.AllenCahn2DPeriodic, ac(X, Y))):
+        eq = cls(dom, kappa, lambda c: c**3 - c, lambda c: 1 + c**2, derivs="fourier")
+        got = eq.rhs(np.stack([ue, 0.5 * ue]), 0)  # batch of two
+        assert rel_l2(got[0], exact) < 1e-11
+        want1 = (O.ch_rhs_fourier if cls is P.CahnHilliard2DPeriodic else O.ac_rhs_fourier)(
+            0.5 * ue, dom.dx[0], dom.dx[1], kappa, lambda c: c**3 - c, lambda c: 1 + c**2)
+        assert rel_l2(got[1], want1) < 1e-11
+    # fp32 works too (tolerance of an fp32 FFT chain)
+    eq = P.AllenCahn2DPeriodic(dom, kappa, lambda c: c**3 - c, lambda c: 1 + c**2, derivs="fourier")
+    assert rel_l2(eq.rhs(ue.astype(np.float32), 0), ac(X, Y)) < 2e-5
+
+
+def test_explicit_step_with_fourier_rhs():
+    rng = np.random.default_rng(12)
+    dom = std_domain(P, 32, 48)
+    eq = P.AllenCahn2DPeriodic(dom, 0.002, MU["cubic"], MOB["one_plus_sq"], derivs="fourier")
+    y0 = 0.1 * rng.standard_normal((32, 48))
+    hx, hy = dom.dx
+    f = lambda t, u: O.ac_rhs_fourier(u, hx, hy, 0.002, MU["cubic"], MOB["one_plus_sq"])
+    got = P.diffeqsolve(eq, P.RK4(), 0.0, 4e-4, 1e-4, y0).ys[-1]
+    ref = y0
+    for _ in range(4):
+        ref = O.rk4_step(f, 0.0, ref, 1e-4)
+    np.testing.assert_allclose(got, ref, rtol=0, atol=1e-13)
+    with pytest.raises(ValueError, match="Invalid derivative type"):
+        P.AllenCahn2DPeriodic(dom, 0.002, MU["cubic"], MOB["one"], derivs="spectral")
