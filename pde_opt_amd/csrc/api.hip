@@ -209,7 +209,15 @@ int pdeopt_configure(pdeopt_ctx* ctx, const pdeopt_problem* pr) {
   if (!ctx || !pr) return PDEOPT_EINVAL;
   PDEOPT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   PDEOPT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-  free_fields(ctx);
+  // Re-configuring with the same shape (the per-step "rebuild the equation" of PDEEnv.step,
+  // pde_env.py:286) keeps every device buffer, rocFFT plan and the resident state: only the
+  // parameters change.
+  const bool same_shape = ctx->configured && pr->equation == ctx->prob.equation &&
+                          pr->dtype == ctx->prob.dtype && pr->nx == ctx->prob.nx &&
+                          pr->ny == ctx->prob.ny && pr->batch == ctx->prob.batch &&
+                          (int)ctx->opt_halo == ctx->halo;
+  if (!same_shape) free_fields(ctx);
+  ctx->configured = false;
   if (pr->dtype != PDEOPT_F32 && pr->dtype != PDEOPT_F64)
     return fail(ctx, PDEOPT_EINVAL, "unknown dtype %d", pr->dtype);
   if (pr->equation < PDEOPT_EQ_CAHN_HILLIARD || pr->equation > PDEOPT_EQ_GPE)
@@ -238,8 +246,12 @@ int pdeopt_configure(pdeopt_ctx* ctx, const pdeopt_problem* pr) {
   ctx->env_elems = (size_t)(pr->nx + 2 * ctx->halo) * (pr->ny + 2 * ctx->halo) * ctx->comps;
   ctx->total_bytes = ctx->env_elems * pr->batch * ctx->esize;
   int rc;
-  if ((rc = ensure_buffer(ctx, &ctx->Y, ctx->total_bytes))) return rc;
-  PDEOPT_HIP_CHECK(ctx, hipMemsetAsync(ctx->Y, 0, ctx->total_bytes, ctx->stream));
+  if (!same_shape) {
+    if ((rc = ensure_buffer(ctx, &ctx->Y, ctx->total_bytes))) return rc;
+    PDEOPT_HIP_CHECK(ctx, hipMemsetAsync(ctx->Y, 0, ctx->total_bytes, ctx->stream));
+  }
+  ctx->tsit5_pending = false;
+  ctx->tsit5_fsal_valid = false;
   if (pr->dtype == PDEOPT_F32)
     fill_env_params<float>(ctx);
   else
@@ -282,6 +294,7 @@ int pdeopt_set_aux(pdeopt_ctx* ctx, int which, const void* host, int per_env) {
   if (rc) return rc;
   a.bytes = bytes;
   a.per_env = per_env ? 1 : 0;
+  spectral_invalidate(ctx);  // multipliers derived from the old aux field are stale
   PDEOPT_HIP_CHECK(ctx, hipMemcpyAsync(a.dev, host, bytes, hipMemcpyHostToDevice, ctx->stream));
   PDEOPT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   return PDEOPT_OK;

@@ -147,5 +147,6 @@ int advance_imex(pdeopt_ctx* ctx, double t0, double dt, int64_t n);
 int rhs_fourier(pdeopt_ctx* ctx, const void* in, void* out);
 int advance_strang(pdeopt_ctx* ctx, double t0, double dt, int64_t n);
 void spectral_destroy(pdeopt_ctx* ctx);
+void spectral_invalidate(pdeopt_ctx* ctx);
 
 }  // namespace pdeopt

@@ -492,6 +492,10 @@ int advance_strang(pdeopt_ctx* ctx, double, double dt, int64_t n) {
   return ctx->prob.dtype == PDEOPT_F32 ? strang_t<float>(ctx, dt, n) : strang_t<double>(ctx, dt, n);
 }
 
+void spectral_invalidate(pdeopt_ctx* ctx) {
+  if (ctx->spectral) ctx->spectral->mult_kind = -1;
+}
+
 void spectral_destroy(pdeopt_ctx* ctx) {
   Spectral* sp = ctx->spectral;
   if (!sp) return;

@@ -176,8 +176,53 @@ def _match(expr, c):
     )
 
 
+_trace_cache: dict = {}
+
+
+def _cache_key(fn):
+    """Hashable identity of a plain Python function: code object + captured scalars.  PDEEnv.step
+    rebuilds the equation every step (pde_env.py:286) with the same callables (or the same lambda
+    re-created around a new number); tracing through sympy costs ~1 ms, this lookup ~1 us."""
+    code = getattr(fn, "__code__", None)
+    if code is None:
+        return None
+    simple = (int, float, complex, str, bool, type(None))
+    cells = []
+    for c in getattr(fn, "__closure__", None) or ():
+        try:
+            v = c.cell_contents
+        except ValueError:
+            return None
+        if not isinstance(v, simple):
+            return None
+        cells.append(v)
+    defaults = getattr(fn, "__defaults__", None) or ()
+    if not all(isinstance(v, simple) for v in defaults):
+        return None
+    if code.co_names and any(n not in ("np", "numpy", "jnp", "log", "exp", "ones_like", "zeros_like", "full_like",
+                                       "sqrt", "square", "power") for n in code.co_names):
+        return None  # refers to globals whose values may change between calls
+    return (code, tuple(cells), tuple(defaults))
+
+
 def as_closure(fn) -> ClosureDesc:
     """Descriptor for a user closure: ``ClosureDesc``, number, Legendre object or callable."""
+    if isinstance(fn, ClosureDesc):
+        return fn
+    key = _cache_key(fn) if callable(fn) else None
+    if key is not None:
+        hit = _trace_cache.get(key)
+        if hit is not None:
+            return hit
+        desc = _as_closure_uncached(fn)
+        if len(_trace_cache) > 512:
+            _trace_cache.clear()
+        _trace_cache[key] = desc
+        return desc
+    return _as_closure_uncached(fn)
+
+
+def _as_closure_uncached(fn) -> ClosureDesc:
     if isinstance(fn, ClosureDesc):
         return fn
     if hasattr(fn, "closure_desc"):

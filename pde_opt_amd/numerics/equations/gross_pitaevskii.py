@@ -21,6 +21,7 @@ import numpy as np
 from ... import _lib as L
 from ..domains import Domain
 from .base_eq import TimeSplittingEquation
+from .phase_field import spectral_table
 
 # constants published by the reference module (gross_pitaevskii.py:12-15)
 hbar = 1.05e-34
@@ -47,17 +48,18 @@ class GPE2DTSControl(TimeSplittingEquation):
         if len(self.domain.points) != 2:
             raise ValueError("GPE2DTSControl needs a 2-D domain")
         self.dx = self.domain.dx[0]
-        self.kx, self.ky = self.domain.fft_mesh()
-        self.two_pi_i_kx = 2j * np.pi * self.kx
-        self.two_pi_i_ky = 2j * np.pi * self.ky
-        self.two_pi_i_kx_2 = self.two_pi_i_kx**2
-        self.two_pi_i_ky_2 = self.two_pi_i_ky**2
-        self.two_pi_i_k_2 = self.two_pi_i_kx_2 + self.two_pi_i_ky_2
+        tab = spectral_table(self.domain)  # shared per grid: PDEEnv.step rebuilds the equation every step
+        for name, arr in tab.items():
+            setattr(self, name, arr)
+        if "mesh" not in tab:
+            tab["mesh"] = self.domain.mesh()
+            tab["A_kinetic"] = 0.5j * tab["two_pi_i_k_2"]
+            tab["A_zero"] = tab["A_kinetic"] * 0.0
         self.fft = np.fft.fftn
         self.ifft = np.fft.ifftn
-        self.xmesh, self.ymesh = self.domain.mesh()
+        self.xmesh, self.ymesh = tab["mesh"]
         self.control = lambda t: self.lights(t, self.xmesh, self.ymesh)
-        self.A_term = 0.5j * self.two_pi_i_k_2 * (1.0 if self.kinetic else 0.0)
+        self.A_term = tab["A_kinetic"] if self.kinetic else tab["A_zero"]
 
     def potential(self, t: float) -> np.ndarray:
         """V with b = -i (V + k |psi|^2): harmonic trap + control field."""

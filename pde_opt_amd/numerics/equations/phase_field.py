@@ -23,17 +23,49 @@ from ..domains import Domain
 from .base_eq import BaseEquation
 
 
-def _spectral_attributes(eq):
-    """Wave-number meshes shared by CH and AC (cahn_hilliard.py:65-73, allen_cahn.py:58-65)."""
-    eq.kx, eq.ky = eq.domain.fft_mesh()
-    eq.two_pi_i_kx = 2j * np.pi * eq.kx
-    eq.two_pi_i_ky = 2j * np.pi * eq.ky
-    eq.two_pi_i_kx_2 = eq.two_pi_i_kx**2
-    eq.two_pi_i_ky_2 = eq.two_pi_i_ky**2
-    eq.two_pi_i_k_2 = eq.two_pi_i_kx_2 + eq.two_pi_i_ky_2
+_SPECTRAL_NAMES = ("kx", "ky", "two_pi_i_kx", "two_pi_i_ky", "two_pi_i_kx_2", "two_pi_i_ky_2",
+                   "two_pi_i_k_2", "two_pi_i_k_4")
+_spectral_cache: dict = {}
+
+
+def spectral_table(domain) -> dict:
+    """Wave-number meshes shared by CH, AC and the GPE (cahn_hilliard.py:65-73, allen_cahn.py:58-65),
+    built once per (points, box) and shared by every equation object on that grid: PDEEnv.step
+    constructs a new equation per step (pde_env.py:286) and must not pay for 1024^2 meshes each time."""
+    key = (tuple(domain.points), tuple(tuple(b) for b in domain.box))
+    tab = _spectral_cache.get(key)
+    if tab is None:
+        kx, ky = domain.fft_mesh()
+        ikx, iky = 2j * np.pi * kx, 2j * np.pi * ky
+        k2 = ikx**2 + iky**2
+        tab = dict(kx=kx, ky=ky, two_pi_i_kx=ikx, two_pi_i_ky=iky, two_pi_i_kx_2=ikx**2,
+                   two_pi_i_ky_2=iky**2, two_pi_i_k_2=k2, two_pi_i_k_4=k2**2)
+        if len(_spectral_cache) > 8:
+            _spectral_cache.clear()
+        _spectral_cache[key] = tab
+    return tab
+
+
+class _Spectral:
+    """Published spectral attribute, computed on first access (class access keeps ``hasattr`` true
+    for ``check_equation_solver_compatibility``)."""
+
+    def __init__(self, name):
+        self.name = name
+
+    def __get__(self, obj, cls=None):
+        if obj is None:
+            return self
+        return spectral_table(obj.domain)[self.name]
+
+
+def _install_spectral(cls):
+    for name in _SPECTRAL_NAMES:
+        setattr(cls, name, _Spectral(name))
     # published for signature compatibility with the solvers; the HIP integrators use rocFFT
-    eq.fft = np.fft.fftn
-    eq.ifft = np.fft.ifftn
+    cls.fft = staticmethod(np.fft.fftn)
+    cls.ifft = staticmethod(np.fft.ifftn)
+    return cls
 
 
 def _select_rhs(eq):
@@ -45,6 +77,7 @@ def _select_rhs(eq):
         raise ValueError(f"Invalid derivative type: {eq.derivs}")
 
 
+@_install_spectral
 @dataclasses.dataclass
 class CahnHilliard2DPeriodic(BaseEquation):
     """du/dt = div( D(u) grad( mu_h(u) - kappa lap u ) )."""
@@ -54,9 +87,11 @@ class CahnHilliard2DPeriodic(BaseEquation):
     mu: Any
     D: Any
     derivs: str = "fd"
-    fft = None
-    ifft = None
-    fourier_symbol = None
+
+    @property
+    def fourier_symbol(self):
+        """kappa (2 pi i k)^4, the stiff linear symbol of the IMEX solver (cahn_hilliard.py:74)"""
+        return self.kappa * self.two_pi_i_k_4
 
     def rhs(self, state, t):  # replaced in __post_init__, as upstream
         raise NotImplementedError("rhs method not implemented")
@@ -64,9 +99,6 @@ class CahnHilliard2DPeriodic(BaseEquation):
     def __post_init__(self):
         if len(self.domain.points) != 2:
             raise ValueError("CahnHilliard2DPeriodic needs a 2-D domain")
-        _spectral_attributes(self)
-        self.two_pi_i_k_4 = self.two_pi_i_k_2**2
-        self.fourier_symbol = self.kappa * self.two_pi_i_k_4
         self._mu_desc = as_closure(self.mu)
         self._mob_desc = as_closure(self.D)
         _select_rhs(self)
@@ -85,6 +117,7 @@ class CahnHilliard2DPeriodic(BaseEquation):
         return self._run_rhs(state, t)  # 7 batched rocFFT transforms (cahn_hilliard.py:82-87)
 
 
+@_install_spectral
 @dataclasses.dataclass
 class AllenCahn2DPeriodic(BaseEquation):
     """du/dt = -R(u) ( mu_h(u) - kappa lap u )."""
@@ -101,7 +134,6 @@ class AllenCahn2DPeriodic(BaseEquation):
     def __post_init__(self):
         if len(self.domain.points) != 2:
             raise ValueError("AllenCahn2DPeriodic needs a 2-D domain")
-        _spectral_attributes(self)
         self._mu_desc = as_closure(self.mu)
         self._mob_desc = as_closure(self.R)
         _select_rhs(self)
