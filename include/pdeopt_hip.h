@@ -177,6 +177,11 @@ int pdeopt_get_interpolated(pdeopt_ctx* ctx, double theta, int env_first, int en
                             void* host_out);
 /* per-environment reductions of the state (reward helpers); out is [batch] doubles. */
 int pdeopt_reduce(pdeopt_ctx* ctx, int op, double* out_per_env);
+/* uint8 image observations formed on the device (observation space Box(0, 255, (1, *points), uint8),
+ * pde_env.py:118-126): q = rint(clip((x - lo) / (hi - lo), 0, 1) * 255); host_out is
+ * [env_count][nx][ny] bytes -- a quarter (fp32) / an eighth (fp64) of the D2H of the raw field. */
+int pdeopt_observe_u8(pdeopt_ctx* ctx, double lo, double hi, int env_first, int env_count,
+                      uint8_t* host_out);
 
 /* ---- domain decomposition of one large field (BASELINE config 5; no reference counterpart) -----
  * With PDEOPT_OPT_HALO_LAYOUT = 4 a ctx holds one rank's tile.  Per RK4 substep the caller runs

@@ -36,7 +36,7 @@ int ensure_buffer(pdeopt_ctx* ctx, void** p, size_t bytes) {
 namespace {
 
 void free_fields(pdeopt_ctx* ctx) {
-  void** bufs[] = {&ctx->Y, &ctx->TA, &ctx->TB, &ctx->ACC, &ctx->SNAP, &ctx->KS, &ctx->env_params_dev};
+  void** bufs[] = {&ctx->Y, &ctx->TA, &ctx->TB, &ctx->ACC, &ctx->SNAP, &ctx->KS, &ctx->obs_dev, &ctx->env_params_dev};
   for (void** b : bufs) {
     if (*b) (void)hipFree(*b);
     *b = nullptr;
@@ -451,6 +451,16 @@ int pdeopt_reduce(pdeopt_ctx* ctx, int op, double* out_per_env) {
   if (ctx->halo) return fail(ctx, PDEOPT_EINVAL, "reductions are not available in the padded layout");
   PDEOPT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   return reduce_state(ctx, op, out_per_env);
+}
+
+int pdeopt_observe_u8(pdeopt_ctx* ctx, double lo, double hi, int env_first, int env_count,
+                      uint8_t* host_out) {
+  if (!ctx || !host_out) return PDEOPT_EINVAL;
+  int rc = check_envs(ctx, env_first, env_count);
+  if (rc) return rc;
+  if (ctx->prob.equation == PDEOPT_EQ_GPE) return fail(ctx, PDEOPT_EINVAL, "observe_u8 needs a real field");
+  PDEOPT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  return observe_u8(ctx, lo, hi, env_first, env_count, host_out);
 }
 
 int pdeopt_tsit5_trial(pdeopt_ctx* ctx, double t, double dt, double rtol, double atol,

@@ -74,6 +74,7 @@ struct pdeopt_ctx {
   void* TB = nullptr;
   void* ACC = nullptr;
   void* SNAP = nullptr;
+  void* obs_dev = nullptr;  // uint8 observation frames
   void* KS = nullptr;  // slope scratch of the spectral-RHS stage path
   void* K[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // Tsit5 slopes
   bool tsit5_pending = false;
@@ -142,6 +143,7 @@ int rk4_phase_plan(pdeopt_ctx* ctx, int* fields, int* nphases);
 void* field_ptr(pdeopt_ctx* ctx, int field);
 // reduce.hip
 int reduce_state(pdeopt_ctx* ctx, int op, double* out);
+int observe_u8(pdeopt_ctx* ctx, double lo, double hi, int env_first, int env_count, void* host_out);
 // spectral.hip
 int advance_imex(pdeopt_ctx* ctx, double t0, double dt, int64_t n);
 int rhs_fourier(pdeopt_ctx* ctx, const void* in, void* out);

@@ -1,6 +1,8 @@
 // Per-environment reductions of the state (reward helpers of PDEEnv.step, pde_env.py:309:
 // e.g. reward_function = np.var, notebooks/test_pde_env.ipynb:57).  Deterministic: fixed
 // partition into chunks, fp64 partials, combined on the host in a fixed order.
+#include <algorithm>
+
 #include "common.hpp"
 
 namespace pdeopt {
@@ -100,6 +102,46 @@ int run_pass(pdeopt_ctx* ctx, const double* shift_dev, std::vector<Partial>& hos
 }
 
 }  // namespace
+
+// uint8 frames for image observations (the reference declares Box(0, 255, (1, *points), uint8),
+// pde_env.py:118-126): q = rint(clip((x - lo) / (hi - lo), 0, 1) * 255), 4 cells per thread
+template <typename T>
+__global__ void observe_u8_kernel(const T* __restrict__ y, uint32_t* __restrict__ out, int64_t n4, T lo,
+                                  T scale) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    uint32_t w = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      T v = (y[4 * i + e] - lo) * scale;
+      v = v < T(0) ? T(0) : (v > T(255) ? T(255) : v);  // NaN -> 0 through the first comparison chain
+      if (!(v == v)) v = T(0);
+      w |= (uint32_t)__builtin_rint((double)v) << (8 * e);
+    }
+    out[i] = w;
+  }
+}
+
+int observe_u8(pdeopt_ctx* ctx, double lo, double hi, int env_first, int env_count, void* host_out) {
+  if (ctx->halo) return fail(ctx, PDEOPT_EINVAL, "observations are not available in the padded layout");
+  if (!(hi > lo)) return fail(ctx, PDEOPT_EINVAL, "observe_u8 needs hi > lo");
+  const int64_t n = (int64_t)ctx->env_elems * env_count;
+  if (n % 4) return fail(ctx, PDEOPT_EINVAL, "observe_u8 needs a multiple of 4 cells");
+  int rc = ensure_buffer(ctx, &ctx->obs_dev, ctx->env_elems * (size_t)ctx->prob.batch);
+  if (rc) return rc;
+  const int64_t n4 = n / 4;
+  const int blocks = (int)std::min<int64_t>((n4 + 255) / 256, 4096);
+  const size_t off = (size_t)env_first * ctx->env_elems;
+  if (ctx->prob.dtype == PDEOPT_F32)
+    hipLaunchKernelGGL(observe_u8_kernel<float>, dim3(blocks), dim3(256), 0, ctx->stream,
+                       (const float*)ctx->Y + off, (uint32_t*)ctx->obs_dev, n4, (float)lo, (float)(255.0 / (hi - lo)));
+  else
+    hipLaunchKernelGGL(observe_u8_kernel<double>, dim3(blocks), dim3(256), 0, ctx->stream,
+                       (const double*)ctx->Y + off, (uint32_t*)ctx->obs_dev, n4, lo, 255.0 / (hi - lo));
+  PDEOPT_HIP_CHECK(ctx, hipGetLastError());
+  PDEOPT_HIP_CHECK(ctx, hipMemcpyAsync(host_out, ctx->obs_dev, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+  PDEOPT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return PDEOPT_OK;
+}
 
 int reduce_state(pdeopt_ctx* ctx, int op, double* out) {
   const int batch = ctx->prob.batch;

@@ -212,6 +212,14 @@ class HipEngine:
         self._check(self._lib.pdeopt_reduce(self._h, int(op), out.ctypes.data_as(C.c_void_p)))
         return out
 
+    def observe_u8(self, lo: float, hi: float, env_first: int = 0, env_count: Optional[int] = None) -> np.ndarray:
+        """uint8 frames ``rint(clip((x-lo)/(hi-lo), 0, 1) * 255)`` of shape (envs, nx, ny), quantised on the GPU"""
+        n = self.batch - env_first if env_count is None else env_count
+        out = np.empty((n,) + self.state_shape, dtype=np.uint8)
+        self._check(self._lib.pdeopt_observe_u8(self._h, float(lo), float(hi), int(env_first), int(n),
+                                                out.ctypes.data_as(C.c_void_p)))
+        return out
+
     def tsit5_trial(self, t: float, dt: float, rtol: float, atol: float) -> np.ndarray:
         err = np.empty(self.batch, dtype=np.float64)
         self._check(

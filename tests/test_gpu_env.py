@@ -101,3 +101,19 @@ def test_vector_env_matches_single_envs():
     venv.close()
     for e in singles:
         e.close()
+
+
+def test_device_observation_uint8():
+    dom = std_domain(P, 64, 128)
+    kw = _env_kwargs(dom)
+    venv = P.VectorPDEEnv(2, **kw, device_reward="mean", device_observation=(0.0, 1.0))
+    venv.reset(seed=5)
+    obs, rewards, _, _, _ = venv.step([1, 1])
+    states = venv.states
+    assert obs.shape == (2, 1, 64, 128) and obs.dtype == np.uint8
+    want = np.rint(np.clip(states, 0.0, 1.0) * 255).astype(np.uint8)
+    # rint ties may differ by the fp32 scaling; allow one level on a vanishing fraction of cells
+    diff = np.abs(obs[:, 0].astype(int) - want.astype(int))
+    assert diff.max() <= 1 and (diff > 0).mean() < 1e-3
+    np.testing.assert_allclose(rewards, states.astype(np.float64).mean(axis=(1, 2)), rtol=1e-12)
+    venv.close()
