@@ -33,7 +33,14 @@ struct Spectral {
   void* dens = nullptr;    // real |psi0|^2 (Strang)
   double* partial = nullptr;  // [batch][kNormBlocks]
   double* scale = nullptr;    // [batch]
-  // cache key of `mult`
+  // real <-> hermitian transforms of the IMEX step (half the bytes of C2C)
+  rocfft_plan r2c = nullptr, c2r = nullptr;
+  rocfft_execution_info rinfo = nullptr;
+  void* rwork = nullptr;
+  void* hbuf = nullptr;    // hermitian half-spectrum work field
+  void* hmult = nullptr;   // multiplier on the half-spectrum
+  int64_t half_cells = 0;  // complex elements of one half-spectrum
+  // cache key of `mult` / `hmult`
   int mult_kind = -1;
   double mult_dt = NAN, mult_A = NAN, mult_tr = NAN, mult_ti = NAN;
 };
@@ -85,6 +92,47 @@ int ensure_plans(pdeopt_ctx* ctx) {
   }
   PDEOPT_FFT_CHECK(ctx, rocfft_execution_info_set_stream(sp.info, ctx->stream));
   sp.setup = true;
+  return PDEOPT_OK;
+}
+
+// real-to-hermitian plans.  The fastest non-trivial dimension is the one rocFFT halves.
+int ensure_real_plans(pdeopt_ctx* ctx) {
+  Spectral& sp = *ctx->spectral;
+  if (sp.r2c) return PDEOPT_OK;
+  const pdeopt_problem& p = ctx->prob;
+  size_t lengths[2];
+  size_t dims = 0;
+  if (p.ny > 1) lengths[dims++] = (size_t)p.ny;
+  if (p.nx > 1) lengths[dims++] = (size_t)p.nx;
+  if (dims == 0) lengths[dims++] = 1;
+  sp.half_cells = (int64_t)(lengths[0] / 2 + 1) * (dims > 1 ? (int64_t)lengths[1] : 1);
+  const rocfft_precision prec =
+      p.dtype == PDEOPT_F32 ? rocfft_precision_single : rocfft_precision_double;
+  PDEOPT_FFT_CHECK(ctx, rocfft_plan_create(&sp.r2c, rocfft_placement_notinplace,
+                                           rocfft_transform_type_real_forward, prec, dims, lengths,
+                                           (size_t)p.batch, nullptr));
+  PDEOPT_FFT_CHECK(ctx, rocfft_plan_create(&sp.c2r, rocfft_placement_notinplace,
+                                           rocfft_transform_type_real_inverse, prec, dims, lengths,
+                                           (size_t)p.batch, nullptr));
+  size_t w1 = 0, w2 = 0;
+  PDEOPT_FFT_CHECK(ctx, rocfft_plan_get_work_buffer_size(sp.r2c, &w1));
+  PDEOPT_FFT_CHECK(ctx, rocfft_plan_get_work_buffer_size(sp.c2r, &w2));
+  const size_t wb = w1 > w2 ? w1 : w2;
+  PDEOPT_FFT_CHECK(ctx, rocfft_execution_info_create(&sp.rinfo));
+  if (wb) {
+    int rc = ensure_buffer(ctx, &sp.rwork, wb);
+    if (rc) return rc;
+    PDEOPT_FFT_CHECK(ctx, rocfft_execution_info_set_work_buffer(sp.rinfo, sp.rwork, wb));
+  }
+  PDEOPT_FFT_CHECK(ctx, rocfft_execution_info_set_stream(sp.rinfo, ctx->stream));
+  return PDEOPT_OK;
+}
+
+int real_fft_exec(pdeopt_ctx* ctx, bool forward, void* in, void* out) {
+  Spectral& sp = *ctx->spectral;
+  void* ib[1] = {in};
+  void* ob[1] = {out};
+  PDEOPT_FFT_CHECK(ctx, rocfft_execute(forward ? sp.r2c : sp.c2r, ib, ob, sp.rinfo));
   return PDEOPT_OK;
 }
 
@@ -249,6 +297,19 @@ int fetch_complex_aux(pdeopt_ctx* ctx, int which, std::vector<std::complex<doubl
   return PDEOPT_OK;
 }
 
+// y += dt * r
+template <typename T>
+__global__ void axpy_real_kernel(T* __restrict__ y, const T* __restrict__ r, T dt, int64_t n) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t st = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += st) y[i] += dt * r[i];
+}
+
+// IMEX on real <-> hermitian transforms.  The reference runs full complex transforms on the real
+// field (cahn_hilliard.py:72-73) and keeps `.real` of the result (solvers.py:63).  For a real input F
+// is hermitian, so  Re ifft(F m) = ifft(F m_h)  with  m_h(k) = (m(k) + conj(m(-k))) / 2 : the
+// symmetrised multiplier on the half-spectrum reproduces the reference for ANY (also non-even,
+// complex) fourier_symbol while moving half the bytes through rocFFT.
 template <typename T>
 int imex_t(pdeopt_ctx* ctx, double dt, int64_t n) {
   Spectral& sp = *ctx->spectral;
@@ -256,32 +317,43 @@ int imex_t(pdeopt_ctx* ctx, double dt, int64_t n) {
   const int64_t cells = (int64_t)p.nx * p.ny;
   const int64_t total = cells * p.batch;
   int rc;
+  if ((rc = ensure_real_plans(ctx))) return rc;
+  const int64_t hc = sp.half_cells;
   if ((rc = ensure_buffer(ctx, &ctx->TA, ctx->total_bytes))) return rc;
-  if ((rc = ensure_buffer(ctx, &sp.cbuf, (size_t)total * 2 * sizeof(T)))) return rc;
-  if (sp.mult_kind != 0 || sp.mult_dt != dt || sp.mult_A != ctx->imex_A) {
-    // multiplier 1 / ((1 + A dt symbol) N): solvers.py:62-63 with ifft's 1/N folded in
+  if ((rc = ensure_buffer(ctx, &sp.hbuf, (size_t)hc * p.batch * 2 * sizeof(T)))) return rc;
+  if (sp.mult_kind != 2 || sp.mult_dt != dt || sp.mult_A != ctx->imex_A) {
     std::vector<std::complex<double>> sym;
     if ((rc = fetch_complex_aux(ctx, PDEOPT_AUX_IMEX_SYMBOL, sym))) return rc;
     const double inv_n = 1.0 / (double)cells;
-    for (auto& s : sym) s = inv_n / (1.0 + ctx->imex_A * dt * s);
-    if ((rc = upload_mult<T>(ctx, sym))) return rc;
-    sp.mult_kind = 0;
+    auto m = [&](int i, int j) { return inv_n / (1.0 + ctx->imex_A * dt * sym[(size_t)i * p.ny + j]); };
+    std::vector<C2<T>> h((size_t)hc);
+    // half-spectrum layout [slow][fast/2+1]; the halved (fastest non-trivial) axis is y unless ny == 1
+    const bool y_fast = p.ny > 1;
+    const int nfast = y_fast ? p.ny : p.nx, nslow = y_fast ? p.nx : 1, nh = nfast / 2 + 1;
+    for (int sidx = 0; sidx < nslow; ++sidx)
+      for (int f = 0; f < nh; ++f) {
+        const int i = y_fast ? sidx : f, j = y_fast ? f : 0;
+        const std::complex<double> v = 0.5 * (m(i, j) + std::conj(m((p.nx - i) % p.nx, (p.ny - j) % p.ny)));
+        h[(size_t)sidx * nh + f] = C2<T>{(T)v.real(), (T)v.imag()};
+      }
+    if ((rc = ensure_buffer(ctx, &sp.hmult, (size_t)hc * sizeof(C2<T>)))) return rc;
+    PDEOPT_HIP_CHECK(ctx, hipMemcpyAsync(sp.hmult, h.data(), (size_t)hc * sizeof(C2<T>), hipMemcpyHostToDevice, ctx->stream));
+    PDEOPT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    sp.mult_kind = 2;
     sp.mult_dt = dt;
     sp.mult_A = ctx->imex_A;
   }
   for (int64_t s = 0; s < n; ++s) {
     if ((rc = launch_rhs(ctx, ctx->Y, ctx->TA, 0.0))) return rc;
-    hipLaunchKernelGGL(embed_real_kernel<T>, dim3(grid_for(total)), dim3(256), 0, ctx->stream,
-                       (const T*)ctx->TA, (C2<T>*)sp.cbuf, total);
-    if ((rc = fft_exec(ctx, true, sp.cbuf))) return rc;
-    hipLaunchKernelGGL((spectral_mul_kernel<T, false>), dim3(grid_for(cells), p.batch), dim3(256), 0,
-                       ctx->stream, (C2<T>*)sp.cbuf, (const C2<T>*)sp.mult, nullptr, cells);
-    if ((rc = fft_exec(ctx, false, sp.cbuf))) return rc;
-    hipLaunchKernelGGL(imex_update_kernel<T>, dim3(grid_for(total)), dim3(256), 0, ctx->stream,
-                       (T*)ctx->Y, (const C2<T>*)sp.cbuf, (T)dt, total);
+    if ((rc = real_fft_exec(ctx, true, ctx->TA, sp.hbuf))) return rc;
+    hipLaunchKernelGGL((spectral_mul_kernel<T, false>), dim3(grid_for(hc), p.batch), dim3(256), 0,
+                       ctx->stream, (C2<T>*)sp.hbuf, (const C2<T>*)sp.hmult, nullptr, hc);
+    if ((rc = real_fft_exec(ctx, false, sp.hbuf, ctx->TA))) return rc;
+    hipLaunchKernelGGL(axpy_real_kernel<T>, dim3(grid_for(total)), dim3(256), 0, ctx->stream,
+                       (T*)ctx->Y, (const T*)ctx->TA, (T)dt, total);
   }
   PDEOPT_HIP_CHECK(ctx, hipGetLastError());
-  ctx->last_kernel += "+imex_rocfft_c2c";
+  ctx->last_kernel += "+imex_rocfft_r2c";
   return PDEOPT_OK;
 }
 
@@ -499,10 +571,13 @@ void spectral_invalidate(pdeopt_ctx* ctx) {
 void spectral_destroy(pdeopt_ctx* ctx) {
   Spectral* sp = ctx->spectral;
   if (!sp) return;
+  if (sp->r2c) rocfft_plan_destroy(sp->r2c);
+  if (sp->c2r) rocfft_plan_destroy(sp->c2r);
+  if (sp->rinfo) rocfft_execution_info_destroy(sp->rinfo);
   if (sp->fwd) rocfft_plan_destroy(sp->fwd);
   if (sp->inv) rocfft_plan_destroy(sp->inv);
   if (sp->info) rocfft_execution_info_destroy(sp->info);
-  void* bufs[] = {sp->work, sp->cbuf, sp->cbuf2, sp->cbuf3, sp->mult, sp->dens, sp->partial, sp->scale};
+  void* bufs[] = {sp->work, sp->rwork, sp->hbuf, sp->hmult, sp->cbuf, sp->cbuf2, sp->cbuf3, sp->mult, sp->dens, sp->partial, sp->scale};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   delete sp;
