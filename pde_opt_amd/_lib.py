@@ -13,7 +13,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpdeopt_hip.so")
+LIB_PATH = os.environ.get("PDEOPT_LIB") or os.path.join(_HERE, "libpdeopt_hip.so")  # PDEOPT_LIB: A/B builds
 
 MAX_COEF = 16
 

@@ -212,8 +212,13 @@ __global__ __launch_bounds__(256) void stage_pair_kernel(const PairArgs<T> a, co
   // mu on `nrows` rows starting at mu-row `rm0` (mu row rm <-> sU row rm + 1)
   auto mu_pass = [&](const int rm0, const int nrows) {
     const int nvec = nrows * PV;
+    const int lane = tid & 63;
+    // uniform trip count (every lane takes part in the DPP shifts); lanes past the end recompute
+    // the last vector and do not store
 #pragma unroll 1
-    for (int idx = tid; idx < nvec; idx += 256) {
+    for (int base0 = 0; base0 < nvec; base0 += 256) {
+      const int idx_raw = base0 + tid;
+      const int idx = idx_raw < nvec ? idx_raw : nvec - 1;
       const int rr = idx / PV;
       const int cv = idx - rr * PV;
       const int rm = rm0 + rr;
@@ -221,7 +226,17 @@ __global__ __launch_bounds__(256) void stage_pair_kernel(const PairArgs<T> a, co
       const Vec c = *reinterpret_cast<const Vec*>(c_);
       const Vec xp = *reinterpret_cast<const Vec*>(c_ + P);
       const Vec xm = *reinterpret_cast<const Vec*>(c_ - P);
+      // consecutive lanes hold consecutive vectors of the (unpadded) row-major array: the left /
+      // right scalar neighbours sit in the adjacent lanes' registers; only the wave's end lanes read LDS
+#ifdef PDEOPT_DPP_EXCHANGE  // measured 6 % SLOWER than the conflicted LDS reads (VALU-bound kernel, +6 VGPRs)
+      T left = lane_from_prev(T(0), c[V - 1]);
+      T right = lane_from_next(T(0), c[0]);
+      if (lane == 0) left = c_[-1];
+      if (lane == 63) right = c_[V];
+#else
       const T left = c_[-1], right = c_[V];
+      (void)lane;
+#endif
       Vec m;
 #pragma unroll
       for (int e = 0; e < V; ++e) {
@@ -229,7 +244,7 @@ __global__ __launch_bounds__(256) void stage_pair_kernel(const PairArgs<T> a, co
         const T yp = (e == V - 1) ? right : c[e + 1];
         m[e] = eval_mu<T, CL>(a.mu, p.mu, c[e]) - kap * lap_at<T>(c[e], xp[e], xm[e], yp, ym, a.rhx2, a.rhy2);
       }
-      *reinterpret_cast<Vec*>(sMu + rm * P + cv * V) = m;
+      if (idx_raw < nvec) *reinterpret_cast<Vec*>(sMu + rm * P + cv * V) = m;
     }
   };
 
@@ -265,8 +280,24 @@ __global__ __launch_bounds__(256) void stage_pair_kernel(const PairArgs<T> a, co
       const Vec m_hi = *reinterpret_cast<const Vec*>(mp + P);
       const Vec u_hi = *reinterpret_cast<const Vec*>(up + P);
       const Vec d_hi = mob_vec<T, CL, Vec, V>(a.mob, p.mob, u_hi);
+      // left / right neighbours of the centre row: adjacent lanes' registers (mu and the mobility
+      // they already evaluated); the first / last lane of a tile row takes the halo from LDS
+#ifdef PDEOPT_DPP_EXCHANGE  // measured 6 % SLOWER than the conflicted LDS reads (VALU-bound kernel, +6 VGPRs)
+      T ml = lane_from_prev(T(0), m_c[V - 1]), mr = lane_from_next(T(0), m_c[0]);
+      T dl = lane_from_prev(T(0), d_c[V - 1]), dr = lane_from_next(T(0), d_c[0]);
+      if (lx == 0) {
+        ml = mp[-1];
+        dl = eval_mob<T, CL>(a.mob, p.mob, up[-1]);
+      }
+      if (lx == kLanesPerRow - 1) {
+        mr = mp[V];
+        dr = eval_mob<T, CL>(a.mob, p.mob, up[V]);
+      }
+#else
+      const T ml = mp[-1], mr = mp[V];
       const T dl = eval_mob<T, CL>(a.mob, p.mob, up[-1]), dr = eval_mob<T, CL>(a.mob, p.mob, up[V]);
-      const Vec dy = div_y<T, Vec, V>(m_c, d_c, mp[-1], mp[V], dl, dr, a.rhy);
+#endif
+      const Vec dy = div_y<T, Vec, V>(m_c, d_c, ml, mr, dl, dr, a.rhy);
       Vec fx_hi, k;
 #pragma unroll
       for (int e = 0; e < V; ++e) {

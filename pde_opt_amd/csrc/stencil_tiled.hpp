@@ -39,6 +39,31 @@ struct VecOf<double> {
   static constexpr int V = 2;
 };
 
+// Whole-wave DPP shifts (gfx9: wave_shr:1 / wave_shl:1; checked on gfx950 with tools/dpp_test.hip):
+// lane i receives the value of lane i-1 (from_prev) / lane i+1 (from_next); lane 0 / lane 63 keep
+// `old`.  Neighbour exchange along a tile row in registers instead of a scalar LDS read whose
+// 16-byte lane stride is a 4-way bank conflict.
+__device__ __forceinline__ float lane_from_prev(float old, float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old),
+                                                                __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float lane_from_next(float old, float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old),
+                                                                __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false));
+}
+__device__ __forceinline__ double lane_from_prev(double old, double v) {
+  const long long o = __builtin_bit_cast(long long, old), x = __builtin_bit_cast(long long, v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp((int)(unsigned)o, (int)(unsigned)x, 0x138, 0xf, 0xf, false);
+  const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp((int)(o >> 32), (int)(x >> 32), 0x138, 0xf, 0xf, false);
+  return __builtin_bit_cast(double, ((long long)hi << 32) | (long long)lo);
+}
+__device__ __forceinline__ double lane_from_next(double old, double v) {
+  const long long o = __builtin_bit_cast(long long, old), x = __builtin_bit_cast(long long, v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp((int)(unsigned)o, (int)(unsigned)x, 0x130, 0xf, 0xf, false);
+  const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp((int)(o >> 32), (int)(x >> 32), 0x130, 0xf, 0xf, false);
+  return __builtin_bit_cast(double, ((long long)hi << 32) | (long long)lo);
+}
+
 constexpr int kLanesPerRow = 32;   // vectors per tile row
 constexpr int kPV = kLanesPerRow + 2;  // vectors per LDS row (one halo vector each side)
 // RPT = rows per thread; a tile has TX = 8 * RPT rows (8 row groups of 32 lanes = 256 threads)
