@@ -27,6 +27,7 @@ HEADERS = [
     "stencil_generic.hpp",
     "stencil_tiled.hpp",
     "stencil_fused.hpp",
+    "stencil_fused_ac.hpp",
     os.path.join(ROOT, "include", "pdeopt_hip.h"),
 ]
 ARCH = "gfx950"

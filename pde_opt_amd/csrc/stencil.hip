@@ -10,6 +10,7 @@
 #include "stencil_generic.hpp"
 #include "stencil_tiled.hpp"
 #include "stencil_fused.hpp"
+#include "stencil_fused_ac.hpp"
 
 namespace pdeopt {
 

@@ -375,13 +375,18 @@ __global__ __launch_bounds__(256) void stage_pair_kernel(const PairArgs<T> a, co
 template <typename T>
 bool fused_supported(const pdeopt_ctx* ctx) {
   if (ctx->opt_fuse_stages < 0) return false;
-  if (ctx->prob.equation != PDEOPT_EQ_CAHN_HILLIARD) return false;
+  if (ctx->prob.equation != PDEOPT_EQ_CAHN_HILLIARD && ctx->prob.equation != PDEOPT_EQ_ALLEN_CAHN)
+    return false;
   if (!tiled_supported<T>(ctx)) return false;
   return classify_closures(ctx->prob.mu, ctx->prob.mob) != CL_GENERIC;
 }
 
 template <typename T, int CL, int PAIR, int RPT>
+int launch_pair_ac_inst(pdeopt_ctx* ctx, const PairArgs<T>& s);  // stencil_fused_ac.hpp
+
+template <typename T, int CL, int PAIR, int RPT>
 int launch_pair_inst(pdeopt_ctx* ctx, const PairArgs<T>& s) {
+  if (ctx->prob.equation == PDEOPT_EQ_ALLEN_CAHN) return launch_pair_ac_inst<T, CL, PAIR, RPT>(ctx, s);
   constexpr int V = VecOf<T>::V;
   const pdeopt_problem& p = ctx->prob;
   const int tiles_i = p.nx / (8 * RPT);
@@ -418,8 +423,8 @@ int launch_pair(pdeopt_ctx* ctx, int pair, const void* in, const void* y, const 
   const int cl = classify_closures(p.mu, p.mob);
   const int rpt = tiled_rpt(ctx);
   char name[96];
-  snprintf(name, sizeof(name), "stage_pair<%s,CH,%s,rows%d>", sizeof(T) == 4 ? "f32" : "f64",
-           cl == CL_LOGIT ? "logit" : "poly", 8 * rpt);
+  snprintf(name, sizeof(name), "stage_pair<%s,%s,%s,rows%d>", sizeof(T) == 4 ? "f32" : "f64",
+           p.equation == PDEOPT_EQ_ALLEN_CAHN ? "AC" : "CH", cl == CL_LOGIT ? "logit" : "poly", 8 * rpt);
   ctx->last_kernel = name;
 #define PDEOPT_PAIR_DISPATCH(CLV, PAIRV)                                             \
   (rpt == 2 ? launch_pair_inst<T, CLV, PAIRV, 2>(ctx, s) : launch_pair_inst<T, CLV, PAIRV, 4>(ctx, s))

@@ -99,12 +99,23 @@ class TorchComm:
     'gloo' on CPU tensors (tests)."""
 
     def __init__(self, group=None):
+        import torch
         import torch.distributed as dist
 
         self._dist = dist
+        self._torch = torch
         self.group = group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
+        # On the GPU the collectives are issued under a dedicated torch stream and the HIP engine
+        # runs on the SAME stream (stream_handle), so pack -> all-gather -> unpack -> stencil order
+        # without host synchronisation.  (torch's default stream is the null stream, whose handle is
+        # 0 and cannot be shared with a non-blocking stream: an explicit stream is required.)
+        self.stream = None
+        self.stream_handle = None
+        if dist.get_backend(group) == "nccl":
+            self.stream = torch.cuda.Stream()
+            self.stream_handle = self.stream.cuda_stream
 
     def make_buffers(self, backend):
         import torch
@@ -116,7 +127,11 @@ class TorchComm:
         return send, recv
 
     def all_gather(self, send, recv):
-        self._dist.all_gather_into_tensor(recv, send, group=self.group)
+        if self.stream is not None:
+            with self._torch.cuda.stream(self.stream):
+                self._dist.all_gather_into_tensor(recv, send, group=self.group)
+        else:
+            self._dist.all_gather_into_tensor(recv, send, group=self.group)
 
 
 # ---------------------------------------------------------------------------------- HIP backend
@@ -175,6 +190,8 @@ class DecomposedSolver:
         self.tile_shape = grid.tile_shape(nx, ny)
         if min(self.tile_shape) < 2 * HALO:
             raise ValueError("tiles must be at least 8 cells wide")
+        if stream is None:
+            stream = getattr(self.comm, "stream_handle", None)
         self.backend = backend or HipTileBackend(equation, self.tile_shape, dtype, device, stream)
         self.send, self.recv = self.comm.make_buffers(self.backend)
         self.neighbours = grid.neighbours()

@@ -114,11 +114,13 @@ def test_rccl_allgather_path_single_rank():
         eq = P.CahnHilliard2DPeriodic(dom, 0.002, MU["regsol"], MOB["c1mc"])
         y0 = np.clip(0.5 + 0.05 * rng.standard_normal((64, 128)), 0.05, 0.95).astype(np.float32)
         want, _ = _monolithic(eq, y0, 2e-7, 5, 0)
-        stream = torch.cuda.current_stream().cuda_stream
-        sol = DecomposedSolver(eq, CartesianGrid(1, 1, 0), comm=TorchComm(), dtype=np.float32, stream=stream)
+        comm = TorchComm()
+        assert comm.stream_handle  # a real (non-null) stream shared by RCCL and the engine
+        sol = DecomposedSolver(eq, CartesianGrid(1, 1, 0), comm=comm, dtype=np.float32)
         sol.set_global_state(y0)
-        sol.advance(2e-7, 5)
+        sol.advance(2e-7, 50)
         torch.cuda.synchronize()
+        want, _ = _monolithic(eq, y0, 2e-7, 50, 0)
         np.testing.assert_array_equal(sol.local_state(), want)
         assert sol.send.is_cuda and sol.recv.numel() == sol.backend.strip_elems
     finally:
