@@ -76,6 +76,40 @@ def test_multi_tile_on_one_gpu_equals_monolithic(grid, fuse):
     np.testing.assert_array_equal(got, want)
 
 
+def test_generic_kernel_in_padded_layout():
+    """tiles the LDS kernels do not cover (24 x 40) go through the generic kernel, halo reads included"""
+    rng = np.random.default_rng(5)
+    px, py, tx, ty = 2, 2, 24, 40
+    nx, ny = px * tx, py * ty
+    dom = std_domain(P, nx, ny)
+    eq = P.AllenCahn2DPeriodic(dom, 0.002, MU["cubic"], MOB["one_plus_sq"])
+    y0 = 0.1 * rng.standard_normal((nx, ny))
+    want, kern = _monolithic(eq, y0, 1e-4, 3, 0)
+    assert "generic" in kern
+    comm = InProcessComm(px * py)
+    solvers = []
+    for r in range(px * py):
+        be = HipTileBackend(eq, (tx, ty), np.float64)
+        s = DecomposedSolver(eq, CartesianGrid(px, py, r), comm=comm.view(r), dtype=np.float64, backend=be)
+        s.set_global_state(y0)
+        solvers.append(s)
+    plan = solvers[0].backend.phase_plan()
+    assert len(plan) == 4
+    for _ in range(3):
+        for phase, field in enumerate(plan):
+            for s in solvers:
+                s.backend.pack(field, s.send)
+            gather_all(comm)
+            for s in solvers:
+                s.backend.unpack(field, s.recv, s.neighbours)
+                s.backend.phase(phase, 1e-4)
+    got = np.empty_like(want)
+    for s in solvers:
+        si, sj = s.grid.tile_slices(nx, ny)
+        got[si, sj] = s.local_state()
+    np.testing.assert_array_equal(got, want)
+
+
 def test_config5_tile_size_smoke():
     """one 2048^2 tile of BASELINE config 5 (4096^2 over 2x2) with self-neighbours: finite + mass"""
     rng = np.random.default_rng(2)
