@@ -481,3 +481,60 @@ def test_explicit_step_with_fourier_rhs():
     np.testing.assert_allclose(got, ref, rtol=0, atol=1e-13)
     with pytest.raises(ValueError, match="Invalid derivative type"):
         P.AllenCahn2DPeriodic(dom, 0.002, MU["cubic"], MOB["one"], derivs="spectral")
+
+
+# ------------------------------------------------------------------ API corners
+def test_per_env_closure_coefficients():
+    """closure coefficient VALUES travel with the environment (same structure across the batch)"""
+    rng = np.random.default_rng(21)
+    dom = std_domain(P, 64, 128)
+    y0 = np.clip(0.5 + 0.05 * rng.standard_normal((3, 64, 128)), 0.05, 0.95).astype(np.float32)
+    omegas = [2.5, 3.0, 3.5]
+    mobs = [0.5, 1.0, 2.0]
+    mk = lambda om, m: P.CahnHilliard2DPeriodic(
+        dom, 0.002, P.polynomial(om, -2 * om, logit_prior=True), P.polynomial(0.0, m, -m))
+    eqs = [mk(om, m) for om, m in zip(omegas, mobs)]
+    eng = P.HipEngine()
+    eng.configure(dtype=np.float32, batch=3, **eqs[0]._engine_problem())
+    eng.set_env_params(0, mu_coef=[e._mu_desc.coef for e in eqs], mob_coef=[e._mob_desc.coef for e in eqs])
+    eng.set_state(y0)
+    eng.advance(L.INT_RK4, 2e-7, 4)
+    got = eng.get_state()
+    for b, e in enumerate(eqs):
+        want = P.diffeqsolve(e, P.RK4(), 0.0, 8e-7, 2e-7, y0[b]).ys[-1]
+        np.testing.assert_array_equal(got[b], want)
+    ptr, nbytes = eng.state_device_ptr()
+    assert ptr and nbytes == 3 * 64 * 128 * 4
+    eng.close()
+
+
+def test_saveat_variants_and_max_steps():
+    rng = np.random.default_rng(22)
+    dom = std_domain(P, 32, 32)
+    eq = P.AllenCahn2DPeriodic(dom, 0.002, MU["cubic"], MOB["one"])
+    y0 = 0.1 * rng.standard_normal((32, 32))
+    sol = P.diffeqsolve(eq, P.Euler(), 0.0, 1e-3, 1e-4, y0, saveat=P.SaveAt(t0=True, t1=True))
+    assert sol.ys.shape == (2, 32, 32) and sol.stats["num_steps"] == 10
+    np.testing.assert_array_equal(sol.ys[0], y0)
+    with pytest.raises(RuntimeError, match="max_steps"):
+        P.diffeqsolve(eq, P.Euler(), 0.0, 1e-3, 1e-4, y0, max_steps=5)
+    short = P.diffeqsolve(eq, P.Euler(), 0.0, 1e-3, 1e-4, y0, max_steps=5, throw=False)
+    five = P.diffeqsolve(eq, P.Euler(), 0.0, 5e-4, 1e-4, y0)
+    np.testing.assert_array_equal(short.ys[-1], five.ys[-1])
+    # a remainder step: 0.35e-3 = 3 full steps of 1e-4 + one of 0.5e-4
+    hx, hy = dom.dx
+    f = lambda t, u: O.ac_rhs_fd(u, hx, hy, 0.002, MU["cubic"], MOB["one"])
+    got = P.diffeqsolve(eq, P.Euler(), 0.0, 3.5e-4, 1e-4, y0)
+    assert got.stats["num_steps"] == 4
+    want = O.integrate(lambda t, y, dt: O.euler_step(f, t, y, dt), y0, 0.0, 3.5e-4, 1e-4)
+    np.testing.assert_allclose(got.ys[-1], want, rtol=0, atol=1e-14)
+
+
+def test_nan_state_is_returned_not_raised():
+    """PDEModel.solve has throw=False upstream (pde_model.py:131): divergence surfaces as NaN"""
+    dom = std_domain(P, 64, 128)
+    y0 = np.full((64, 128), 0.5, dtype=np.float32)
+    y0[3, 3] = 1.5  # outside (0, 1): log(c / (1 - c)) is NaN there and spreads
+    model = P.PDEModel(P.CahnHilliard2DPeriodic, dom, P.RK4)
+    ys = model.solve(dict(kappa=0.002, mu=MU["regsol"], D=MOB["c1mc"]), y0, [0.0, 2e-6], dt0=2e-7)
+    assert ys.shape == (2, 64, 128) and np.isnan(ys[-1]).any()
