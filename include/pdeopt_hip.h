@@ -127,6 +127,8 @@ typedef enum {
                                  environments so a group's working set stays in the 256 MiB
                                  Infinity Cache across stages and substeps (0 = auto, < 0 = whole
                                  batch in one sweep) */
+  PDEOPT_OPT_GRAPH = 6,       /* explicit integrators: replay the substep loop from a captured hipGraph:
+                                 0 = auto (launch-bound problem sizes), 1 = always, -1 = never */
   PDEOPT_OPT_HALO_LAYOUT = 5, /* layout of the NEXT pdeopt_configure: 0 = periodic field (wrap by index),
                                  4 = rank-local tile padded by a 4-cell halo on every side, no wrap
                                  (domain decomposition; halos filled by pdeopt_halo_unpack) */

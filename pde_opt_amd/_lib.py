@@ -33,6 +33,7 @@ OPT_GROUP_ENVS = 2
 OPT_DEBUG_ABLATE = 3
 OPT_FUSE_STAGES = 4
 OPT_HALO_LAYOUT = 5
+OPT_GRAPH = 6
 CNT_STAGE_LAUNCHES = 0
 COPY_H2D, COPY_D2H, COPY_D2D = 0, 1, 2
 FIELD_Y, FIELD_TA, FIELD_TB, FIELD_ACC = 0, 1, 2, 3

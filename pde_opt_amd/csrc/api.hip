@@ -50,6 +50,7 @@ void free_fields(pdeopt_ctx* ctx) {
     a = AuxField{};
   }
   spectral_destroy(ctx);
+  graph_destroy(ctx);
   ctx->tsit5_pending = false;
   ctx->tsit5_fsal_valid = false;
   ctx->configured = false;
@@ -185,6 +186,10 @@ int pdeopt_set_option(pdeopt_ctx* ctx, int option, int64_t value) {
       if (value != 0 && value != 16 && value != 32)
         return fail(ctx, PDEOPT_EINVAL, "tile rows must be 0 (auto), 16 or 32");
       ctx->opt_tile_rows = value;
+      return PDEOPT_OK;
+    case PDEOPT_OPT_GRAPH:
+      if (value < -1 || value > 1) return fail(ctx, PDEOPT_EINVAL, "graph option must be -1, 0 or 1");
+      ctx->opt_graph = value;
       return PDEOPT_OK;
     case PDEOPT_OPT_HALO_LAYOUT:
       if (value != 0 && value != 4)

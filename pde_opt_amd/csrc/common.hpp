@@ -53,6 +53,21 @@ struct AuxField {
 
 struct Spectral;  // rocFFT plans + work buffers (spectral.hip)
 
+// what a captured substep graph depends on (explicit integrators, stencil.hip)
+struct GraphStructure {
+  int equation, dtype, nx, ny, batch, derivs;
+  double hx, hy;
+  int mu_kind, mu_flags, mu_n, mob_kind, mob_flags, mob_n;
+};
+struct GraphKey {
+  int integrator;
+  int fused;
+  double dt;
+  void *Y, *TA, *TB, *ACC, *ep, *vx, *vy;
+  int64_t kernel_path, tile_rows, ablate;
+  GraphStructure structure;
+};
+
 }  // namespace pdeopt
 
 struct pdeopt_ctx {
@@ -90,6 +105,11 @@ struct pdeopt_ctx {
   int halo = 0;                  // halo width of the configured layout
   void* halo_scratch = nullptr;  // single-rank loop-back buffer for pack/unpack
   size_t halo_scratch_bytes = 0;
+  int64_t opt_graph = 0;         // hipGraph replay of the substep loop: 0 auto (launch-bound sizes), 1 always, -1 never
+  hipGraphExec_t graph_exec = nullptr;
+  pdeopt::GraphKey graph_key{};
+  int64_t graph_launches_per_replay = 0;
+  std::string graph_name;
   int64_t opt_fuse_stages = 0;   // RK4 stage-pair fusion: 0 auto (on where supported), -1 off
   int64_t opt_debug_ablate = 0;  // timing-only ablations, results are wrong when set
   int win_lo = 0, win_n = 0;  // environment window the stage launchers operate on
@@ -132,6 +152,7 @@ int launch_rhs(pdeopt_ctx* ctx, const void* in, void* out, double t);
 int advance_explicit(pdeopt_ctx* ctx, int integrator, double t0, double dt, int64_t n);
 int tsit5_trial(pdeopt_ctx* ctx, double t, double dt, double rtol, double atol, double* err);
 int tsit5_commit(pdeopt_ctx* ctx, int accept);
+void graph_destroy(pdeopt_ctx* ctx);
 int launch_lerp(pdeopt_ctx* ctx, const void* a, const void* b, void* out, double theta,
                 size_t env_first, size_t env_count);
 // halo.hip (domain decomposition: padded, non-periodic layout)

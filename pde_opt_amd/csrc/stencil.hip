@@ -6,6 +6,7 @@
 // same pass.
 #include <algorithm>
 #include <cmath>
+#include <cstring>
 
 #include "stencil_generic.hpp"
 #include "stencil_tiled.hpp"
@@ -148,6 +149,20 @@ int launch_rhs(pdeopt_ctx* ctx, const void* in, void* out, double) {
   return launch_stage(ctx, in, in, out, nullptr, 0.0, 0.0, OUT_K, ACC_NONE);
 }
 
+namespace {
+constexpr int kGraphUnit = 16;  // substeps per captured graph (even: ping-pong buffers return)
+
+// the part of a problem that is baked into kernel arguments (not the per-env parameter values)
+GraphStructure graph_structure(const pdeopt_problem& p) {
+  GraphStructure g{};
+  g.equation = p.equation; g.dtype = p.dtype; g.nx = p.nx; g.ny = p.ny; g.batch = p.batch; g.derivs = p.derivs;
+  g.hx = p.hx; g.hy = p.hy;
+  g.mu_kind = p.mu.kind; g.mu_flags = p.mu.flags; g.mu_n = p.mu.n;
+  g.mob_kind = p.mob.kind; g.mob_flags = p.mob.flags; g.mob_n = p.mob.n;
+  return g;
+}
+}  // namespace
+
 int advance_explicit(pdeopt_ctx* ctx, int integrator, double, double dt, int64_t n) {
   int rc;
   if ((rc = ensure_buffer(ctx, &ctx->TA, ctx->total_bytes))) return rc;
@@ -181,6 +196,84 @@ int advance_explicit(pdeopt_ctx* ctx, int integrator, double, double dt, int64_t
   const bool fused = integrator == PDEOPT_INT_RK4 && ctx->opt_kernel_path != 1 &&
                      ctx->prob.derivs == PDEOPT_DERIVS_FD &&
                      (ctx->prob.dtype == PDEOPT_F32 ? fused_supported<float>(ctx) : fused_supported<double>(ctx));
+
+  // one substep on the current window; Y / TA are swapped where the integrator ping-pongs
+  auto substep = [&](void*& Y, void*& TA) -> int {
+    int r;
+    if (integrator == PDEOPT_INT_EULER) {
+      r = launch_stage(ctx, Y, Y, TA, nullptr, dt, 0.0, OUT_Y_PLUS_AK, ACC_NONE);
+      std::swap(Y, TA);
+      return r;
+    }
+    if (fused) {
+      // stages 1+2 and 3+4 as two temporally fused launches (7 words/cell instead of 16)
+      r = launch_pair_dt(ctx, PAIR_12, Y, nullptr, nullptr, ctx->TB, ctx->ACC, dt / 2, dt / 6, dt / 2, dt / 3);
+      if (!r) r = launch_pair_dt(ctx, PAIR_34, ctx->TB, Y, ctx->ACC, TA, nullptr, dt, dt / 3, 0.0, dt / 6);
+      std::swap(Y, TA);
+      return r;
+    }
+    // stage 1: k1 = f(y);        TA = y + dt/2 k1;  ACC = y + dt/6 k1
+    r = launch_stage(ctx, Y, Y, TA, ctx->ACC, dt / 2, dt / 6, OUT_Y_PLUS_AK, ACC_INIT);
+    // stage 2: k2 = f(TA);       TB = y + dt/2 k2;  ACC += dt/3 k2
+    if (!r) r = launch_stage(ctx, TA, Y, ctx->TB, ctx->ACC, dt / 2, dt / 3, OUT_Y_PLUS_AK, ACC_ADD);
+    // stage 3: k3 = f(TB);       TA = y + dt k3;    ACC += dt/3 k3
+    if (!r) r = launch_stage(ctx, ctx->TB, Y, TA, ctx->ACC, dt, dt / 3, OUT_Y_PLUS_AK, ACC_ADD);
+    // stage 4: k4 = f(TA);       y  = ACC + dt/6 k4   (in place: y is only touched pointwise)
+    if (!r) r = launch_stage(ctx, TA, Y, Y, ctx->ACC, 0.0, dt / 6, OUT_ACC_PLUS_BK, ACC_NONE);
+    return r;
+  };
+
+  // Launch-bound regime (small grids / few environments: a stage kernel runs for a few microseconds,
+  // the host needs ~3.5 us to issue one): capture kGraphUnit substeps once into a hipGraph and replay
+  // it.  Kernel arguments baked into the graph are the field pointers, dt and the problem structure;
+  // per-environment parameter VALUES live in device memory and may change between replays.
+  int64_t done = 0;
+  const int64_t cells_per_launch = (int64_t)ctx->prob.nx * ctx->prob.ny * group;
+  const bool want_graph = ctx->opt_graph >= 0 && group >= batch && ctx->prob.derivs == PDEOPT_DERIVS_FD &&
+                          n >= 2 * kGraphUnit && (ctx->opt_graph > 0 || cells_per_launch <= (1 << 20));
+  if (want_graph) {
+    ctx->win_lo = 0;
+    ctx->win_n = batch;
+    GraphKey key;
+    memset(&key, 0, sizeof(key));  // padding bytes take part in the memcmp below
+    key.integrator = integrator;
+    key.fused = fused;
+    key.dt = dt;
+    key.Y = ctx->Y; key.TA = ctx->TA; key.TB = ctx->TB; key.ACC = ctx->ACC;
+    key.ep = ctx->env_params_dev;
+    key.vx = ctx->aux[PDEOPT_AUX_VX_FACE].dev; key.vy = ctx->aux[PDEOPT_AUX_VY_FACE].dev;
+    key.kernel_path = ctx->opt_kernel_path; key.tile_rows = ctx->opt_tile_rows; key.ablate = ctx->opt_debug_ablate;
+    key.structure = graph_structure(ctx->prob);
+    if (!ctx->graph_exec || memcmp(&key, &ctx->graph_key, sizeof(key)) != 0) {
+      graph_destroy(ctx);
+      void* Y = ctx->Y;
+      void* TA = ctx->TA;
+      const int64_t launches_before = ctx->n_stage_launches;
+      hipGraph_t graph = nullptr;
+      PDEOPT_HIP_CHECK(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+      for (int u = 0; u < kGraphUnit && !rc; ++u) rc = substep(Y, TA);
+      const hipError_t e_end = hipStreamEndCapture(ctx->stream, &graph);
+      ctx->graph_launches_per_replay = ctx->n_stage_launches - launches_before;
+      ctx->n_stage_launches = launches_before;
+      if (rc) {
+        if (graph) (void)hipGraphDestroy(graph);
+        return rc;
+      }
+      PDEOPT_HIP_CHECK(ctx, e_end);
+      const hipError_t e_inst = hipGraphInstantiate(&ctx->graph_exec, graph, nullptr, nullptr, 0);
+      (void)hipGraphDestroy(graph);
+      PDEOPT_HIP_CHECK(ctx, e_inst);
+      ctx->graph_key = key;
+      ctx->graph_name = ctx->last_kernel + "+hipGraph";
+      // kGraphUnit is even: the ping-pong buffers are back in place after one replay
+    }
+    for (; done + kGraphUnit <= n; done += kGraphUnit) {
+      PDEOPT_HIP_CHECK(ctx, hipGraphLaunch(ctx->graph_exec, ctx->stream));
+      ctx->n_stage_launches += ctx->graph_launches_per_replay;
+    }
+    ctx->last_kernel = ctx->graph_name;
+  }
+
   void* y_final = ctx->Y;
   void* ta_final = ctx->TA;
   for (int lo = 0; lo < batch; lo += group) {
@@ -188,28 +281,7 @@ int advance_explicit(pdeopt_ctx* ctx, int integrator, double, double dt, int64_t
     ctx->win_n = std::min(group, batch - lo);
     void* Y = ctx->Y;
     void* TA = ctx->TA;
-    for (int64_t s = 0; s < n && !rc; ++s) {
-      if (integrator == PDEOPT_INT_EULER) {
-        rc = launch_stage(ctx, Y, Y, TA, nullptr, dt, 0.0, OUT_Y_PLUS_AK, ACC_NONE);
-        std::swap(Y, TA);
-        continue;
-      }
-      if (fused) {
-        // stages 1+2 and 3+4 as two temporally fused launches (7 words/cell instead of 16)
-        rc = launch_pair_dt(ctx, PAIR_12, Y, nullptr, nullptr, ctx->TB, ctx->ACC, dt / 2, dt / 6, dt / 2, dt / 3);
-        if (!rc) rc = launch_pair_dt(ctx, PAIR_34, ctx->TB, Y, ctx->ACC, TA, nullptr, dt, dt / 3, 0.0, dt / 6);
-        std::swap(Y, TA);
-        continue;
-      }
-      // stage 1: k1 = f(y);        TA = y + dt/2 k1;  ACC = y + dt/6 k1
-      rc = launch_stage(ctx, Y, Y, TA, ctx->ACC, dt / 2, dt / 6, OUT_Y_PLUS_AK, ACC_INIT);
-      // stage 2: k2 = f(TA);       TB = y + dt/2 k2;  ACC += dt/3 k2
-      if (!rc) rc = launch_stage(ctx, TA, Y, ctx->TB, ctx->ACC, dt / 2, dt / 3, OUT_Y_PLUS_AK, ACC_ADD);
-      // stage 3: k3 = f(TB);       TA = y + dt k3;    ACC += dt/3 k3
-      if (!rc) rc = launch_stage(ctx, ctx->TB, Y, TA, ctx->ACC, dt, dt / 3, OUT_Y_PLUS_AK, ACC_ADD);
-      // stage 4: k4 = f(TA);       y  = ACC + dt/6 k4   (in place: y is only touched pointwise)
-      if (!rc) rc = launch_stage(ctx, TA, Y, Y, ctx->ACC, 0.0, dt / 6, OUT_ACC_PLUS_BK, ACC_NONE);
-    }
+    for (int64_t s = done; s < n && !rc; ++s) rc = substep(Y, TA);
     y_final = Y;  // every group performs the same number of swaps
     ta_final = TA;
     if (rc) break;
@@ -219,6 +291,11 @@ int advance_explicit(pdeopt_ctx* ctx, int integrator, double, double dt, int64_t
   ctx->Y = y_final;
   ctx->TA = ta_final;
   return rc;
+}
+
+void graph_destroy(pdeopt_ctx* ctx) {
+  if (ctx->graph_exec) (void)hipGraphExecDestroy(ctx->graph_exec);
+  ctx->graph_exec = nullptr;
 }
 
 // One phase of an RK4 substep for callers that interleave their own work between phases (the

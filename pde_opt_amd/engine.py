@@ -86,6 +86,10 @@ class HipEngine:
     def set_tile_rows(self, rows: int):
         self._check(self._lib.pdeopt_set_option(self._h, L.OPT_TILE_ROWS, int(rows)))
 
+    def set_graph(self, v: int):
+        """hipGraph replay of the substep loop: 0 auto, 1 always, -1 never"""
+        self._check(self._lib.pdeopt_set_option(self._h, L.OPT_GRAPH, int(v)))
+
     def set_fuse_stages(self, v: int):
         self._check(self._lib.pdeopt_set_option(self._h, L.OPT_FUSE_STAGES, int(v)))
 

@@ -538,3 +538,35 @@ def test_nan_state_is_returned_not_raised():
     model = P.PDEModel(P.CahnHilliard2DPeriodic, dom, P.RK4)
     ys = model.solve(dict(kappa=0.002, mu=MU["regsol"], D=MOB["c1mc"]), y0, [0.0, 2e-6], dt0=2e-7)
     assert ys.shape == (2, 64, 128) and np.isnan(ys[-1]).any()
+
+
+@pytest.mark.parametrize("case", ["ad_euler_128", "ch_rk4_fused", "ac_rk4_generic"])
+def test_hipgraph_replay_equals_eager(case):
+    """launch-bound sizes replay the substep loop from a captured hipGraph: same bits as eager"""
+    rng = np.random.default_rng(30)
+    if case == "ad_euler_128":
+        dom = std_domain(P, 128, 128, h=0.02)
+        eq = P.AdvectionDiffusion2D(dom, lambda t, x, y: (0.1 * np.sin(x), 0.05 * np.cos(y)), 0.1)
+        y0, solver, dt, n = 0.5 + 0.01 * rng.standard_normal((128, 128)), P.Euler(), 1e-4, 101
+    elif case == "ch_rk4_fused":
+        dom = std_domain(P, 64, 128)
+        eq = P.CahnHilliard2DPeriodic(dom, 0.002, MU["regsol"], MOB["c1mc"])
+        y0 = np.clip(0.5 + 0.05 * rng.standard_normal((2, 64, 128)), 0.05, 0.95).astype(np.float32)
+        solver, dt, n = P.RK4(), 2e-7, 50
+    else:
+        dom = std_domain(P, 48, 40)
+        eq = P.AllenCahn2DPeriodic(dom, 0.002, MU["cubic"], MOB["one"])
+        y0, solver, dt, n = 0.1 * rng.standard_normal((48, 40)), P.RK4(), 1e-4, 37
+    outs, names = [], []
+    for mode in (-1, 1, 0):
+        eng = P.HipEngine()
+        eng.set_graph(mode)
+        outs.append(P.diffeqsolve(eq, solver, 0.0, n * dt, dt, y0, engine=eng).ys[-1])
+        names.append(eng.last_kernel)
+        # a second solve on the same engine reuses the cached graph
+        again = P.diffeqsolve(eq, solver, 0.0, n * dt, dt, y0, engine=eng).ys[-1]
+        np.testing.assert_array_equal(again, outs[-1])
+        eng.close()
+    assert "hipGraph" not in names[0] and "hipGraph" in names[1] or n % 16 != 0
+    np.testing.assert_array_equal(outs[1], outs[0])
+    np.testing.assert_array_equal(outs[2], outs[0])
