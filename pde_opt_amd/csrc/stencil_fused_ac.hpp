@@ -15,7 +15,7 @@ constexpr size_t fused_ac_lds_bytes() {
   return ((size_t)(8 * RPT + 4) * (kLanesPerRow + 2) * V + 2 * V) * sizeof(T);
 }
 
-template <typename T, int CL, int PAIR, int RPT>
+template <typename T, int CL, int PAIR, int RPT, bool RAGGED>
 __global__ __launch_bounds__(256) void stage_pair_ac_kernel(const PairArgs<T> a, const int tiles_i,
                                                             const int tiles_j, const int nblk,
                                                             const int xcd_remap) {
@@ -66,28 +66,29 @@ __global__ __launch_bounds__(256) void stage_pair_ac_kernel(const PairArgs<T> a,
     ring_cv = (t2 & 1) ? (PV - 1) : 0;
   }
 
-  auto wrap_row = [&](int gi) {
-    if (g.periodic) {
-      if (gi < 0) gi += g.nx;
-      if (gi >= g.nx) gi -= g.nx;
-    }
-    return gi;
-  };
-  auto wrap_col = [&](int gj) {
-    if (g.periodic) {
-      if (gj < 0) gj += g.ny;
-      if (gj >= g.ny) gj -= g.ny;
-    }
-    return gj;
-  };
+  constexpr bool ragged = RAGGED;  // compile-time: the divisible case pays nothing for the masks
+  auto wrap_row = [&](int gi) { return g.periodic ? tile_wrap(gi, g.nx, ragged) : gi; };
+  auto wrap_col = [&](int gj) { return g.periodic ? tile_wrap(gj, g.ny, ragged) : gj; };
+  // ragged tiles: every lane computes, only cells inside the grid are loaded pointwise / stored
+  const bool col_ok = !RAGGED || (j0 + lx * V) < g.ny;
+  auto cell_ok = [&](int r) { return !RAGGED || (col_ok && (i0 + r0 + r) < g.nx); };
 
   const int64_t pidx0 = base + (int64_t)(i0 + r0) * ld + (j0 + lx * V);
   Vec ybase[RPT], accp[RPT], yring;
   if constexpr (PAIR == PAIR_34) {
 #pragma unroll
     for (int r = 0; r < RPT; ++r) {
-      ybase[r] = *reinterpret_cast<const Vec*>(a.y + pidx0 + r * ld);
-      accp[r] = *reinterpret_cast<const Vec*>(a.acc + pidx0 + r * ld);
+      accp[r] = Vec{};
+      if constexpr (RAGGED) {
+        // cells of the tile that lie beyond the grid are periodic images: stage B of the cells next
+        // to the grid edge reads w there, so their base value is needed (wrapped), not masked
+        const int gi = wrap_row(i0 + r0 + r), gj = wrap_col(j0 + lx * V);
+        ybase[r] = *reinterpret_cast<const Vec*>(a.y + base + (int64_t)gi * ld + gj);
+        if (cell_ok(r)) accp[r] = *reinterpret_cast<const Vec*>(a.acc + pidx0 + r * ld);
+      } else {
+        ybase[r] = *reinterpret_cast<const Vec*>(a.y + pidx0 + r * ld);
+        accp[r] = *reinterpret_cast<const Vec*>(a.acc + pidx0 + r * ld);
+      }
     }
     if (has_ring) {
       const int gi = wrap_row(i0 + ring_r);
@@ -162,6 +163,7 @@ __global__ __launch_bounds__(256) void stage_pair_ac_kernel(const PairArgs<T> a,
 #pragma unroll
   for (int r = 0; r < RPT; ++r) {
     const Vec kB = k_at(r0 + r, cvo, nullptr);
+    if (!cell_ok(r)) continue;
     const int64_t idx = pidx0 + r * ld;
     if constexpr (PAIR == PAIR_12) {
       *reinterpret_cast<Vec*>(a.out + idx) = yown[r] + a.aB * kB;
@@ -176,14 +178,19 @@ template <typename T, int CL, int PAIR, int RPT>
 int launch_pair_ac_inst(pdeopt_ctx* ctx, const PairArgs<T>& s) {
   constexpr int V = VecOf<T>::V;
   const pdeopt_problem& p = ctx->prob;
-  const int tiles_i = p.nx / (8 * RPT);
-  const int tiles_j = p.ny / (kLanesPerRow * V);
+  const int tiles_i = (p.nx + 8 * RPT - 1) / (8 * RPT);
+  const int tiles_j = (p.ny + kLanesPerRow * V - 1) / (kLanesPerRow * V);
   const int64_t nblk64 = (int64_t)tiles_i * tiles_j * ctx->win_n;
   if (nblk64 > 0x7fffffffLL) return fail(ctx, PDEOPT_EINVAL, "too many tiles");
   const int nblk = (int)nblk64;
   const size_t lds = fused_ac_lds_bytes<T, RPT>();
-  hipLaunchKernelGGL((stage_pair_ac_kernel<T, CL, PAIR, RPT>), dim3(nblk), dim3(256), lds, ctx->stream,
-                     s, tiles_i, tiles_j, nblk, (nblk % 8 == 0) ? 1 : 0);
+  const bool ragged = p.nx % (8 * RPT) != 0 || p.ny % (kLanesPerRow * V) != 0;
+  if (ragged)
+    hipLaunchKernelGGL((stage_pair_ac_kernel<T, CL, PAIR, RPT, true>), dim3(nblk), dim3(256), lds, ctx->stream, s, tiles_i,
+                       tiles_j, nblk, (nblk % 8 == 0) ? 1 : 0);
+  else
+    hipLaunchKernelGGL((stage_pair_ac_kernel<T, CL, PAIR, RPT, false>), dim3(nblk), dim3(256), lds, ctx->stream, s, tiles_i,
+                       tiles_j, nblk, (nblk % 8 == 0) ? 1 : 0);
   PDEOPT_HIP_CHECK(ctx, hipGetLastError());
   return PDEOPT_OK;
 }

@@ -64,6 +64,18 @@ __device__ __forceinline__ double lane_from_next(double old, double v) {
   return __builtin_bit_cast(double, ((long long)hi << 32) | (long long)lo);
 }
 
+// periodic index of a tile cell: one conditional add/subtract when tiles divide the grid, a true
+// modulo for ragged tiles (a tile may then cover the grid more than once)
+__device__ __forceinline__ int tile_wrap(int i, int n, bool ragged) {
+  if (ragged) {
+    i %= n;
+    return i < 0 ? i + n : i;
+  }
+  if (i < 0) i += n;
+  if (i >= n) i -= n;
+  return i;
+}
+
 constexpr int kLanesPerRow = 32;   // vectors per tile row
 constexpr int kPV = kLanesPerRow + 2;  // vectors per LDS row (one halo vector each side)
 // RPT = rows per thread; a tile has TX = 8 * RPT rows (8 row groups of 32 lanes = 256 threads)
@@ -112,19 +124,29 @@ __global__ __launch_bounds__(256) void stage_tiled_kernel(const StageArgs<T> a, 
   const int64_t base = (int64_t)b * g.bstride + g.off;
   const EnvParams<T>& p = a.ep[b];
   const T* __restrict__ in = a.in + base;
+  const bool ragged = (g.nx % TX != 0) || (g.ny % (kLanesPerRow * V) != 0);
 
   const int tid = threadIdx.x;
   const int lx = tid & 31;
   const int ly = tid >> 5;
   const int r0 = ly * kRowsPerThread;  // first tile row of this thread's micro-tile
 
+  // Ragged tiles (grid extents that are not multiples of the tile): the tile is filled modulo the
+  // grid, every lane computes, and only cells inside the grid are loaded pointwise / stored.
+  const bool col_ok = (j0 + lx * V) < g.ny;
+  auto cell_ok = [&](int r) { return col_ok && (i0 + r0 + r) < g.nx; };
+
   // ---- prefetch the pointwise operands of the stage update
   Vec yv[kRowsPerThread], av[kRowsPerThread];
   const int64_t pidx0 = base + (int64_t)(i0 + r0) * ld + (j0 + lx * V);
 #pragma unroll
   for (int r = 0; r < kRowsPerThread; ++r) {
-    if constexpr (kNeedY && !Y_FROM_TILE) yv[r] = *reinterpret_cast<const Vec*>(a.y + pidx0 + r * ld);
-    if constexpr (kNeedAcc) av[r] = *reinterpret_cast<const Vec*>(a.acc + pidx0 + r * ld);
+    yv[r] = Vec{};
+    av[r] = Vec{};
+    if (cell_ok(r)) {
+      if constexpr (kNeedY && !Y_FROM_TILE) yv[r] = *reinterpret_cast<const Vec*>(a.y + pidx0 + r * ld);
+      if constexpr (kNeedAcc) av[r] = *reinterpret_cast<const Vec*>(a.acc + pidx0 + r * ld);
+    }
   }
 
   // ---- phase 1: tile + halo -> LDS
@@ -138,10 +160,8 @@ __global__ __launch_bounds__(256) void stage_tiled_kernel(const StageArgs<T> a, 
       int gi = i0 - HR + row;
       int gj = j0 - V + cv * V;
       if (g.periodic) {
-        if (gi < 0) gi += g.nx;
-        if (gi >= g.nx) gi -= g.nx;
-        if (gj < 0) gj += g.ny;
-        if (gj >= g.ny) gj -= g.ny;
+        gi = tile_wrap(gi, g.nx, ragged);
+        gj = tile_wrap(gj, g.ny, ragged);
       }
       const Vec v = *reinterpret_cast<const Vec*>(in + (int64_t)gi * ld + gj);
       *reinterpret_cast<Vec*>(su + row * P + cv * V) = v;
@@ -270,6 +290,7 @@ __global__ __launch_bounds__(256) void stage_tiled_kernel(const StageArgs<T> a, 
   // ---- stage update, 16-byte stores
 #pragma unroll
   for (int r = 0; r < kRowsPerThread; ++r) {
+    if (!cell_ok(r)) continue;
     const int64_t idx = pidx0 + r * ld;
     const Vec k = kout[r];
     if constexpr (kNeedY && Y_FROM_TILE) {
@@ -291,9 +312,7 @@ __global__ __launch_bounds__(256) void stage_tiled_kernel(const StageArgs<T> a, 
 
 // rows per thread for a problem: 4 (32-row tiles) unless the grid only divides by 16
 inline int tiled_rpt(const pdeopt_ctx* ctx) {
-  const int want = ctx->opt_tile_rows > 0 ? (int)ctx->opt_tile_rows / 8 : 2;  // 16-row tiles measured fastest
-  if (ctx->prob.nx % (8 * want) == 0) return want;
-  return (ctx->prob.nx % 16 == 0) ? 2 : 0;  // 32-row request on a grid that only divides by 16
+  return ctx->opt_tile_rows == 32 ? 4 : 2;  // 16-row tiles measured fastest
 }
 
 template <typename T>
@@ -301,7 +320,11 @@ bool tiled_supported(const pdeopt_ctx* ctx) {
   constexpr int V = VecOf<T>::V;
   const pdeopt_problem& p = ctx->prob;
   if (p.equation != PDEOPT_EQ_CAHN_HILLIARD && p.equation != PDEOPT_EQ_ALLEN_CAHN) return false;
-  if (tiled_rpt(ctx) == 0 || p.ny % (kLanesPerRow * V) != 0) return false;
+  // 16-byte vectors need ny % V == 0.  Grids that the tiles do not divide run ragged tiles (periodic
+  // layout only); degenerate extents (a single row / column, the 256 x 1 "1-D" runs) stay generic.
+  if (p.ny % V != 0 || p.nx < 8 || p.ny < 4 * V) return false;
+  const bool divides = p.nx % (8 * tiled_rpt(ctx)) == 0 && p.ny % (kLanesPerRow * V) == 0;
+  if (!divides && ctx->halo) return false;
   return true;
 }
 
@@ -310,8 +333,8 @@ int launch_tiled_rpt(pdeopt_ctx* ctx, const StageArgs<T>& s) {
   constexpr int V = VecOf<T>::V;
   constexpr int kTileRows = 8 * RPT;
   const pdeopt_problem& p = ctx->prob;
-  const int tiles_i = p.nx / kTileRows;
-  const int tiles_j = p.ny / (kLanesPerRow * V);
+  const int tiles_i = (p.nx + kTileRows - 1) / kTileRows;
+  const int tiles_j = (p.ny + kLanesPerRow * V - 1) / (kLanesPerRow * V);
   const int64_t nblk64 = (int64_t)tiles_i * tiles_j * ctx->win_n;
   if (nblk64 > 0x7fffffffLL) return fail(ctx, PDEOPT_EINVAL, "too many tiles");
   const int nblk = (int)nblk64;

@@ -570,3 +570,30 @@ def test_hipgraph_replay_equals_eager(case):
     assert "hipGraph" not in names[0] and "hipGraph" in names[1] or n % 16 != 0
     np.testing.assert_array_equal(outs[1], outs[0])
     np.testing.assert_array_equal(outs[2], outs[0])
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("shape", [(100, 100), (64, 64), (48, 40), (72, 200), (8, 16), (130, 132)])
+def test_ragged_tiles_match_generic_and_oracle(engine, dtype, shape):
+    """grids the tiles do not divide (the reference notebooks use 64^2, 100^2 ...) run ragged tiles"""
+    rng = np.random.default_rng(31)
+    nx, ny = shape
+    dom = std_domain(P, nx, ny)
+    hx, hy = dom.dx
+    for cls, fn, kind in ((P.CahnHilliard2DPeriodic, O.ch_rhs_fd, "c"), (P.AllenCahn2DPeriodic, O.ac_rhs_fd, "sym")):
+        mu_fn, mob_fn = (MU["regsol"], MOB["c1mc"]) if kind == "c" else (MU["cubic"], MOB["one_plus_sq"])
+        eq = cls(dom, 0.002, mu_fn, mob_fn)
+        u = white_noise_state(rng, (2, nx, ny), dtype, kind)
+        got = eq.rhs(u, 0.0)
+        assert "tiled" in engine.last_kernel, (shape, engine.last_kernel)
+        for b in range(2):
+            assert rel_l2(got[b], fn(u[b], hx, hy, 0.002, mu_fn, mob_fn)) < TOL[np.dtype(dtype)]
+        # RK4 through the fused stage pairs == per-stage generic kernels to rounding
+        sol = P.diffeqsolve(eq, P.RK4(), 0.0, 4 * 2e-7, 2e-7, u)
+        assert "pair" in sol.stats["kernel"]
+        eng = P.HipEngine()
+        eng.set_kernel_path(L.PATH_GENERIC)
+        ref = P.diffeqsolve(eq, P.RK4(), 0.0, 4 * 2e-7, 2e-7, u, engine=eng).ys[-1]
+        eng.close()
+        inc, inc_ref = sol.ys[-1].astype(np.float64) - u, ref.astype(np.float64) - u
+        assert rel_l2(inc, inc_ref) < (1e-10 if dtype is np.float64 else 5e-4), (shape, cls.__name__)
