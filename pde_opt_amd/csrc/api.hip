@@ -50,6 +50,7 @@ void free_fields(pdeopt_ctx* ctx) {
     a = AuxField{};
   }
   spectral_destroy(ctx);
+  strang_fused_destroy(ctx);
   graph_destroy(ctx);
   ctx->tsit5_pending = false;
   ctx->tsit5_fsal_valid = false;

@@ -20,7 +20,7 @@ ROOT = os.path.dirname(PKG)
 LIB = os.path.join(PKG, "libpdeopt_hip.so")
 OBJ_DIR = os.path.join(HERE, "build")
 
-SOURCES = ["api.hip", "stencil.hip", "reduce.hip", "spectral.hip", "halo.hip"]
+SOURCES = ["api.hip", "stencil.hip", "reduce.hip", "spectral.hip", "halo.hip", "strang_fused.hip"]
 HEADERS = [
     "common.hpp",
     "closures.hpp",
@@ -28,6 +28,7 @@ HEADERS = [
     "stencil_tiled.hpp",
     "stencil_fused.hpp",
     "stencil_fused_ac.hpp",
+    "fft_lds.hpp",
     os.path.join(ROOT, "include", "pdeopt_hip.h"),
 ]
 ARCH = "gfx950"
@@ -76,7 +77,7 @@ def _compile(src: str, force: bool, extra: list[str]) -> str:
 def build(force: bool = False, verbose: bool = True, extra_flags: list[str] | None = None) -> str:
     os.makedirs(OBJ_DIR, exist_ok=True)
     extra = list(extra_flags or [])
-    with ThreadPoolExecutor(max_workers=min(4, len(SOURCES))) as ex:
+    with ThreadPoolExecutor(max_workers=min(6, len(SOURCES))) as ex:
         objs = list(ex.map(lambda s: _compile(s, force, extra), SOURCES))
     need_link = force or not os.path.exists(LIB) or any(
         os.path.getmtime(o) > os.path.getmtime(LIB) for o in objs

@@ -51,7 +51,8 @@ struct AuxField {
   size_t bytes = 0;
 };
 
-struct Spectral;  // rocFFT plans + work buffers (spectral.hip)
+struct Spectral;     // rocFFT plans + work buffers (spectral.hip)
+struct StrangFused;  // LDS-FFT split-step state (strang_fused.hip)
 
 // what a captured substep graph depends on (explicit integrators, stencil.hip)
 struct GraphStructure {
@@ -118,6 +119,7 @@ struct pdeopt_ctx {
   size_t red_cap = 0;
   double* red_mean_dev = nullptr;
   pdeopt::Spectral* spectral = nullptr;
+  pdeopt::StrangFused* strang_fused = nullptr;
 };
 
 namespace pdeopt {
@@ -171,5 +173,10 @@ int rhs_fourier(pdeopt_ctx* ctx, const void* in, void* out);
 int advance_strang(pdeopt_ctx* ctx, double t0, double dt, int64_t n);
 void spectral_destroy(pdeopt_ctx* ctx);
 void spectral_invalidate(pdeopt_ctx* ctx);
+// strang_fused.hip
+bool strang_fused_supported(const pdeopt_ctx* ctx);
+int advance_strang_fused(pdeopt_ctx* ctx, double dt, int64_t n);
+void strang_fused_invalidate(pdeopt_ctx* ctx);
+void strang_fused_destroy(pdeopt_ctx* ctx);
 
 }  // namespace pdeopt

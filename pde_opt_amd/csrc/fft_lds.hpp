@@ -1,0 +1,187 @@
+// Power-of-two FFTs of length N held entirely in LDS (gfx950), radix 8 with a radix-4/2 tail.
+//
+// Why not rocFFT for the split-step: a Strang step is   ifft2(fft2(psi) E) -> pointwise -> ifft2(fft2(.) E)
+// (pde_opt/numerics/solvers.py:99-122).  With a library FFT every arrow is a pass over HBM (and the
+// strided column pass of rocFFT's 2-D plan runs at ~2 TB/s).  With the transform in LDS the
+// pointwise operators fuse INTO the passes:  a column pass does FFT_x -> *E -> IFFT_x without leaving
+// the CU, a row pass does IFFT_y -> *exp(b tau) (+ norm partial sums) -> FFT_y, so a whole step is
+// 4 passes of 16 B/cell instead of 8 library passes + 4 pointwise kernels.
+//
+// Two in-place transforms over F sequences stored as s[f * NP + fft_lds_addr(pos)]:
+//   dif<SIGN>: natural order in  -> position p holds X[rev(p)]       (decimation in frequency)
+//   dit<SIGN>: position p holds x[rev(p)] on entry -> natural order out (decimation in time)
+// rev() is the mixed-radix digit reversal of the radix list (8, 8, ..., tail); pos_of() its inverse.
+// A pointwise spectral multiply between dif and dit therefore needs no reordering, and the global
+// side of every pass stays in natural order (coalesced) -- only LDS addresses are permuted.
+// Index algebra checked against numpy.fft in /tmp-style prototype (see tests/test_gpu_fft.py).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+namespace pdeopt {
+
+template <typename T>
+struct Cx {
+  T re, im;
+};
+
+template <typename T>
+__device__ __forceinline__ Cx<T> cadd(Cx<T> a, Cx<T> b) { return {a.re + b.re, a.im + b.im}; }
+template <typename T>
+__device__ __forceinline__ Cx<T> csub(Cx<T> a, Cx<T> b) { return {a.re - b.re, a.im - b.im}; }
+template <typename T>
+__device__ __forceinline__ Cx<T> cmul(Cx<T> a, Cx<T> b) {
+  return {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re};
+}
+// multiply by  SIGN * i
+template <typename T, int SIGN>
+__device__ __forceinline__ Cx<T> mul_si(Cx<T> a) {
+  return SIGN > 0 ? Cx<T>{-a.im, a.re} : Cx<T>{a.im, -a.re};
+}
+
+// ---- small DFTs in registers:  y_q = sum_m v_m exp(SIGN 2 pi i q m / R)
+template <typename T, int SIGN>
+__device__ __forceinline__ void dft2(Cx<T>* v) {
+  const Cx<T> a = v[0], b = v[1];
+  v[0] = cadd(a, b);
+  v[1] = csub(a, b);
+}
+template <typename T, int SIGN>
+__device__ __forceinline__ void dft4(Cx<T>& a0, Cx<T>& a1, Cx<T>& a2, Cx<T>& a3) {
+  const Cx<T> t0 = cadd(a0, a2), t1 = csub(a0, a2), t2 = cadd(a1, a3), t3 = mul_si<T, SIGN>(csub(a1, a3));
+  a0 = cadd(t0, t2);
+  a2 = csub(t0, t2);
+  a1 = cadd(t1, t3);
+  a3 = csub(t1, t3);
+}
+template <typename T, int SIGN>
+__device__ __forceinline__ void dft8(Cx<T>* v) {
+  // even / odd DFT4, then the radix-2 combine with w8^q
+  Cx<T> e0 = v[0], e1 = v[2], e2 = v[4], e3 = v[6];
+  Cx<T> o0 = v[1], o1 = v[3], o2 = v[5], o3 = v[7];
+  dft4<T, SIGN>(e0, e1, e2, e3);
+  dft4<T, SIGN>(o0, o1, o2, o3);
+  const T h = T(0.70710678118654752440);
+  // o1 *= (1 + s i)/sqrt2 ; o2 *= s i ; o3 *= (-1 + s i)/sqrt2
+  const Cx<T> si1 = mul_si<T, SIGN>(o1), si3 = mul_si<T, SIGN>(o3);
+  o1 = {(o1.re + si1.re) * h, (o1.im + si1.im) * h};
+  o2 = mul_si<T, SIGN>(o2);
+  o3 = {(si3.re - o3.re) * h, (si3.im - o3.im) * h};
+  v[0] = cadd(e0, o0); v[4] = csub(e0, o0);
+  v[1] = cadd(e1, o1); v[5] = csub(e1, o1);
+  v[2] = cadd(e2, o2); v[6] = csub(e2, o2);
+  v[3] = cadd(e3, o3); v[7] = csub(e3, o3);
+}
+template <typename T, int R, int SIGN>
+__device__ __forceinline__ void dft_small(Cx<T>* v) {
+  if constexpr (R == 8) dft8<T, SIGN>(v);
+  if constexpr (R == 4) dft4<T, SIGN>(v[0], v[1], v[2], v[3]);
+  if constexpr (R == 2) dft2<T, SIGN>(v);
+}
+
+// ---- radix plan of a power of two: as many 8s as fit, then a tail of 4 or 2
+template <int N>
+struct FftPlan {
+  static constexpr int log2n() { int l = 0, n = N; while (n > 1) { n >>= 1; ++l; } return l; }
+  static constexpr int n8 = log2n() / 3;
+  static constexpr int tail = 1 << (log2n() % 3);          // 1, 2 or 4
+  static constexpr int stages = n8 + (tail > 1 ? 1 : 0);
+  static constexpr int radix(int i) { return i < n8 ? 8 : tail; }
+  // sub-length entering stage i (stage 0 sees N)
+  static constexpr int sublen(int i) { int ns = N; for (int k = 0; k < i; ++k) ns /= radix(k); return ns; }
+};
+
+// position p (after dif)  ->  frequency index k
+template <int N>
+__device__ __forceinline__ int fft_rev(int p) {
+  using P = FftPlan<N>;
+  int k = 0, w = 1;
+#pragma unroll
+  for (int i = 0; i < P::stages; ++i) {
+    const int R = P::radix(i), S = P::sublen(i) / R;
+    k += ((p / S) % R) * w;
+    w *= R;
+  }
+  return k;
+}
+// frequency / natural index k  ->  position p whose content dit() expects / dif() produces
+template <int N>
+__device__ __forceinline__ int fft_pos_of(int k) {
+  using P = FftPlan<N>;
+  int p = 0, w = 1;
+#pragma unroll
+  for (int i = 0; i < P::stages; ++i) {
+    const int R = P::radix(i), S = P::sublen(i) / R;
+    p += ((k / w) % R) * S;
+    w *= R;
+  }
+  return p;
+}
+
+// LDS address of sequence position `pos`: one pad element per 8.  A stage with lane stride 8 (or 64)
+// would otherwise put 8 (16) lanes of a half-wave on the same ds_read_b64 bank slot; with the pad
+// the stride becomes 9 (72) slots, which walks all 32 slots before repeating (conflict-free).
+__device__ __forceinline__ constexpr int fft_lds_addr(int pos) { return pos + (pos >> 3); }
+// padded length of one sequence (+1 so that consecutive sequences start one slot apart: the column
+// pass loads/stores with the sequence index fastest across lanes)
+template <int N>
+constexpr int fft_lds_pitch() { return N + N / 8 + 1; }
+
+// twiddle exp(SIGN 2 pi i n / N) from the table tw[n] = exp(-2 pi i n / N)
+template <typename T, int SIGN>
+__device__ __forceinline__ Cx<T> twiddle(const Cx<T>* __restrict__ tw, int n) {
+  const Cx<T> w = tw[n];
+  return SIGN < 0 ? w : Cx<T>{w.re, -w.im};
+}
+
+template <typename T, int N, int F, int NP, int SIGN, int STAGE, int R, bool DIT>
+__device__ __forceinline__ void fft_stage(Cx<T>* __restrict__ s, const Cx<T>* __restrict__ tw, int tid) {
+  constexpr int Ns = FftPlan<N>::sublen(STAGE);
+  constexpr int S = Ns / R;
+  constexpr int per_fft = N / R;
+  constexpr int total = F * per_fft;
+#pragma unroll 1
+  for (int id = tid; id < total; id += (int)blockDim.x) {
+    const int f = id / per_fft, j = id - f * per_fft;
+    const int blk = j / S, jj = j - blk * S;
+    Cx<T>* seq = s + f * NP;
+    const int p0 = blk * Ns + jj;
+    Cx<T> v[R];
+#pragma unroll
+    for (int m = 0; m < R; ++m) v[m] = seq[fft_lds_addr(p0 + m * S)];
+    if constexpr (DIT && S > 1) {
+#pragma unroll
+      for (int q = 1; q < R; ++q) v[q] = cmul(v[q], twiddle<T, SIGN>(tw, jj * q * (N / Ns)));
+    }
+    dft_small<T, R, SIGN>(v);
+    if constexpr (!DIT && S > 1) {
+#pragma unroll
+      for (int q = 1; q < R; ++q) v[q] = cmul(v[q], twiddle<T, SIGN>(tw, jj * q * (N / Ns)));
+    }
+#pragma unroll
+    for (int m = 0; m < R; ++m) seq[fft_lds_addr(p0 + m * S)] = v[m];
+  }
+  __syncthreads();
+}
+
+template <typename T, int N, int F, int NP, int SIGN, bool DIT, int I>
+__device__ __forceinline__ void fft_run(Cx<T>* s, const Cx<T>* tw, int tid) {
+  using P = FftPlan<N>;
+  if constexpr (I < P::stages) {
+    constexpr int STAGE = DIT ? (P::stages - 1 - I) : I;
+    fft_stage<T, N, F, NP, SIGN, STAGE, P::radix(STAGE), DIT>(s, tw, tid);
+    fft_run<T, N, F, NP, SIGN, DIT, I + 1>(s, tw, tid);
+  }
+}
+
+// in-place transforms of F sequences (barrier after every stage; call with data already visible)
+template <typename T, int N, int F, int NP, int SIGN>
+__device__ __forceinline__ void fft_dif(Cx<T>* s, const Cx<T>* tw, int tid) {
+  fft_run<T, N, F, NP, SIGN, false, 0>(s, tw, tid);
+}
+template <typename T, int N, int F, int NP, int SIGN>
+__device__ __forceinline__ void fft_dit(Cx<T>* s, const Cx<T>* tw, int tid) {
+  fft_run<T, N, F, NP, SIGN, true, 0>(s, tw, tid);
+}
+
+}  // namespace pdeopt

@@ -559,6 +559,7 @@ int advance_imex(pdeopt_ctx* ctx, double, double dt, int64_t n) {
 int advance_strang(pdeopt_ctx* ctx, double, double dt, int64_t n) {
   if (!ctx->aux[PDEOPT_AUX_GPE_A_TERM].dev)
     return fail(ctx, PDEOPT_ESTATE, "Strang splitting needs the GPE_A_TERM aux field");
+  if (strang_fused_supported(ctx)) return advance_strang_fused(ctx, dt, n);  // LDS FFTs, fused passes
   int rc = ensure_plans(ctx);
   if (rc) return rc;
   return ctx->prob.dtype == PDEOPT_F32 ? strang_t<float>(ctx, dt, n) : strang_t<double>(ctx, dt, n);
@@ -566,6 +567,7 @@ int advance_strang(pdeopt_ctx* ctx, double, double dt, int64_t n) {
 
 void spectral_invalidate(pdeopt_ctx* ctx) {
   if (ctx->spectral) ctx->spectral->mult_kind = -1;
+  strang_fused_invalidate(ctx);
 }
 
 void spectral_destroy(pdeopt_ctx* ctx) {

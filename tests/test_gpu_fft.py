@@ -1,0 +1,73 @@
+"""The fused split-step (FFTs in LDS, csrc/strang_fused.hip + fft_lds.hpp) against the oracle and
+against the rocFFT pipeline it replaces for power-of-two grids."""
+import numpy as np
+import pytest
+
+import pde_opt_amd as P
+from oracle import np_oracle as O
+from pde_opt_amd import _lib as L
+from util import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(nx, ny, kinetic=True):
+    dom = P.Domain((nx, ny), ((-12.0, 12.0), (-9.0, 9.0)), "dimensionless")
+    eq = P.GPE2DTSControl(dom, 500.0, 0.2, lambda t, x, y: 0.05 * x - 0.02 * y, trap_factor=1.0, kinetic=kinetic)
+    X, Y = dom.mesh()
+    psi = np.exp(-(X**2 / 18.0 + Y**2 / 10.0)) * np.exp(0.3j * X - 0.2j * Y)
+    psi /= np.sqrt(np.sum(np.abs(psi) ** 2) * dom.dx[0] ** 2)
+    return dom, eq, np.stack([psi.real, psi.imag], axis=-1), (X, Y)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("shape", [(64, 64), (128, 64), (64, 256), (512, 128)])
+@pytest.mark.parametrize("tscale", [1.0, -1j])
+def test_fused_strang_vs_oracle(dtype, shape, tscale):
+    nx, ny = shape
+    dom, eq, y0, (X, Y) = _setup(nx, ny)
+    solver = P.StrangSplitting(eq.A_term, eq.dx, eq.fft, eq.ifft, tscale)
+    n, dt = 4, 1e-3
+    eng = P.HipEngine()
+    sol = P.diffeqsolve(eq, solver, 0.0, n * dt, dt, y0.astype(dtype), engine=eng)
+    assert eng.last_kernel == "strang_fused_lds_fft", eng.last_kernel
+    eng.close()
+    lights = 0.05 * X - 0.02 * Y
+    b = lambda t, yy: O.gpe_b_terms(yy, X, Y, 500.0, 0.2, 1.0, lights)
+    ref = y0
+    for i in range(n):
+        ref = O.strang_step(b, i * dt, ref, dt, eq.A_term, eq.dx, tscale)
+    tol = 1e-11 if dtype is np.float64 else 2e-5
+    assert rel_l2(sol.ys[-1], ref) < tol, rel_l2(sol.ys[-1], ref)
+
+
+def test_fused_equals_rocfft_pipeline_and_batch():
+    dom, eq, y0, _ = _setup(128, 128)
+    solver = P.StrangSplitting(eq.A_term, eq.dx, eq.fft, eq.ifft, 1.0)
+    yb = np.stack([y0, 0.5 * y0, y0[::-1].copy()])
+    outs = {}
+    for path in (L.PATH_AUTO, L.PATH_GENERIC):
+        eng = P.HipEngine()
+        eng.set_kernel_path(path)
+        outs[path] = P.diffeqsolve(eq, solver, 0.0, 5e-3, 1e-3, yb, engine=eng).ys[-1]
+        name = eng.last_kernel
+        eng.close()
+        assert ("lds_fft" in name) == (path == L.PATH_AUTO), name
+    assert rel_l2(outs[L.PATH_AUTO], outs[L.PATH_GENERIC]) < 1e-12
+    # every environment is renormalised separately
+    dens = outs[L.PATH_AUTO][..., 0] ** 2 + outs[L.PATH_AUTO][..., 1] ** 2
+    np.testing.assert_allclose(dens.sum(axis=(1, 2)) * dom.dx[0] ** 2, 1.0, rtol=1e-12)
+
+
+def test_fused_zero_A_term_matches_committed_reference_behaviour():
+    """the committed reference multiplies A_term by 0 (gross_pitaevskii.py:62): identity kinetic step"""
+    dom, eq, y0, (X, Y) = _setup(64, 64, kinetic=False)
+    assert np.abs(eq.A_term).max() == 0.0
+    solver = P.StrangSplitting(eq.A_term, eq.dx, eq.fft, eq.ifft, -1j)
+    sol = P.diffeqsolve(eq, solver, 0.0, 3e-3, 1e-3, y0)
+    lights = 0.05 * X - 0.02 * Y
+    b = lambda t, yy: O.gpe_b_terms(yy, X, Y, 500.0, 0.2, 1.0, lights)
+    ref = y0
+    for i in range(3):
+        ref = O.strang_step(b, i * 1e-3, ref, 1e-3, eq.A_term, eq.dx, -1j)
+    assert rel_l2(sol.ys[-1], ref) < 1e-12
