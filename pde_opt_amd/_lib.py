@@ -34,6 +34,7 @@ OPT_DEBUG_ABLATE = 3
 OPT_FUSE_STAGES = 4
 OPT_HALO_LAYOUT = 5
 OPT_GRAPH = 6
+OPT_IMEX_LDS_FFT = 7
 CNT_STAGE_LAUNCHES = 0
 COPY_H2D, COPY_D2H, COPY_D2D = 0, 1, 2
 FIELD_Y, FIELD_TA, FIELD_TB, FIELD_ACC = 0, 1, 2, 3

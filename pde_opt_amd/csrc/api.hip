@@ -188,6 +188,9 @@ int pdeopt_set_option(pdeopt_ctx* ctx, int option, int64_t value) {
         return fail(ctx, PDEOPT_EINVAL, "tile rows must be 0 (auto), 16 or 32");
       ctx->opt_tile_rows = value;
       return PDEOPT_OK;
+    case PDEOPT_OPT_IMEX_LDS_FFT:
+      ctx->opt_imex_lds_fft = value;
+      return PDEOPT_OK;
     case PDEOPT_OPT_GRAPH:
       if (value < -1 || value > 1) return fail(ctx, PDEOPT_EINVAL, "graph option must be -1, 0 or 1");
       ctx->opt_graph = value;

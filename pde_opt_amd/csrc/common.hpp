@@ -106,6 +106,7 @@ struct pdeopt_ctx {
   int halo = 0;                  // halo width of the configured layout
   void* halo_scratch = nullptr;  // single-rank loop-back buffer for pack/unpack
   size_t halo_scratch_bytes = 0;
+  int64_t opt_imex_lds_fft = 0;  // 1: IMEX through the LDS FFT passes (slower than rocFFT R2C; kept for study)
   int64_t opt_graph = 0;         // hipGraph replay of the substep loop: 0 auto (launch-bound sizes), 1 always, -1 never
   hipGraphExec_t graph_exec = nullptr;
   pdeopt::GraphKey graph_key{};
@@ -176,6 +177,8 @@ void spectral_invalidate(pdeopt_ctx* ctx);
 // strang_fused.hip
 bool strang_fused_supported(const pdeopt_ctx* ctx);
 int advance_strang_fused(pdeopt_ctx* ctx, double dt, int64_t n);
+bool imex_fused_supported(const pdeopt_ctx* ctx);
+int advance_imex_fused(pdeopt_ctx* ctx, double dt, int64_t n);
 void strang_fused_invalidate(pdeopt_ctx* ctx);
 void strang_fused_destroy(pdeopt_ctx* ctx);
 

@@ -71,3 +71,38 @@ def test_fused_zero_A_term_matches_committed_reference_behaviour():
     for i in range(3):
         ref = O.strang_step(b, i * 1e-3, ref, 1e-3, eq.A_term, eq.dx, -1j)
     assert rel_l2(sol.ys[-1], ref) < 1e-12
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("shape", [(64, 64), (128, 256)])
+def test_fused_imex_vs_oracle_and_rocfft(dtype, shape):
+    from util import MOB, MU, std_domain
+
+    rng = np.random.default_rng(40)
+    nx, ny = shape
+    dom = std_domain(P, nx, ny)
+    eq = P.CahnHilliard2DPeriodic(dom, 0.002, MU["regsol"], MOB["c1mc"])
+    solver = P.SemiImplicitFourierSpectral(0.5, eq.fourier_symbol, eq.fft, eq.ifft)
+    y0 = np.clip(0.5 + 0.01 * rng.standard_normal((2, nx, ny)), 0.05, 0.95).astype(dtype)
+    n, dt = 6, 1e-6
+    outs = {}
+    for path in (L.PATH_AUTO, L.PATH_GENERIC):
+        eng = P.HipEngine()
+        if path == L.PATH_AUTO:  # the LDS-FFT IMEX is opt-in (rocFFT R2C is faster)
+            eng._check(eng._lib.pdeopt_set_option(eng._h, L.OPT_IMEX_LDS_FFT, 1))
+        else:
+            eng.set_kernel_path(path)
+        outs[path] = P.diffeqsolve(eq, solver, 0.0, n * dt, dt, y0, engine=eng).ys[-1]
+        assert ("imex_fused_lds_fft" in eng.last_kernel) == (path == L.PATH_AUTO), eng.last_kernel
+        eng.close()
+    hx, hy = dom.dx
+    sym = O.ch_fourier_symbol(nx, ny, hx, hy, 0.002)
+    rhs = lambda t, u: O.ch_rhs_fd(u, hx, hy, 0.002, MU["regsol"], MOB["c1mc"])
+    for b in range(2):
+        ref = y0[b].astype(np.float64)
+        for i in range(n):
+            ref = O.imex_step(rhs, i * dt, ref, dt, 0.5, sym)
+        inc_ref = ref - y0[b].astype(np.float64)
+        tol = 1e-9 if dtype is np.float64 else 5e-4
+        assert rel_l2(outs[L.PATH_AUTO][b].astype(np.float64) - y0[b], inc_ref) < tol
+        assert rel_l2(outs[L.PATH_GENERIC][b].astype(np.float64) - y0[b], inc_ref) < tol
