@@ -43,7 +43,8 @@ struct PairArgs {
   T* acc_out;     // PAIR_12: ACC (write)
   T aA, bA;       // w = base + aA kA ;  accp = (y | acc) + bA kA
   T aB, bB;       // PAIR_12: out = y + aB kB, acc_out = accp + bB kB ;  PAIR_34: out = accp + bB kB
-  T rhx, rhy, rhx2, rhy2;
+  T rhx, rhy;    // 0.5 / hx^2, 0.5 / hy^2 (folded flux constants, see face_flux)
+  T rhx2, rhy2;  // 1 / hx^2, 1 / hy^2 (Laplacian)
   Geo g;
   const EnvParams<T>* ep;
   ClosureSpec mu, mob;
@@ -53,9 +54,14 @@ struct PairArgs {
 // avg_face(D) * grad_face(mu)  (derivatives.py:24-31,39-46; cahn_hilliard.py:105-106).  Every face
 // value in this file goes through this one expression so that a face shared by two rows, two
 // threads or two workgroups evaluates to the same bits.
+//
+// The constants are folded: flux = (D_a + D_b)(mu_b - mu_a) here, and the 1/2 of the face average and
+// the 1/h of the face gradient join the 1/h of the divergence in ONE factor 0.5/h^2 per axis
+// (PairArgs::rhx / rhy), applied to the difference of two face values: 2 multiplies per face less
+// than the literal form, ~5 % of this VALU-bound kernel.
 template <typename T>
-__device__ __forceinline__ T face_flux(T d_a, T d_b, T m_a, T m_b, T rh) {
-  return (T(0.5) * (d_a + d_b)) * ((m_b - m_a) * rh);
+__device__ __forceinline__ T face_flux(T d_a, T d_b, T m_a, T m_b, T /*unused*/) {
+  return (d_a + d_b) * (m_b - m_a);
 }
 
 // y-divergence of the face fluxes of one vector of cells (needs the scalar neighbours left / right)
@@ -421,7 +427,7 @@ int launch_pair(pdeopt_ctx* ctx, int pair, const void* in, const void* y, const 
   s.out = static_cast<T*>(out) + woff;
   s.acc_out = acc_out ? static_cast<T*>(acc_out) + woff : nullptr;
   s.aA = T(aA); s.bA = T(bA); s.aB = T(aB); s.bB = T(bB);
-  s.rhx = T(1.0 / p.hx); s.rhy = T(1.0 / p.hy);
+  s.rhx = T(0.5 / (p.hx * p.hx)); s.rhy = T(0.5 / (p.hy * p.hy));
   s.rhx2 = T(1.0 / (p.hx * p.hx)); s.rhy2 = T(1.0 / (p.hy * p.hy));
   s.ep = static_cast<const EnvParams<T>*>(ctx->env_params_dev) + ctx->win_lo;
   s.mu = ClosureSpec{p.mu.kind, p.mu.flags, p.mu.n};
