@@ -52,7 +52,10 @@ typedef enum {
   PDEOPT_EQ_CAHN_HILLIARD = 0,   /* cahn_hilliard.py:89-109  div(D(u) grad(mu_h(u) - kappa lap u)) */
   PDEOPT_EQ_ALLEN_CAHN = 1,      /* allen_cahn.py:81-84      -R(u) (mu_h(u) - kappa lap u)          */
   PDEOPT_EQ_ADVECTION_DIFFUSION = 2, /* not in the reference package: -div(v u) + D lap u */
-  PDEOPT_EQ_GPE = 3              /* gross_pitaevskii.py:67-75 (Strang only)                         */
+  PDEOPT_EQ_GPE = 3,             /* gross_pitaevskii.py:67-75 (Strang only)                         */
+  /* smoothed-boundary variants: psi = domain.geometry.smooth is an aux field */
+  PDEOPT_EQ_ALLEN_CAHN_SBM = 4,     /* allen_cahn.py:88-159    -R (mu_h - kappa/psi div(psi grad u) - wall sqrt(2 f)) */
+  PDEOPT_EQ_CAHN_HILLIARD_SBM = 5   /* cahn_hilliard.py:204-289 div(psi D grad(inner))/psi + source                  */
 } pdeopt_equation;
 
 /* which solver.step() is fused around it */
@@ -68,11 +71,14 @@ typedef enum {
  * (dataclass fields cahn_hilliard.py:51-54, allen_cahn.py:47-50; catalogue: SURVEY Appendix D).
  *     s(c)  = sum_k coef[k] * c^k                      (kind POLY)
  *           = sum_k coef[k] * P_k(2c - 1)              (kind LEGENDRE, legendre.py:23-34,50,70)
- *     f(c)  = s(c) [+ log(c / (1 - c)) if LOGIT_PRIOR]   then  exp(.) if EXP_WRAP            */
+ *     f(c)  = s(c) [+ log(c / (1 - c)) if LOGIT_PRIOR] [+ c log c + (1-c) log(1-c) if MIX_ENTROPY]
+ *             then  exp(.) if EXP_WRAP                                                        */
 #define PDEOPT_CLOSURE_MAX_COEF 16
 typedef enum { PDEOPT_CL_POLY = 0, PDEOPT_CL_LEGENDRE = 1 } pdeopt_closure_kind;
 #define PDEOPT_CL_LOGIT_PRIOR 1
 #define PDEOPT_CL_EXP_WRAP 2
+#define PDEOPT_CL_MIX_ENTROPY 4  /* + c log c + (1 - c) log(1 - c): ideal mixing entropy of the regular-
+                                    solution free energy f(c) (notebooks/smooth_boundary.ipynb)          */
 
 typedef struct {
   int32_t kind;   /* pdeopt_closure_kind */
@@ -99,6 +105,7 @@ typedef struct {
   pdeopt_closure mob; /* D (CH) or R (AC) */
   /* GPE (gross_pitaevskii.py:35-44): b = -i (V + k |psi|^2); V is an auxiliary field */
   double gpe_k;
+  pdeopt_closure fe;  /* free-energy density f(u) of the smoothed-boundary equations (allen_cahn.py:112) */
 } pdeopt_problem;
 
 /* auxiliary read-only fields (pdeopt_set_aux) */
@@ -107,8 +114,21 @@ typedef enum {
   PDEOPT_AUX_VY_FACE = 1,    /* AD: y velocity on faces (i, j+1/2), real [nx][ny]                    */
   PDEOPT_AUX_IMEX_SYMBOL = 2,/* IMEX: fourier_symbol, complex [nx][ny] (cahn_hilliard.py:74)         */
   PDEOPT_AUX_GPE_A_TERM = 3, /* Strang: A_term, complex [nx][ny] (gross_pitaevskii.py:62)            */
-  PDEOPT_AUX_GPE_POTENTIAL = 4 /* Strang: V = 1/2 tf((1+e)X^2+(1-e)Y^2) + lights(t,X,Y), real [nx][ny] */
+  PDEOPT_AUX_GPE_POTENTIAL = 4,/* Strang: V = 1/2 tf((1+e)X^2+(1-e)Y^2) + lights(t,X,Y), real [nx][ny] */
+  PDEOPT_AUX_SBM_PSI = 5,      /* SBM: level-set field psi = domain.geometry.smooth, real [nx][ny]            */
+  PDEOPT_AUX_SBM_NORM_GRAD = 6,/* SBM: norm_grad_psi = |grad_c psi| / psi, real [nx][ny] (allen_cahn.py:128-133) */
+  PDEOPT_AUX_SBM_MASK = 7      /* SBM: left_half, the 0/1 field selecting which wall carries cos(theta)
+                                  (allen_cahn.py:134-135, cahn_hilliard.py:253-254), real [nx][ny]            */
 } pdeopt_aux;
+
+/* Time-dependent scalars of the smoothed-boundary equations, evaluated by the host at every RHS
+ * evaluation time t (each Runge-Kutta stage has its own):
+ *   out[0] = cos(theta(t))                       weight of the wall term where MASK = 1
+ *   out[1] = cos(pi - theta(t)) (CH) or 0 (AC)   weight of the wall term where MASK = 0
+ *   out[2] = flux(t)  (CH; 0 for AC)             normal boundary flux J_n
+ * (allen_cahn.py:150-154, cahn_hilliard.py:269-275,289).  The kernel forms
+ *   wall = sqrt(kappa) NORM_GRAD (out[0] MASK + out[1] (1 - MASK)),  source = NORM_GRAD out[2]. */
+typedef void (*pdeopt_time_fn)(double t, double out[3], void* user);
 
 typedef enum {
   PDEOPT_RED_MEAN = 0,
@@ -171,6 +191,9 @@ int pdeopt_rhs(pdeopt_ctx* ctx, double t, void* host_out);
 /* n_substeps of size dt starting at local time t0:  the body of diffeqsolve's while-loop
  * under ConstantStepSize.  Asynchronous. */
 int pdeopt_advance(pdeopt_ctx* ctx, int integrator, double t0, double dt, int64_t n_substeps);
+/* Smoothed-boundary equations: fn is called on the calling thread, once per RHS evaluation, from
+ * inside pdeopt_rhs / pdeopt_advance / pdeopt_tsit5_trial; fn == NULL uses constant[3] instead.  */
+int pdeopt_set_time_terms(pdeopt_ctx* ctx, pdeopt_time_fn fn, void* user, const double constant[3]);
 /* integrator parameters: IMEX A (solvers.py:43); Strang time_scale re/im and dx (solvers.py:86-89) */
 int pdeopt_set_integrator_params(pdeopt_ctx* ctx, double imex_A, double time_scale_re,
                                  double time_scale_im, double strang_dx);

@@ -105,6 +105,49 @@ def load_reference():
     return ns
 
 
+class _AtSetter:
+    def __init__(self, arr, idx):
+        self._arr, self._idx = arr, idx
+
+    def set(self, v):
+        out = self._arr.copy()
+        np.ndarray.__setitem__(out, self._idx, v)
+        return out
+
+
+class _At:
+    def __init__(self, arr):
+        self._arr = arr
+
+    def __getitem__(self, idx):
+        return _AtSetter(self._arr, idx)
+
+
+class JaxLikeArray(np.ndarray):
+    """numpy array with jax's functional-update spelling ``a.at[idx].set(v)`` -- the one piece of
+    jax.Array API the smoothed-boundary equations use on their inputs (allen_cahn.py:135)."""
+
+    @property
+    def at(self):
+        return _At(self)
+
+
+def sbm_geometry(nx, ny, hx, hy, floor=0.05):
+    """A smooth level-set field in (floor, 1]: a disc of radius 0.3 min(Lx, Ly), tanh profile."""
+    x = (np.arange(nx) + 0.5) * hx
+    y = (np.arange(ny) + 0.5) * hy
+    X, Y = np.meshgrid(x, y, indexing="ij")
+    r = np.sqrt((X - 0.5 * nx * hx) ** 2 + (Y - 0.5 * ny * hy) ** 2)
+    eps = 2.5 * max(hx, hy)
+    psi = 0.5 * (1.0 + np.tanh((0.3 * min(nx * hx, ny * hy) - r) / eps))
+    return floor + (1.0 - floor) * psi
+
+
+SBM_F = lambda c: c * np.log(c) + (1.0 - c) * np.log(1.0 - c) + 3.0 * c * (1.0 - c) + 0.059  # noqa: E731
+SBM_THETA = lambda t: 34.9065850398866 * t**2 - 10.4719755119660 * t + np.pi / 2  # noqa: E731
+SBM_FLUX = lambda t: 0.02 * (1.0 + 3.0 * t)  # noqa: E731
+
+
 class _Terms:
     def __init__(self, vf):
         self._vf = vf
@@ -280,6 +323,30 @@ def main():
     traj["strang/b_terms"] = np.asarray(geq.B_terms(y0, 0.0))
     traj["strang/A_real"] = a_real
     np.savez_compressed(os.path.join(OUT, "trajectories.npz"), **traj)
+    # ---- smoothed-boundary equations -----------------------------
+    # notebooks/smooth_boundary.ipynb closures; theta(t) is that notebook's quadratic ramp.
+    sbm = {}
+    for kind, (nx, ny) in (("ac", (64, 128)), ("ch", (96, 64)), ("ac", (40, 100)), ("ch", (50, 24))):
+        for dtype in (np.float64, np.float32):
+            dom0 = Domain((nx, ny), ((0.0, 1.0 * nx), (0.0, 1.0 * ny)), "dimensionless")
+            psi = sbm_geometry(nx, ny, *dom0.dx).astype(dtype).view(JaxLikeArray)
+            dom = Domain((nx, ny), dom0.box, "dimensionless", geometry=types.SimpleNamespace(smooth=psi))
+            u = np.clip(0.5 + 0.2 * rng.standard_normal((nx, ny)), 0.05, 0.95).astype(dtype)
+            kappa = 1.5
+            tag = f"{kind}/{nx}x{ny}_{np.dtype(dtype).name}"
+            if kind == "ac":
+                eq = ref.ac.AllenCahn2DSmoothedBoundary(dom, kappa, SBM_F, MU["regsol"], MOB["c1mc"], SBM_THETA)
+            else:
+                eq = ref.ch.CahnHilliard2DSmoothedBoundary(dom, kappa, SBM_F, MU["regsol"], MOB["c1mc"],
+                                                           SBM_THETA, SBM_FLUX)
+            sbm[f"{tag}/psi"] = np.asarray(psi)
+            sbm[f"{tag}/u"] = u
+            for t in (0.0, 0.17):
+                sbm[f"{tag}/rhs_t{t}"] = np.asarray(eq.rhs(u, t))
+            sbm[f"{tag}/norm_grad_psi"] = np.asarray(eq.norm_grad_psi)
+            sbm[f"{tag}/left_half"] = np.asarray(eq.left_half)
+    np.savez_compressed(os.path.join(OUT, "sbm_cases.npz"), **sbm)
+
     print("wrote goldens to", os.path.abspath(OUT))
     for f in sorted(os.listdir(OUT)):
         print("  ", f, os.path.getsize(os.path.join(OUT, f)))

@@ -99,6 +99,42 @@ def ac_rhs_fd(u, hx, hy, kappa, mu_h, R):
     return -R(u) * chem_potential(u, hx, hy, kappa, mu_h)
 
 
+def sbm_norm_grad(psi, hx, hy):
+    """|grad_c psi| / psi with periodic centred differences, allen_cahn.py:128-133."""
+    gx = 0.5 * (nb(psi, 1, 0) - nb(psi, -1, 0)) / hx
+    gy = 0.5 * (nb(psi, 1, 1) - nb(psi, -1, 1)) / hy
+    return np.sqrt(gx**2 + gy**2) / psi
+
+
+def sbm_inner(u, psi, hx, hy, kappa, f, mu_h, wall_weight):
+    """mu_h(u) - kappa/psi div(psi grad u) - sqrt(kappa) |grad psi|/psi sqrt(2 f(u)) w,
+    allen_cahn.py:139-155 / cahn_hilliard.py:257-276.  ``wall_weight`` is the field
+    cos(theta) left_half [+ cos(pi - theta)(1 - left_half)]."""
+    lap = div_face(avg_face(psi, 0) * grad_face(u, hx, 0), hx, 0) + div_face(
+        avg_face(psi, 1) * grad_face(u, hy, 1), hy, 1
+    )
+    return (
+        mu_h(u)
+        - (kappa / psi) * lap
+        - np.sqrt(kappa) * sbm_norm_grad(psi, hx, hy) * np.sqrt(2.0 * f(u)) * wall_weight
+    )
+
+
+def ac_sbm_rhs(u, psi, hx, hy, kappa, f, mu_h, R, theta_t, left_half):
+    """Smoothed-boundary Allen-Cahn, allen_cahn.py:139-156."""
+    return -R(u) * sbm_inner(u, psi, hx, hy, kappa, f, mu_h, np.cos(theta_t) * left_half)
+
+
+def ch_sbm_rhs(u, psi, hx, hy, kappa, f, mu_h, D, theta_t, flux_t, left_half):
+    """Smoothed-boundary Cahn-Hilliard, cahn_hilliard.py:257-289."""
+    w = np.cos(theta_t) * left_half + np.cos(np.pi - theta_t) * (1.0 - left_half)
+    inner = sbm_inner(u, psi, hx, hy, kappa, f, mu_h, w)
+    Du = D(u)
+    Fx = avg_face(psi, 0) * avg_face(Du, 0) * grad_face(inner, hx, 0)
+    Fy = avg_face(psi, 1) * avg_face(Du, 1) * grad_face(inner, hy, 1)
+    return (div_face(Fx, hx, 0) + div_face(Fy, hy, 1)) / psi + sbm_norm_grad(psi, hx, hy) * flux_t
+
+
 def fft_wavenumbers(nx, ny, hx, hy):
     """``(2 pi i kx, 2 pi i ky)`` meshes, domains.py:44-47,58-60 and
     cahn_hilliard.py:65-67 (``fftfreq`` is cycles/unit; ``indexing='ij'``)."""

@@ -14,8 +14,10 @@ from .numerics.domains import Domain
 from .numerics.equations import (
     AdvectionDiffusion2D,
     AllenCahn2DPeriodic,
+    AllenCahn2DSmoothedBoundary,
     BaseEquation,
     CahnHilliard2DPeriodic,
+    CahnHilliard2DSmoothedBoundary,
     GPE2DTSControl,
 )
 from .numerics.functions import (
@@ -39,6 +41,7 @@ from .pde_model import PDEModel
 __all__ = [
     "PDEModel", "PDEEnv", "VectorPDEEnv", "HipEngine", "diffeqsolve", "Solution",
     "BaseEquation", "AllenCahn2DPeriodic", "CahnHilliard2DPeriodic", "AdvectionDiffusion2D", "GPE2DTSControl",
+    "AllenCahn2DSmoothedBoundary", "CahnHilliard2DSmoothedBoundary",
     "Domain", "LegendrePolynomialExpansion", "DiffusionLegendrePolynomials", "ChemicalPotentialLegendrePolynomials",
     "SemiImplicitFourierSpectral", "StrangSplitting", "Euler", "RK4", "Tsit5",
     "ConstantStepSize", "PIDController", "SaveAt",

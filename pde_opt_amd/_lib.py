@@ -22,10 +22,12 @@ OK, EINVAL, EHIP, EFFT, ENONFINITE, ENOMEM, ESTATE = range(7)
 F32, F64 = 0, 1
 DERIVS_FD, DERIVS_FOURIER = 0, 1
 EQ_CAHN_HILLIARD, EQ_ALLEN_CAHN, EQ_ADVECTION_DIFFUSION, EQ_GPE = 0, 1, 2, 3
+EQ_ALLEN_CAHN_SBM, EQ_CAHN_HILLIARD_SBM = 4, 5
 INT_EULER, INT_RK4, INT_IMEX, INT_STRANG, INT_TSIT5 = 0, 1, 2, 3, 4
 CL_POLY, CL_LEGENDRE = 0, 1
 CL_LOGIT_PRIOR, CL_EXP_WRAP = 1, 2
 AUX_VX_FACE, AUX_VY_FACE, AUX_IMEX_SYMBOL, AUX_GPE_A_TERM, AUX_GPE_POTENTIAL = 0, 1, 2, 3, 4
+AUX_SBM_PSI, AUX_SBM_NORM_GRAD, AUX_SBM_MASK = 5, 6, 7
 RED_MEAN, RED_VAR, RED_MIN, RED_MAX, RED_SUMSQ, RED_NONFINITE = 0, 1, 2, 3, 4, 5
 OPT_KERNEL_PATH = 0
 OPT_TILE_ROWS = 1
@@ -75,11 +77,14 @@ class Problem(C.Structure):
         ("mu", Closure),
         ("mob", Closure),
         ("gpe_k", C.c_double),
+        ("fe", Closure),
     ]
 
 
 # every symbol include/pdeopt_hip.h declares: name -> (restype, argtypes)
 _VP = C.c_void_p
+# pdeopt_time_fn: void (*)(double t, double out[3], void* user)
+TIME_FN = C.CFUNCTYPE(None, C.c_double, C.POINTER(C.c_double), C.c_void_p)
 _SIGNATURES = {
     "pdeopt_abi_version": (C.c_int, []),
     "pdeopt_device_count": (C.c_int, [C.POINTER(C.c_int)]),
@@ -96,6 +101,7 @@ _SIGNATURES = {
     "pdeopt_rhs": (C.c_int, [_VP, C.c_double, _VP]),
     "pdeopt_advance": (C.c_int, [_VP, C.c_int, C.c_double, C.c_double, C.c_int64]),
     "pdeopt_set_integrator_params": (C.c_int, [_VP, C.c_double, C.c_double, C.c_double, C.c_double]),
+    "pdeopt_set_time_terms": (C.c_int, [_VP, TIME_FN, _VP, C.POINTER(C.c_double)]),
     "pdeopt_snapshot": (C.c_int, [_VP]),
     "pdeopt_get_interpolated": (C.c_int, [_VP, C.c_double, C.c_int, C.c_int, _VP]),
     "pdeopt_reduce": (C.c_int, [_VP, C.c_int, _VP]),

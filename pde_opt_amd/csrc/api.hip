@@ -62,7 +62,7 @@ int check_closure(pdeopt_ctx* ctx, const pdeopt_closure& c, const char* name) {
     return fail(ctx, PDEOPT_EINVAL, "closure %s: unknown kind %d", name, c.kind);
   if (c.n < 1 || c.n > kMaxCoef)
     return fail(ctx, PDEOPT_EINVAL, "closure %s: n=%d outside 1..%d", name, c.n, kMaxCoef);
-  if (c.flags & ~(PDEOPT_CL_LOGIT_PRIOR | PDEOPT_CL_EXP_WRAP))
+  if (c.flags & ~(PDEOPT_CL_LOGIT_PRIOR | PDEOPT_CL_EXP_WRAP | PDEOPT_CL_MIX_ENTROPY))
     return fail(ctx, PDEOPT_EINVAL, "closure %s: unknown flags 0x%x", name, c.flags);
   return PDEOPT_OK;
 }
@@ -78,6 +78,7 @@ void fill_env_params(pdeopt_ctx* ctx) {
     for (int k = 0; k < kMaxCoef; ++k) {
       e[b].mu[k] = k < p.mu.n ? T(p.mu.coef[k]) : T(0);
       e[b].mob[k] = k < p.mob.n ? T(p.mob.coef[k]) : T(0);
+      e[b].fe[k] = k < p.fe.n ? T(p.fe.coef[k]) : T(0);
     }
   }
 }
@@ -229,16 +230,20 @@ int pdeopt_configure(pdeopt_ctx* ctx, const pdeopt_problem* pr) {
   ctx->configured = false;
   if (pr->dtype != PDEOPT_F32 && pr->dtype != PDEOPT_F64)
     return fail(ctx, PDEOPT_EINVAL, "unknown dtype %d", pr->dtype);
-  if (pr->equation < PDEOPT_EQ_CAHN_HILLIARD || pr->equation > PDEOPT_EQ_GPE)
+  if (pr->equation < PDEOPT_EQ_CAHN_HILLIARD || pr->equation > PDEOPT_EQ_CAHN_HILLIARD_SBM)
     return fail(ctx, PDEOPT_EINVAL, "unknown equation %d", pr->equation);
   if (pr->nx < 1 || pr->ny < 1 || pr->batch < 1)
     return fail(ctx, PDEOPT_EINVAL, "bad extents nx=%d ny=%d batch=%d", pr->nx, pr->ny, pr->batch);
   if (!(pr->hx > 0) || !(pr->hy > 0)) return fail(ctx, PDEOPT_EINVAL, "grid spacing must be > 0");
-  if (pr->equation == PDEOPT_EQ_CAHN_HILLIARD || pr->equation == PDEOPT_EQ_ALLEN_CAHN) {
+  const bool sbm = pr->equation == PDEOPT_EQ_ALLEN_CAHN_SBM || pr->equation == PDEOPT_EQ_CAHN_HILLIARD_SBM;
+  if (pr->equation == PDEOPT_EQ_CAHN_HILLIARD || pr->equation == PDEOPT_EQ_ALLEN_CAHN || sbm) {
     int rc;
     if ((rc = check_closure(ctx, pr->mu, "mu"))) return rc;
     if ((rc = check_closure(ctx, pr->mob, "mob"))) return rc;
+    if (sbm && (rc = check_closure(ctx, pr->fe, "f"))) return rc;
   }
+  if (sbm && pr->derivs != PDEOPT_DERIVS_FD)
+    return fail(ctx, PDEOPT_EINVAL, "Invalid derivative type: %d", pr->derivs);
   if (pr->derivs != PDEOPT_DERIVS_FD && pr->derivs != PDEOPT_DERIVS_FOURIER)
     return fail(ctx, PDEOPT_EINVAL, "Invalid derivative type: %d", pr->derivs);
   if (pr->derivs == PDEOPT_DERIVS_FOURIER && pr->equation != PDEOPT_EQ_CAHN_HILLIARD &&
@@ -247,6 +252,7 @@ int pdeopt_configure(pdeopt_ctx* ctx, const pdeopt_problem* pr) {
   ctx->prob = *pr;
   if (ctx->prob.mu.n < 1) ctx->prob.mu.n = 1;
   if (ctx->prob.mob.n < 1) ctx->prob.mob.n = 1;
+  if (ctx->prob.fe.n < 1) ctx->prob.fe.n = 1;
   ctx->esize = pr->dtype == PDEOPT_F32 ? 4 : 8;
   ctx->comps = pr->equation == PDEOPT_EQ_GPE ? 2 : 1;
   ctx->halo = (int)ctx->opt_halo;
@@ -378,6 +384,15 @@ int pdeopt_rhs(pdeopt_ctx* ctx, double t, void* host_out) {
   return PDEOPT_OK;
 }
 
+int pdeopt_set_time_terms(pdeopt_ctx* ctx, pdeopt_time_fn fn, void* user, const double constant[3]) {
+  if (!ctx) return PDEOPT_EINVAL;
+  ctx->time_fn = fn;
+  ctx->time_user = user;
+  for (int i = 0; i < 3; ++i) ctx->time_const[i] = constant ? constant[i] : 0.0;
+  ctx->tsit5_fsal_valid = false;
+  return PDEOPT_OK;
+}
+
 int pdeopt_set_integrator_params(pdeopt_ctx* ctx, double imex_A, double time_scale_re,
                                  double time_scale_im, double strang_dx) {
   if (!ctx) return PDEOPT_EINVAL;
@@ -407,7 +422,7 @@ int pdeopt_advance(pdeopt_ctx* ctx, int integrator, double t0, double dt, int64_
       return advance_explicit(ctx, integrator, t0, dt, n_substeps);
     case PDEOPT_INT_IMEX:
       if (eq != PDEOPT_EQ_CAHN_HILLIARD && eq != PDEOPT_EQ_ALLEN_CAHN)
-        return fail(ctx, PDEOPT_EINVAL, "IMEX needs a Cahn-Hilliard/Allen-Cahn equation");
+        return fail(ctx, PDEOPT_EINVAL, "IMEX needs a periodic Cahn-Hilliard/Allen-Cahn equation");
       return advance_imex(ctx, t0, dt, n_substeps);
     case PDEOPT_INT_STRANG:
       if (eq != PDEOPT_EQ_GPE) return fail(ctx, PDEOPT_EINVAL, "Strang splitting needs the GPE");

@@ -77,6 +77,7 @@ template <typename T>
 __device__ __forceinline__ T closure_generic(const ClosureSpec& s, const T* __restrict__ coef, T c) {
   T r = series_generic<T>(s, coef, c);
   if (s.flags & PDEOPT_CL_LOGIT_PRIOR) r += t_logit<T>(c);
+  if (s.flags & PDEOPT_CL_MIX_ENTROPY) r += c * t_log<T>(c) + (T(1) - c) * t_log<T>(T(1) - c);
   if (s.flags & PDEOPT_CL_EXP_WRAP) r = t_exp<T>(r);
   return r;
 }

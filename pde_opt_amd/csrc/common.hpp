@@ -14,7 +14,7 @@
 namespace pdeopt {
 
 constexpr int kMaxCoef = PDEOPT_CLOSURE_MAX_COEF;
-constexpr int kNumAux = 5;
+constexpr int kNumAux = 8;
 
 // Per-environment scalar parameters, stored in the arithmetic type of the path.  One struct per
 // environment in device memory; kernels index it with the (wave-uniform) batch index so the
@@ -26,6 +26,7 @@ struct EnvParams {
   T r0, r1;
   T mu[kMaxCoef];
   T mob[kMaxCoef];
+  T fe[kMaxCoef];  // free-energy density closure (smoothed-boundary equations)
 };
 
 // structure of a closure (shared by the whole batch; only coefficient VALUES vary per env)
@@ -95,6 +96,11 @@ struct pdeopt_ctx {
   void* K[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // Tsit5 slopes
   bool tsit5_pending = false;
   bool tsit5_fsal_valid = false;
+  // smoothed-boundary equations: time of the RHS evaluation being launched and its scalar terms
+  double cur_t = 0.0;
+  pdeopt_time_fn time_fn = nullptr;
+  void* time_user = nullptr;
+  double time_const[3] = {0.0, 0.0, 0.0};
   void* env_params_dev = nullptr;
   std::vector<char> env_params_host;
   pdeopt::AuxField aux[pdeopt::kNumAux];

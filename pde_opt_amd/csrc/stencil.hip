@@ -43,6 +43,17 @@ StageArgs<T> make_args(pdeopt_ctx* ctx, const void* in, const void* y, void* out
   s.vy = static_cast<const T*>(ctx->aux[PDEOPT_AUX_VY_FACE].dev);
   if (s.vx) s.vx += ctx->win_lo * s.vstride;
   if (s.vy) s.vy += ctx->win_lo * s.vstride;
+  s.psi = static_cast<const T*>(ctx->aux[PDEOPT_AUX_SBM_PSI].dev);
+  s.ngp = static_cast<const T*>(ctx->aux[PDEOPT_AUX_SBM_NORM_GRAD].dev);
+  s.mask = static_cast<const T*>(ctx->aux[PDEOPT_AUX_SBM_MASK].dev);
+  s.fe = ClosureSpec{p.fe.kind, p.fe.flags, p.fe.n};
+  if (p.equation == PDEOPT_EQ_ALLEN_CAHN_SBM || p.equation == PDEOPT_EQ_CAHN_HILLIARD_SBM) {
+    double tv[3] = {ctx->time_const[0], ctx->time_const[1], ctx->time_const[2]};
+    if (ctx->time_fn) ctx->time_fn(ctx->cur_t, tv, ctx->time_user);
+    s.tw_a = T(tv[0]);
+    s.tw_b = T(tv[1]);
+    s.tsrc = T(tv[2]);
+  }
   s.out_mode = out_mode;
   s.acc_mode = acc_mode;
   s.dbg = (int)ctx->opt_debug_ablate;
@@ -74,6 +85,19 @@ int launch_generic(pdeopt_ctx* ctx, const StageArgs<T>& s) {
       hipLaunchKernelGGL((stage_generic_kernel<T, PDEOPT_EQ_ADVECTION_DIFFUSION>), grid, block, 0,
                          ctx->stream, s);
       ctx->last_kernel = "stage_generic<AD>";
+      break;
+    case PDEOPT_EQ_ALLEN_CAHN_SBM:
+    case PDEOPT_EQ_CAHN_HILLIARD_SBM:
+      if (!s.psi || !s.ngp || !s.mask)
+        return fail(ctx, PDEOPT_ESTATE, "smoothed-boundary equations need the SBM_PSI, SBM_NORM_GRAD and SBM_MASK aux fields");
+      if (ctx->halo) return fail(ctx, PDEOPT_EINVAL, "smoothed-boundary equations need the periodic layout");
+      if (p.equation == PDEOPT_EQ_ALLEN_CAHN_SBM) {
+        hipLaunchKernelGGL((stage_generic_kernel<T, PDEOPT_EQ_ALLEN_CAHN_SBM>), grid, block, 0, ctx->stream, s);
+        ctx->last_kernel = "stage_generic<AC-SBM>";
+      } else {
+        hipLaunchKernelGGL((stage_generic_kernel<T, PDEOPT_EQ_CAHN_HILLIARD_SBM>), grid, block, 0, ctx->stream, s);
+        ctx->last_kernel = "stage_generic<CH-SBM>";
+      }
       break;
     default:
       return fail(ctx, PDEOPT_EINVAL, "equation %d has no explicit RHS kernel", p.equation);
@@ -145,7 +169,8 @@ __global__ void lerp_kernel(const T* __restrict__ a, const T* __restrict__ b, T*
 
 }  // namespace
 
-int launch_rhs(pdeopt_ctx* ctx, const void* in, void* out, double) {
+int launch_rhs(pdeopt_ctx* ctx, const void* in, void* out, double t) {
+  ctx->cur_t = t;
   return launch_stage(ctx, in, in, out, nullptr, 0.0, 0.0, OUT_K, ACC_NONE);
 }
 
@@ -163,7 +188,7 @@ GraphStructure graph_structure(const pdeopt_problem& p) {
 }
 }  // namespace
 
-int advance_explicit(pdeopt_ctx* ctx, int integrator, double, double dt, int64_t n) {
+int advance_explicit(pdeopt_ctx* ctx, int integrator, double t0, double dt, int64_t n) {
   int rc;
   if ((rc = ensure_buffer(ctx, &ctx->TA, ctx->total_bytes))) return rc;
   if (integrator == PDEOPT_INT_RK4) {
@@ -198,8 +223,10 @@ int advance_explicit(pdeopt_ctx* ctx, int integrator, double, double dt, int64_t
                      (ctx->prob.dtype == PDEOPT_F32 ? fused_supported<float>(ctx) : fused_supported<double>(ctx));
 
   // one substep on the current window; Y / TA are swapped where the integrator ping-pongs
-  auto substep = [&](void*& Y, void*& TA) -> int {
+  auto substep = [&](void*& Y, void*& TA, int64_t step) -> int {
     int r;
+    const double ts = t0 + (double)step * dt;  // stage times only matter to time-dependent equations
+    ctx->cur_t = ts;
     if (integrator == PDEOPT_INT_EULER) {
       r = launch_stage(ctx, Y, Y, TA, nullptr, dt, 0.0, OUT_Y_PLUS_AK, ACC_NONE);
       std::swap(Y, TA);
@@ -215,10 +242,12 @@ int advance_explicit(pdeopt_ctx* ctx, int integrator, double, double dt, int64_t
     // stage 1: k1 = f(y);        TA = y + dt/2 k1;  ACC = y + dt/6 k1
     r = launch_stage(ctx, Y, Y, TA, ctx->ACC, dt / 2, dt / 6, OUT_Y_PLUS_AK, ACC_INIT);
     // stage 2: k2 = f(TA);       TB = y + dt/2 k2;  ACC += dt/3 k2
+    ctx->cur_t = ts + dt / 2;
     if (!r) r = launch_stage(ctx, TA, Y, ctx->TB, ctx->ACC, dt / 2, dt / 3, OUT_Y_PLUS_AK, ACC_ADD);
     // stage 3: k3 = f(TB);       TA = y + dt k3;    ACC += dt/3 k3
     if (!r) r = launch_stage(ctx, ctx->TB, Y, TA, ctx->ACC, dt, dt / 3, OUT_Y_PLUS_AK, ACC_ADD);
     // stage 4: k4 = f(TA);       y  = ACC + dt/6 k4   (in place: y is only touched pointwise)
+    ctx->cur_t = ts + dt;
     if (!r) r = launch_stage(ctx, TA, Y, Y, ctx->ACC, 0.0, dt / 6, OUT_ACC_PLUS_BK, ACC_NONE);
     return r;
   };
@@ -229,7 +258,8 @@ int advance_explicit(pdeopt_ctx* ctx, int integrator, double, double dt, int64_t
   // per-environment parameter VALUES live in device memory and may change between replays.
   int64_t done = 0;
   const int64_t cells_per_launch = (int64_t)ctx->prob.nx * ctx->prob.ny * group;
-  const bool want_graph = ctx->opt_graph >= 0 && group >= batch && ctx->prob.derivs == PDEOPT_DERIVS_FD &&
+  const bool timed = ctx->prob.equation == PDEOPT_EQ_ALLEN_CAHN_SBM || ctx->prob.equation == PDEOPT_EQ_CAHN_HILLIARD_SBM;
+  const bool want_graph = !timed && ctx->opt_graph >= 0 && group >= batch && ctx->prob.derivs == PDEOPT_DERIVS_FD &&
                           n >= 2 * kGraphUnit && (ctx->opt_graph > 0 || cells_per_launch <= (1 << 20));
   if (want_graph) {
     ctx->win_lo = 0;
@@ -251,7 +281,7 @@ int advance_explicit(pdeopt_ctx* ctx, int integrator, double, double dt, int64_t
       const int64_t launches_before = ctx->n_stage_launches;
       hipGraph_t graph = nullptr;
       PDEOPT_HIP_CHECK(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
-      for (int u = 0; u < kGraphUnit && !rc; ++u) rc = substep(Y, TA);
+      for (int u = 0; u < kGraphUnit && !rc; ++u) rc = substep(Y, TA, u);
       const hipError_t e_end = hipStreamEndCapture(ctx->stream, &graph);
       ctx->graph_launches_per_replay = ctx->n_stage_launches - launches_before;
       ctx->n_stage_launches = launches_before;
@@ -281,7 +311,7 @@ int advance_explicit(pdeopt_ctx* ctx, int integrator, double, double dt, int64_t
     ctx->win_n = std::min(group, batch - lo);
     void* Y = ctx->Y;
     void* TA = ctx->TA;
-    for (int64_t s = done; s < n && !rc; ++s) rc = substep(Y, TA);
+    for (int64_t s = done; s < n && !rc; ++s) rc = substep(Y, TA, s);
     y_final = Y;  // every group performs the same number of swaps
     ta_final = TA;
     if (rc) break;
@@ -357,6 +387,8 @@ constexpr double kTsA[6][6] = {
      -0.028269050394068383, 0},
     {0.09646076681806523, 0.01, 0.4798896504144996, 1.379008574103742, -3.290069515436081,
      2.324710524099774}};
+// abscissae of stages 2..7 (row sums of kTsA)
+constexpr double kTsC[6] = {0.161, 0.327, 0.9, 0.9800255409045097, 1.0, 1.0};
 constexpr double kTsE[7] = {0.00178001105222577714, 0.0008164344596567469, -0.007880878010261995,
                             0.1447110071732629,     -0.5823571654525552,   0.45808210592918697,
                             -1.0 / 66.0};
@@ -407,7 +439,7 @@ __global__ __launch_bounds__(256) void tsit5_err_kernel(const LinComb<T> a, cons
 }
 
 template <typename T>
-int tsit5_trial_t(pdeopt_ctx* ctx, double dt, double rtol, double atol, double* err) {
+int tsit5_trial_t(pdeopt_ctx* ctx, double t, double dt, double rtol, double atol, double* err) {
   int rc;
   for (auto& k : ctx->K)
     if ((rc = ensure_buffer(ctx, &k, ctx->total_bytes))) return rc;
@@ -416,6 +448,7 @@ int tsit5_trial_t(pdeopt_ctx* ctx, double dt, double rtol, double atol, double* 
   const int64_t total = (int64_t)(ctx->env_elems * ctx->prob.batch);
   const int blocks = (int)std::min<int64_t>((total + 255) / 256, 4096);
   if (!ctx->tsit5_fsal_valid) {
+    ctx->cur_t = t;
     if ((rc = launch_stage(ctx, ctx->Y, ctx->Y, ctx->K[0], nullptr, 0, 0, OUT_K, ACC_NONE))) return rc;
   }
   for (int s = 0; s < 6; ++s) {
@@ -429,6 +462,7 @@ int tsit5_trial_t(pdeopt_ctx* ctx, double dt, double rtol, double atol, double* 
     void* dst = (s == 5) ? ctx->TB : ctx->TA;  // the last stage input is the 5th-order solution
     lc.out = (T*)dst;
     hipLaunchKernelGGL(lincomb_kernel<T>, dim3(blocks), dim3(256), 0, ctx->stream, lc, total);
+    ctx->cur_t = t + kTsC[s] * dt;
     if ((rc = launch_stage(ctx, dst, dst, ctx->K[s + 1], nullptr, 0, 0, OUT_K, ACC_NONE))) return rc;
   }
   ctx->tsit5_pending = true;
@@ -468,9 +502,9 @@ int tsit5_trial_t(pdeopt_ctx* ctx, double dt, double rtol, double atol, double* 
 
 }  // namespace
 
-int tsit5_trial(pdeopt_ctx* ctx, double, double dt, double rtol, double atol, double* err) {
-  return ctx->prob.dtype == PDEOPT_F32 ? tsit5_trial_t<float>(ctx, dt, rtol, atol, err)
-                                       : tsit5_trial_t<double>(ctx, dt, rtol, atol, err);
+int tsit5_trial(pdeopt_ctx* ctx, double t, double dt, double rtol, double atol, double* err) {
+  return ctx->prob.dtype == PDEOPT_F32 ? tsit5_trial_t<float>(ctx, t, dt, rtol, atol, err)
+                                       : tsit5_trial_t<double>(ctx, t, dt, rtol, atol, err);
 }
 
 int tsit5_commit(pdeopt_ctx* ctx, int accept) {

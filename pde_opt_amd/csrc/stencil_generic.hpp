@@ -33,6 +33,11 @@ struct StageArgs {
   const T* vx;   // advection-diffusion face velocities
   const T* vy;
   int64_t vstride;
+  const T* psi;  // smoothed-boundary level set, |grad psi|/psi and wall mask (shared [nx][ny])
+  const T* ngp;
+  const T* mask;
+  T tw_a, tw_b, tsrc;  // cos(theta(t)) on / off the mask, flux(t): scalars of this RHS evaluation
+  ClosureSpec fe;
   int out_mode, acc_mode;
   int dbg;  // timing ablations (PDEOPT_OPT_DEBUG_ABLATE): bit0 skip mu phase, bit1 skip flux phase
 };
@@ -67,6 +72,47 @@ __device__ __forceinline__ T rhs_generic_point(const StageArgs<T>& a, const T* _
     const T mu = closure_generic<T>(a.mu, p.mu, u00) -
                  p.kappa * lap_at<T>(u00, uxp, uxm, uyp, uym, a.rhx2, a.rhy2);
     return -closure_generic<T>(a.mob, p.mob, u00) * mu;
+  } else if constexpr (EQ == PDEOPT_EQ_ALLEN_CAHN_SBM || EQ == PDEOPT_EQ_CAHN_HILLIARD_SBM) {
+    // smoothed-boundary method (allen_cahn.py:139-156, cahn_hilliard.py:257-289): psi-weighted
+    // Laplacian through face averages, wall (contact-angle) term, optional boundary flux source
+    const int ny = g.ny;
+    auto PS = [&](int ii, int jj) -> T { return a.psi[(int64_t)ii * ny + jj]; };
+    const T sqk = sqrt(p.kappa);
+    auto WL = [&](int ii, int jj) -> T {
+      const T m = a.mask[(int64_t)ii * ny + jj];
+      return sqk * a.ngp[(int64_t)ii * ny + jj] * (a.tw_a * m + a.tw_b * (T(1) - m));
+    };
+    // inner(c; neighbours) = mu_h(c) - kappa/psi div(psi grad u) - wall sqrt(2 f(c))
+    auto INNER = [&](T c, T xp, T xm, T yp, T ym, T pc, T pxp, T pxm, T pyp, T pym, T w) -> T {
+      const T dx_hi = (T(0.5) * (pc + pxp)) * ((xp - c) * a.rhx), dx_lo = (T(0.5) * (pxm + pc)) * ((c - xm) * a.rhx);
+      const T dy_hi = (T(0.5) * (pc + pyp)) * ((yp - c) * a.rhy), dy_lo = (T(0.5) * (pym + pc)) * ((c - ym) * a.rhy);
+      const T lap = (dx_hi - dx_lo) * a.rhx + (dy_hi - dy_lo) * a.rhy;
+      T r = closure_generic<T>(a.mu, p.mu, c) - (p.kappa / pc) * lap;
+      r -= w * sqrt(T(2) * closure_generic<T>(a.fe, p.fe, c));
+      return r;
+    };
+    const T p00 = PS(i, j), pxp = PS(i1, j), pxm = PS(im1, j), pyp = PS(i, j1), pym = PS(i, jm1);
+    const T in00 = INNER(u00, uxp, uxm, uyp, uym, p00, pxp, pxm, pyp, pym, WL(i, j));
+    if constexpr (EQ == PDEOPT_EQ_ALLEN_CAHN_SBM) {
+      return -closure_generic<T>(a.mob, p.mob, u00) * in00;
+    } else {
+      const T ux2 = U(i2, j), uxm2 = U(im2, j), uy2 = U(i, j2), uym2 = U(i, jm2);
+      const T upp = U(i1, j1), upm = U(i1, jm1), ump = U(im1, j1), umm = U(im1, jm1);
+      const T px2 = PS(i2, j), pxm2 = PS(im2, j), py2 = PS(i, j2), pym2 = PS(i, jm2);
+      const T ppp = PS(i1, j1), ppm = PS(i1, jm1), pmp = PS(im1, j1), pmm = PS(im1, jm1);
+      const T inxp = INNER(uxp, ux2, u00, upp, upm, pxp, px2, p00, ppp, ppm, WL(i1, j));
+      const T inxm = INNER(uxm, u00, uxm2, ump, umm, pxm, p00, pxm2, pmp, pmm, WL(im1, j));
+      const T inyp = INNER(uyp, upp, ump, uy2, u00, pyp, ppp, pmp, py2, p00, WL(i, j1));
+      const T inym = INNER(uym, upm, umm, u00, uym2, pym, ppm, pmm, p00, pym2, WL(i, jm1));
+      const T d00 = closure_generic<T>(a.mob, p.mob, u00);
+      const T dxp = closure_generic<T>(a.mob, p.mob, uxp), dxm = closure_generic<T>(a.mob, p.mob, uxm);
+      const T dyp = closure_generic<T>(a.mob, p.mob, uyp), dym = closure_generic<T>(a.mob, p.mob, uym);
+      const T fx0 = (T(0.5) * (p00 + pxp)) * (T(0.5) * (d00 + dxp)) * ((inxp - in00) * a.rhx);
+      const T fxm = (T(0.5) * (pxm + p00)) * (T(0.5) * (dxm + d00)) * ((in00 - inxm) * a.rhx);
+      const T fy0 = (T(0.5) * (p00 + pyp)) * (T(0.5) * (d00 + dyp)) * ((inyp - in00) * a.rhy);
+      const T fym = (T(0.5) * (pym + p00)) * (T(0.5) * (dym + d00)) * ((in00 - inym) * a.rhy);
+      return ((fx0 - fxm) * a.rhx + (fy0 - fym) * a.rhy) / p00 + a.ngp[(int64_t)i * ny + j] * a.tsrc;
+    }
   } else if constexpr (EQ == PDEOPT_EQ_ADVECTION_DIFFUSION) {
     const int64_t vb = (int64_t)b * a.vstride;
     const T vx0 = a.vx[vb + (int64_t)i * g.ny + j], vxm = a.vx[vb + (int64_t)im1 * g.ny + j];

@@ -111,9 +111,11 @@ class HipEngine:
         mob: Optional[ClosureDesc] = None,
         gpe_k: float = 0.0,
         derivs: int = 0,
+        fe: Optional[ClosureDesc] = None,
     ):
         p = L.Problem()
         p.derivs = int(derivs)
+        p.fe = _closure_struct(fe)
         p.equation, p.dtype = int(equation), L.dtype_code(dtype)
         p.nx, p.ny, p.batch = int(nx), int(ny), int(batch)
         p.hx, p.hy, p.kappa, p.gpe_k = float(hx), float(hy), float(kappa), float(gpe_k)
@@ -169,6 +171,23 @@ class HipEngine:
         self._check(
             self._lib.pdeopt_set_integrator_params(self._h, float(imex_A), ts.real, ts.imag, float(strang_dx))
         )
+
+    def set_time_terms(self, fn=None, constant=(0.0, 0.0, 0.0)):
+        """Smoothed-boundary scalars per RHS evaluation time: ``fn(t) -> (cos theta on the mask,
+        cos off the mask, flux)`` is called by the library at every stage; ``fn=None`` uses
+        ``constant``.  The ctypes thunk is kept alive on the engine."""
+        const = (C.c_double * 3)(*[float(v) for v in constant])
+        if fn is None:
+            self._time_thunk = None
+            self._check(self._lib.pdeopt_set_time_terms(self._h, L.TIME_FN(0), None, const))
+            return
+
+        def thunk(t, out, _user):
+            a, b, f = fn(t)
+            out[0], out[1], out[2] = float(a), float(b), float(f)
+
+        self._time_thunk = L.TIME_FN(thunk)
+        self._check(self._lib.pdeopt_set_time_terms(self._h, self._time_thunk, None, const))
 
     # -- state ------------------------------------------------------------------------------
     def set_state(self, state, env_first: int = 0):

@@ -4,7 +4,7 @@ Upstream these are arbitrary Python callables traced by ``jax.jit`` into the RHS
 fields pde_opt/numerics/equations/cahn_hilliard.py:51-54, allen_cahn.py:47-50).  A HIP kernel
 needs a closed family; the one implemented (include/pdeopt_hip.h) is
 
-    f(c) = series(c) [+ log(c / (1 - c))]  [then exp(.)]
+    f(c) = series(c) [+ log(c / (1 - c))] [+ c log c + (1 - c) log(1 - c)]  [then exp(.)]
 
 with ``series`` a polynomial in ``c`` or a Legendre series in ``2c - 1``.  ``as_closure`` turns a
 user callable into a descriptor by evaluating it once on a symbolic variable (sympy) and matching
@@ -21,7 +21,7 @@ from typing import Callable, Sequence
 import numpy as np
 
 POLY, LEGENDRE = 0, 1
-LOGIT_PRIOR, EXP_WRAP = 1, 2
+LOGIT_PRIOR, EXP_WRAP, MIX_ENTROPY = 1, 2, 4
 MAX_COEF = 16
 
 
@@ -53,6 +53,8 @@ class ClosureDesc:
             r = np.polynomial.legendre.legval(2.0 * c - 1.0, np.asarray(self.coef))
         if self.flags & LOGIT_PRIOR:
             r = r + np.log(c / (1 - c))
+        if self.flags & MIX_ENTROPY:
+            r = r + c * np.log(c) + (1 - c) * np.log(1 - c)
         if self.flags & EXP_WRAP:
             r = np.exp(r)
         return r
@@ -159,7 +161,13 @@ def _match(expr, c):
             flags |= EXP_WRAP
             e = inner
     logit = sp.log(c) - sp.log(1 - c)
-    for candidate_flags, cand in ((0, e), (LOGIT_PRIOR, sp.expand(e - logit))):
+    entropy = sp.expand(c * sp.log(c) + (1 - c) * sp.log(1 - c))
+    for candidate_flags, cand in (
+        (0, e),
+        (LOGIT_PRIOR, sp.expand(e - logit)),
+        (MIX_ENTROPY, sp.expand(e - entropy)),
+        (LOGIT_PRIOR | MIX_ENTROPY, sp.expand(e - logit - entropy)),
+    ):
         # logs written as log(1 - c) or log(-(c - 1)) etc. must cancel exactly to count
         if cand.is_polynomial(c) and not cand.has(sp.log):
             poly = sp.Poly(cand, c)

@@ -4,12 +4,15 @@ from .advection_diffusion import AdvectionDiffusion2D
 from .base_eq import BaseEquation, TimeSplittingEquation
 from .gross_pitaevskii import GPE2DTSControl
 from .phase_field import AllenCahn2DPeriodic, CahnHilliard2DPeriodic
+from .smoothed_boundary import AllenCahn2DSmoothedBoundary, CahnHilliard2DSmoothedBoundary
 
 __all__ = [
     "BaseEquation",
     "TimeSplittingEquation",
     "AllenCahn2DPeriodic",
     "CahnHilliard2DPeriodic",
+    "AllenCahn2DSmoothedBoundary",
+    "CahnHilliard2DSmoothedBoundary",
     "AdvectionDiffusion2D",
     "GPE2DTSControl",
 ]

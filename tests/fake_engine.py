@@ -16,17 +16,23 @@ class OracleEngine:
         self.calls = []
 
     # -- configuration ------------------------------------------------------------------------
-    def configure(self, equation, dtype, nx, ny, batch, hx, hy, kappa=0.0, mu=None, mob=None, gpe_k=0.0, derivs=0):
+    def configure(self, equation, dtype, nx, ny, batch, hx, hy, kappa=0.0, mu=None, mob=None, gpe_k=0.0, derivs=0, fe=None):
         self.eq, self.dtype, self.batch = equation, np.dtype(dtype), batch
         self.hx, self.hy, self.kappa, self.mu, self.mob = hx, hy, kappa, mu, mob
         self.problem = object()
         self.state_shape = (nx, ny)
         self.y = np.zeros((batch, nx, ny), self.dtype)
         self.imex_A, self.symbol = 0.5, None
+        self.fe, self.sbm, self.time_fn = fe, {}, None
 
     def set_aux(self, which, field, per_env=False):
         if which == L.AUX_IMEX_SYMBOL:
             self.symbol = np.asarray(field)
+        if which in (L.AUX_SBM_PSI, L.AUX_SBM_NORM_GRAD, L.AUX_SBM_MASK):
+            self.sbm[which] = np.asarray(field)
+
+    def set_time_terms(self, fn=None, constant=(0.0, 0.0, 0.0)):
+        self.time_fn = fn if fn is not None else (lambda t: constant)
 
     def set_integrator_params(self, imex_A=0.5, time_scale=1.0, strang_dx=1.0):
         self.imex_A = imex_A
@@ -42,6 +48,18 @@ class OracleEngine:
 
     # -- compute --------------------------------------------------------------------------------
     def _f(self, t, u):
+        if self.eq in (L.EQ_ALLEN_CAHN_SBM, L.EQ_CAHN_HILLIARD_SBM):
+            # the ABI's decomposition (include/pdeopt_hip.h, pdeopt_time_fn): scalars from the
+            # callback, spatial fields from the aux uploads
+            a, b, fl = self.time_fn(t)
+            psi, ngp, m = (self.sbm[k] for k in (L.AUX_SBM_PSI, L.AUX_SBM_NORM_GRAD, L.AUX_SBM_MASK))
+            inner = O.sbm_inner(u, psi, self.hx, self.hy, self.kappa, self.fe, self.mu, a * m + b * (1 - m))
+            if self.eq == L.EQ_ALLEN_CAHN_SBM:
+                return -self.mob(u) * inner
+            Du = self.mob(u)
+            Fx = O.avg_face(psi, 0) * O.avg_face(Du, 0) * O.grad_face(inner, self.hx, 0)
+            Fy = O.avg_face(psi, 1) * O.avg_face(Du, 1) * O.grad_face(inner, self.hy, 1)
+            return (O.div_face(Fx, self.hx, 0) + O.div_face(Fy, self.hy, 1)) / psi + ngp * fl
         fn = O.ch_rhs_fd if self.eq == L.EQ_CAHN_HILLIARD else O.ac_rhs_fd
         return fn(u, self.hx, self.hy, self.kappa, self.mu, self.mob)
 

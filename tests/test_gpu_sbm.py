@@ -1,0 +1,117 @@
+"""Smoothed-boundary Allen-Cahn / Cahn-Hilliard on the MI355X against the
+reference's goldens (tests/golden/sbm_cases.npz, written by oracle/gen_golden.py from
+allen_cahn.py:139-156 / cahn_hilliard.py:257-289) and the numpy oracle."""
+import numpy as np
+import pytest
+
+import pde_opt_amd as P
+from oracle import np_oracle as O
+from util import MOB, MU, SBM_F, SBM_FLUX, SBM_THETA, TOL, rel_l2, sbm_domain, sbm_psi
+
+pytestmark = pytest.mark.gpu
+
+
+def _eq(kind, dom, theta=SBM_THETA, flux=SBM_FLUX, kappa=1.5):
+    if kind == "ac":
+        return P.AllenCahn2DSmoothedBoundary(dom, kappa, SBM_F, MU["regsol"], MOB["c1mc"], theta)
+    return P.CahnHilliard2DSmoothedBoundary(dom, kappa, SBM_F, MU["regsol"], MOB["c1mc"], theta, flux)
+
+
+def test_rhs_against_reference_goldens(golden):
+    z = golden("sbm_cases.npz")
+    keys = sorted(k[: -len("/psi")] for k in z.files if k.endswith("/psi"))
+    assert len(keys) == 8
+    for key in keys:
+        kind = key.split("/")[0]
+        psi, u = z[key + "/psi"], z[key + "/u"]
+        eq = _eq(kind, sbm_domain(P, psi.astype(np.float64)))
+        for t in (0.0, 0.17):
+            want = z[f"{key}/rhs_t{t}"]
+            got = eq.rhs(u, t)
+            # (the fp32 goldens came out as float64: numpy promotes float32 * np.cos(float) where JAX
+            # would stay in fp32; the inputs are fp32 and so is the kernel)
+            assert got.dtype == u.dtype
+            assert rel_l2(got, want) < TOL[u.dtype], (key, t, rel_l2(got, want))
+    assert "SBM" in P.engine.default_engine().last_kernel
+
+
+def _oracle_rhs(kind, psi, lh):
+    if kind == "ac":
+        return lambda t, u: O.ac_sbm_rhs(u, psi, 1.0, 1.0, 1.5, SBM_F, MU["regsol"], MOB["c1mc"], SBM_THETA(t), lh)
+    return lambda t, u: O.ch_sbm_rhs(u, psi, 1.0, 1.0, 1.5, SBM_F, MU["regsol"], MOB["c1mc"], SBM_THETA(t),
+                                     SBM_FLUX(t), lh)
+
+
+@pytest.mark.parametrize("kind", ["ac", "ch"])
+@pytest.mark.parametrize("solver", ["euler", "rk4", "tsit5"])
+def test_trajectory_with_time_dependent_contact_angle(kind, solver):
+    """theta(t) / flux(t) are evaluated at every stage time (t, t+dt/2, t+dt; Tsit5's c_i)."""
+    rng = np.random.default_rng(11)
+    psi = sbm_psi(72, 120) if kind == "ac" else sbm_psi(96, 40)
+    eq = _eq(kind, sbm_domain(P, psi))
+    y0 = np.clip(0.5 + 0.1 * rng.standard_normal((2,) + psi.shape), 0.1, 0.9)
+    f = _oracle_rhs(kind, psi, eq.left_half)
+    dt, n, t0 = (2e-3 if kind == "ch" else 2e-2), 4, 0.03
+    s = {"euler": P.Euler(), "rk4": P.RK4(), "tsit5": P.Tsit5()}[solver]
+    sol = P.diffeqsolve(eq, s, t0=t0, t1=t0 + n * dt, dt0=dt, y0=y0)
+    for b in range(2):
+        ref = y0[b]
+        for i in range(n):
+            t = t0 + i * dt
+            if solver == "euler":
+                ref = O.euler_step(f, t, ref, dt)
+            elif solver == "rk4":
+                ref = O.rk4_step(f, t, ref, dt)
+            else:
+                ref = O.tsit5_step(f, t, ref, dt)[0]
+        assert rel_l2(sol.ys[-1][b] - y0[b], ref - y0[b]) < 1e-10, (kind, solver)
+
+
+def test_psi_weighted_mass_balance_and_adaptive_run():
+    """sum(psi u) changes only through the boundary flux: d/dt sum(psi u) = sum(|grad psi|) flux(t)
+    (cahn_hilliard.py:282-289 multiplied by psi).  Run adaptively (Tsit5 + PID) like
+    notebooks/smooth_boundary.ipynb, at a size beyond the oracle's reach in test time."""
+    n = 384
+    psi = sbm_psi(n, n)
+    dom = sbm_domain(P, psi)
+    rng = np.random.default_rng(2)
+    y0 = np.clip(0.5 + 0.05 * rng.standard_normal((n, n)), 0.1, 0.9)
+    flux = lambda t: 0.01  # noqa: E731
+    eq = _eq("ch", dom, flux=flux)
+    sol = P.diffeqsolve(eq, P.Tsit5(), 0.0, 0.05, 1e-4, y0, stepsize_controller=P.PIDController(rtol=1e-5, atol=1e-7))
+    assert sol.stats["num_accepted_steps"] >= 3
+    m0, m1 = np.sum(psi * y0), np.sum(psi * sol.ys[-1])
+    want = 0.05 * 0.01 * np.sum(eq.norm_grad_psi * psi)
+    assert abs((m1 - m0) - want) < 1e-9 * abs(m0), (m1 - m0, want)
+    # without flux the psi-weighted mass is conserved to rounding
+    eq0 = _eq("ch", dom, flux=lambda t: 0.0)
+    sol0 = P.diffeqsolve(eq0, P.RK4(), 0.0, 5e-3, 1e-3, y0)
+    assert abs(np.sum(psi * sol0.ys[-1]) - m0) < 1e-11 * abs(m0)
+
+
+def test_fp32_and_batch_consistency():
+    rng = np.random.default_rng(8)
+    psi = sbm_psi(64, 128)
+    eq = _eq("ac", sbm_domain(P, psi))
+    y0 = np.clip(0.5 + 0.1 * rng.standard_normal((3,) + psi.shape), 0.1, 0.9).astype(np.float32)
+    batch = P.diffeqsolve(eq, P.RK4(), 0.0, 0.08, 0.02, y0).ys[-1]
+    for b in range(3):
+        single = P.diffeqsolve(eq, P.RK4(), 0.0, 0.08, 0.02, y0[b]).ys[-1]
+        np.testing.assert_array_equal(single, batch[b])
+    f = _oracle_rhs("ac", psi, eq.left_half)
+    ref = y0[0].astype(np.float64)
+    for i in range(4):
+        ref = O.rk4_step(f, i * 0.02, ref, 0.02)
+    assert rel_l2(batch[0] - y0[0], ref - y0[0]) < 5e-4
+
+
+def test_missing_aux_is_an_error():
+    eng = P.HipEngine()
+    from pde_opt_amd import _lib as L
+    from pde_opt_amd.numerics.closures import as_closure
+
+    eng.configure(L.EQ_ALLEN_CAHN_SBM, np.float64, 16, 16, 1, 1.0, 1.0, 1.0, as_closure(MU["regsol"]),
+                  as_closure(MOB["c1mc"]), fe=as_closure(SBM_F))
+    eng.set_state(np.full((16, 16), 0.5))
+    with pytest.raises(P.PdeoptError, match="SBM_PSI"):
+        eng.rhs(0.0)

@@ -88,3 +88,33 @@ def test_input_validation():
         P.diffeqsolve(eq, P.Euler(), 0.0, 1e-3, 1e-4, np.zeros(dom.points, complex), engine=OracleEngine())
     with pytest.raises(ValueError, match="positive"):
         P.diffeqsolve(eq, P.Euler(), 0.0, 1e-3, 0.0, np.zeros(dom.points), engine=OracleEngine())
+
+
+def test_smoothed_boundary_host_wiring():
+    """SBM equations: closures traced (incl. the mixing-entropy free energy), psi-derived fields
+    uploaded, theta(t)/flux(t) delivered per RHS evaluation time; Tsit5 stage times reach them."""
+    from util import SBM_F, SBM_FLUX, SBM_THETA, sbm_domain, sbm_psi
+
+    psi = sbm_psi(60, 28)
+    dom = sbm_domain(P, psi)
+    eq = P.CahnHilliard2DSmoothedBoundary(dom, 1.5, SBM_F, MU["regsol"], MOB["c1mc"], SBM_THETA, SBM_FLUX)
+    assert eq._f_desc.flags == 4 and eq._f_desc.coef == (0.059, 3.0, -3.0)
+    assert eq.left_half[:50].all() and not eq.left_half[50:].any()
+    np.testing.assert_array_equal(eq.norm_grad_psi, O.sbm_norm_grad(psi, 1.0, 1.0))
+    y0 = np.clip(0.5 + 0.1 * np.random.default_rng(5).standard_normal(psi.shape), 0.1, 0.9)
+    f = lambda t, u: O.ch_sbm_rhs(u, psi, 1.0, 1.0, 1.5, SBM_F, MU["regsol"], MOB["c1mc"], SBM_THETA(t),
+                                  SBM_FLUX(t), eq.left_half)
+    dt = 2e-3
+    sol = P.diffeqsolve(eq, P.RK4(), 0.05, 0.05 + 3 * dt, dt, y0, engine=OracleEngine())
+    want = y0
+    for i in range(3):
+        want = O.rk4_step(f, 0.05 + i * dt, want, dt)
+    np.testing.assert_allclose(sol.ys[-1], want, rtol=0, atol=1e-14)
+
+    ac = P.AllenCahn2DSmoothedBoundary(sbm_domain(P, sbm_psi(20, 120)), 1.5, SBM_F, MU["regsol"], MOB["c1mc"], SBM_THETA)
+    assert ac.left_half[:, :100].all() and not ac.left_half[:, 100:].any()
+    assert ac._time_terms(0.1) == (np.cos(SBM_THETA(0.1)), 0.0, 0.0)
+    with pytest.raises(ValueError, match="Invalid derivative type"):
+        P.AllenCahn2DSmoothedBoundary(dom, 1.5, SBM_F, MU["regsol"], MOB["c1mc"], SBM_THETA, derivs="fourier")
+    with pytest.raises(ValueError, match="geometry"):
+        P.AllenCahn2DSmoothedBoundary(std_domain(P, 8, 8), 1.5, SBM_F, MU["regsol"], MOB["c1mc"], SBM_THETA)

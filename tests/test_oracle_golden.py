@@ -172,3 +172,32 @@ def test_constant_step_plan():
     assert n == 3 and abs(rem - 0.1) < 1e-12
     ys = O.solve_saveat(lambda t, y, dt: y + dt, np.zeros(1), [0.0, 0.25, 0.5, 1.0], 0.1)
     np.testing.assert_allclose(ys[:, 0], [0.0, 0.25, 0.5, 1.0], atol=1e-12)
+
+
+# ---- smoothed-boundary equations ---------------------------------------
+SBM_F = lambda c: c * np.log(c) + (1.0 - c) * np.log(1.0 - c) + 3.0 * c * (1.0 - c) + 0.059  # noqa: E731
+SBM_THETA = lambda t: 34.9065850398866 * t**2 - 10.4719755119660 * t + np.pi / 2  # noqa: E731
+SBM_FLUX = lambda t: 0.02 * (1.0 + 3.0 * t)  # noqa: E731
+
+
+def sbm_cases(z):
+    return sorted(k[: -len("/psi")] for k in z.files if k.endswith("/psi"))
+
+
+def test_sbm_rhs_matches_reference_goldens(golden):
+    z = golden("sbm_cases.npz")
+    keys = sbm_cases(z)
+    assert len(keys) == 8
+    for key in keys:
+        kind = key.split("/")[0]
+        psi, u, lh = z[key + "/psi"], z[key + "/u"], z[key + "/left_half"]
+        np.testing.assert_allclose(O.sbm_norm_grad(psi, 1.0, 1.0), z[key + "/norm_grad_psi"], rtol=1e-6)
+        for t in (0.0, 0.17):
+            want = z[f"{key}/rhs_t{t}"]
+            if kind == "ac":
+                got = O.ac_sbm_rhs(u, psi, 1.0, 1.0, 1.5, SBM_F, MU["regsol"], MOB["c1mc"], SBM_THETA(t), lh)
+            else:
+                got = O.ch_sbm_rhs(u, psi, 1.0, 1.0, 1.5, SBM_F, MU["regsol"], MOB["c1mc"], SBM_THETA(t),
+                                   SBM_FLUX(t), lh)
+            tol = 1e-12 if want.dtype == np.float64 else 2e-5
+            np.testing.assert_allclose(got, want, rtol=0, atol=tol * np.abs(want).max(), err_msg=f"{key} t={t}")

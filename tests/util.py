@@ -38,3 +38,25 @@ def white_noise_state(rng, shape, dtype, kind):
 #         arithmetic is 2e-7..4e-7 on white noise, so kernels are held to
 #         2e-5 against the fp32 oracle and 5e-5 against fp64.
 TOL = {np.dtype(np.float64): 1e-11, np.dtype(np.float32): 2e-5}
+
+
+# ---- smoothed-boundary fixtures (same closures / theta ramp as oracle/gen_golden.py) ----------
+SBM_F = lambda c: c * np.log(c) + (1.0 - c) * np.log(1.0 - c) + 3.0 * c * (1.0 - c) + 0.059  # noqa: E731
+SBM_THETA = lambda t: 34.9065850398866 * t**2 - 10.4719755119660 * t + np.pi / 2  # noqa: E731
+SBM_FLUX = lambda t: 0.02 * (1.0 + 3.0 * t)  # noqa: E731
+
+
+def sbm_psi(nx, ny, floor=0.05):
+    """disc-shaped level set in (floor, 1] on a unit-spacing grid"""
+    x, y = np.arange(nx) + 0.5, np.arange(ny) + 0.5
+    X, Y = np.meshgrid(x, y, indexing="ij")
+    r = np.sqrt((X - 0.5 * nx) ** 2 + (Y - 0.5 * ny) ** 2)
+    return floor + (1.0 - floor) * 0.5 * (1.0 + np.tanh((0.3 * min(nx, ny) - r) / 2.5))
+
+
+def sbm_domain(P, psi):
+    import types
+
+    nx, ny = psi.shape
+    return P.Domain((nx, ny), ((0.0, float(nx)), (0.0, float(ny))), "dimensionless",
+                    geometry=types.SimpleNamespace(smooth=psi))
