@@ -47,6 +47,9 @@ WORDS = {"rk4": 16, "euler": 2, "imex": 9, "strang": 22}  # strang: 88 B / 4 B a
 
 WORKLOADS = {
     "ch_rk4_1024_f32": dict(eq="ch", n=1024, dtype=np.float32, integ="rk4", dt=2e-7, substeps=100, batch=32),
+    # same kernel with the double-well closures (mu = c^3 - c, D = 1 + c^2: no log / rcp in mu)
+    "ch_rk4_1024_f32_cubic": dict(eq="ch", n=1024, dtype=np.float32, integ="rk4", dt=2e-7, substeps=100, batch=32,
+                                  closures="cubic"),
     "ch_rk4_1024_f64": dict(eq="ch", n=1024, dtype=np.float64, integ="rk4", dt=2e-7, substeps=100, batch=16),
     "ac_rk4_512_f32": dict(eq="ac", n=512, dtype=np.float32, integ="rk4", dt=5e-5, substeps=100, batch=64),
     "ch_imex_1024_f32": dict(eq="ch", n=1024, dtype=np.float32, integ="imex", dt=1e-6, substeps=100, batch=32),
@@ -78,7 +81,9 @@ def make_problem(P, name, batch, rank):
             y0[b] = np.clip(0.5 + 0.01 * rng.standard_normal((n, n)), 0.05, 0.95)
         else:
             y0[b] = 0.01 * rng.standard_normal((n, n))
-    if w["eq"] == "ch":
+    if w["eq"] == "ch" and w.get("closures") == "cubic":
+        eq = P.CahnHilliard2DPeriodic(dom, 0.002, lambda c: c**3 - c, lambda c: 1 + c**2)
+    elif w["eq"] == "ch":
         eq = P.CahnHilliard2DPeriodic(dom, 0.002, REGSOL, C1MC)
     else:
         eq = P.AllenCahn2DPeriodic(dom, 0.002, lambda c: c**3 - c, lambda c: np.ones_like(c))

@@ -146,6 +146,9 @@ int pdeopt_ctx_create(int device, pdeopt_ctx** out) {
   if (e != hipSuccess) return fail(nullptr, PDEOPT_EHIP, "hipSetDevice: %s", hipGetErrorString(e));
   auto* ctx = new pdeopt_ctx();
   ctx->device = device;
+  int cus = 0;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0)
+    ctx->num_cus = cus;
   if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess ||
       (e = hipEventCreate(&ctx->ev0)) != hipSuccess || (e = hipEventCreate(&ctx->ev1)) != hipSuccess) {
     fail(nullptr, PDEOPT_EHIP, "stream/event creation: %s", hipGetErrorString(e));

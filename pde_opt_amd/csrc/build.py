@@ -28,6 +28,8 @@ HEADERS = [
     "stencil_tiled.hpp",
     "stencil_fused.hpp",
     "stencil_fused_ac.hpp",
+    "stencil_fused_pipe.hpp",
+    "stencil_fused_launch.hpp",
     "fft_lds.hpp",
     os.path.join(ROOT, "include", "pdeopt_hip.h"),
 ]

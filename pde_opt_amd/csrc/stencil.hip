@@ -12,6 +12,8 @@
 #include "stencil_tiled.hpp"
 #include "stencil_fused.hpp"
 #include "stencil_fused_ac.hpp"
+#include "stencil_fused_pipe.hpp"
+#include "stencil_fused_launch.hpp"
 
 namespace pdeopt {
 
@@ -267,7 +269,7 @@ int advance_explicit(pdeopt_ctx* ctx, int integrator, double t0, double dt, int6
     GraphKey key;
     memset(&key, 0, sizeof(key));  // padding bytes take part in the memcmp below
     key.integrator = integrator;
-    key.fused = fused;
+    key.fused = fused ? (int)(1 + ctx->opt_fuse_stages) : 0;
     key.dt = dt;
     key.Y = ctx->Y; key.TA = ctx->TA; key.TB = ctx->TB; key.ACC = ctx->ACC;
     key.ep = ctx->env_params_dev;

@@ -34,6 +34,15 @@ namespace pdeopt {
 
 enum { PAIR_12 = 0, PAIR_34 = 1 };
 
+// Phase-ablation hooks (TIMING ONLY, tools/ablate_pair.sh) are compiled in with -DPDEOPT_PAIR_ABLATE
+// (tools/mkvariant.sh): even as never-taken uniform branches they change hipcc's schedule of the
+// product kernel (96 -> 80 VGPRs, 3 % slower), so the shipped build does not carry them.
+#ifdef PDEOPT_PAIR_ABLATE
+#define PDEOPT_ABL(a, bit) ((a).dbg & (bit))
+#else
+#define PDEOPT_ABL(a, bit) false
+#endif
+
 template <typename T>
 struct PairArgs {
   const T* in;    // stage-A input (PAIR_12: y;  PAIR_34: TB)
@@ -48,6 +57,8 @@ struct PairArgs {
   Geo g;
   const EnvParams<T>* ep;
   ClosureSpec mu, mob;
+  int dbg;  // TIMING-ONLY ablation bits (PDEOPT_OPT_DEBUG_ABLATE): 1 skip mu passes, 2 skip marches, 4 skip ring,
+            // 8 skip the tile loads, 16 skip the stores
 };
 
 // flux through the face between cells a and b (b = a + 1 along the axis with spacing 1/rh):
@@ -107,22 +118,28 @@ __device__ __forceinline__ Vec flux_divergence(const ClosureSpec& ms, const T* _
   return k;
 }
 
-template <typename T, int RPT>
+template <typename T, int TX>
 constexpr size_t fused_lds_bytes() {
   constexpr int V = VecOf<T>::V;
   constexpr int HV = 4 / V;            // halo vectors per side (4 columns)
   constexpr int PV = kLanesPerRow + 2 * HV;
-  return ((size_t)(8 * RPT + 8) * PV * V + (size_t)(8 * RPT + 6) * PV * V + 4 * V) * sizeof(T);
+  return ((size_t)(TX + 8) * PV * V + (size_t)(TX + 6) * PV * V + 4 * V) * sizeof(T);
 }
 
-template <typename T, int CL, int PAIR, int RPT, bool RAGGED>
-__global__ __launch_bounds__(256) void stage_pair_kernel(const PairArgs<T> a, const int tiles_i,
-                                                         const int tiles_j, const int nblk,
-                                                         const int xcd_remap) {
+// NT threads = NT/32 thread rows of kLanesPerRow lanes, RPT tile rows each.  A taller tile re-evaluates
+// less (stage A on tile+2, mu on tile+3): 16 rows -> x1.46 mu_A, x1.33 k_A; 32 rows -> x1.26, x1.17.
+// Growing RPT pays for that in VGPRs (RPT 4: 132-156, 3 waves/SIMD); growing NT does not.
+#ifndef PDEOPT_PAIR_WAVES_ATTR
+#define PDEOPT_PAIR_WAVES_ATTR
+#endif
+template <typename T, int CL, int PAIR, int RPT, bool RAGGED, int NT>
+__global__ __launch_bounds__(NT) PDEOPT_PAIR_WAVES_ATTR void stage_pair_kernel(const PairArgs<T> a, const int tiles_i,
+                                                        const int tiles_j, const int nblk,
+                                                        const int xcd_remap) {
   using Vec = typename VecOf<T>::type;
   constexpr int V = VecOf<T>::V;
   constexpr int HV = 4 / V;
-  constexpr int TX = 8 * RPT;
+  constexpr int TX = (NT / kLanesPerRow) * RPT;
   constexpr int PV = kLanesPerRow + 2 * HV;
   constexpr int P = PV * V;
   constexpr int TY = kLanesPerRow * V;
@@ -156,7 +173,7 @@ __global__ __launch_bounds__(256) void stage_pair_kernel(const PairArgs<T> a, co
   constexpr int kRingRowVecs = kLanesPerRow + 2;
   constexpr int kRingTop = 4 * kRingRowVecs;
   constexpr int kRing = kRingTop + 2 * TX;
-  static_assert(kRing <= 256, "ring must fit one pass");
+  static_assert(kRing <= NT, "ring must fit one pass");
   int ring_r = 0, ring_cv = 0;  // tile row / LDS vector column
   const bool has_ring = tid < kRing;
   if (tid < kRingTop) {
@@ -204,14 +221,20 @@ __global__ __launch_bounds__(256) void stage_pair_kernel(const PairArgs<T> a, co
   // ---- P1: stage-A input, tile + 4
   constexpr int kLoadVecs = (TX + 8) * PV;
 #pragma unroll
-  for (int it = 0; it < (kLoadVecs + 255) / 256; ++it) {
-    const int idx = tid + it * 256;
+  for (int it = 0; it < (kLoadVecs + NT - 1) / NT; ++it) {
+    const int idx = tid + it * NT;
     if (idx < kLoadVecs) {
       const int row = idx / PV;
       const int cv = idx - row * PV;
       const int gi = wrap_row(i0 - 4 + row);
       const int gj = wrap_col(j0 - HV * V + cv * V);
-      *reinterpret_cast<Vec*>(sU + row * P + cv * V) = *reinterpret_cast<const Vec*>(in + (int64_t)gi * ld + gj);
+      if (PDEOPT_ABL(a, 8)) {
+        Vec f;
+        for (int e = 0; e < V; ++e) f[e] = T(0.5) + T(1e-4) * T(gj + e);
+        *reinterpret_cast<Vec*>(sU + row * P + cv * V) = f;
+      } else {
+        *reinterpret_cast<Vec*>(sU + row * P + cv * V) = *reinterpret_cast<const Vec*>(in + (int64_t)gi * ld + gj);
+      }
     }
   }
   __syncthreads();
@@ -220,12 +243,19 @@ __global__ __launch_bounds__(256) void stage_pair_kernel(const PairArgs<T> a, co
   auto mu_pass = [&](const int rm0, const int nrows) {
     const int nvec = nrows * PV;
     const int lane = tid & 63;
-    // uniform trip count (every lane takes part in the DPP shifts); lanes past the end recompute
-    // the last vector and do not store
 #pragma unroll 1
-    for (int base0 = 0; base0 < nvec; base0 += 256) {
+    for (int base0 = 0; base0 < nvec; base0 += NT) {
       const int idx_raw = base0 + tid;
+#ifdef PDEOPT_DPP_EXCHANGE
+      // uniform trip count (every lane takes part in the DPP shifts); lanes past the end recompute
+      // the last vector and do not store
       const int idx = idx_raw < nvec ? idx_raw : nvec - 1;
+#else
+      // a wave that lies entirely past the end leaves (mu passes are half of this kernel's VALU work
+      // and the last trip is only 40-90 % populated); a partly populated wave runs under its exec mask
+      if (idx_raw >= nvec) break;
+      const int idx = idx_raw;
+#endif
       const int rr = idx / PV;
       const int cv = idx - rr * PV;
       const int rm = rm0 + rr;
@@ -245,11 +275,15 @@ __global__ __launch_bounds__(256) void stage_pair_kernel(const PairArgs<T> a, co
       (void)lane;
 #endif
       Vec m;
+      if (PDEOPT_ABL(a, 1)) {
+        m = c + xp + xm + left + right;
+      } else {
 #pragma unroll
-      for (int e = 0; e < V; ++e) {
-        const T ym = (e == 0) ? left : c[e - 1];
-        const T yp = (e == V - 1) ? right : c[e + 1];
-        m[e] = eval_mu<T, CL>(a.mu, p.mu, c[e]) - kap * lap_at<T>(c[e], xp[e], xm[e], yp, ym, a.rhx2, a.rhy2);
+        for (int e = 0; e < V; ++e) {
+          const T ym = (e == 0) ? left : c[e - 1];
+          const T yp = (e == V - 1) ? right : c[e + 1];
+          m[e] = eval_mu<T, CL>(a.mu, p.mu, c[e]) - kap * lap_at<T>(c[e], xp[e], xm[e], yp, ym, a.rhx2, a.rhy2);
+        }
       }
       if (idx_raw < nvec) *reinterpret_cast<Vec*>(sMu + rm * P + cv * V) = m;
     }
@@ -330,7 +364,12 @@ __global__ __launch_bounds__(256) void stage_pair_kernel(const PairArgs<T> a, co
   Vec w_own[RPT], yown[RPT], w_ring;
   {
     Vec kA[RPT];
-    march(kA, yown);  // PAIR_12: the stage-A input IS y
+    if (PDEOPT_ABL(a, 2)) {
+#pragma unroll
+      for (int r = 0; r < RPT; ++r) kA[r] = yown[r] = *reinterpret_cast<const Vec*>(sU + (r0 + r + 4) * P + cvo * V);
+    } else {
+      march(kA, yown);  // PAIR_12: the stage-A input IS y
+    }
 #pragma unroll
     for (int r = 0; r < RPT; ++r) {
       if constexpr (PAIR == PAIR_12) {
@@ -344,7 +383,11 @@ __global__ __launch_bounds__(256) void stage_pair_kernel(const PairArgs<T> a, co
   }
   if (has_ring) {
     Vec uc;
-    const Vec kA = k_at(ring_r, ring_cv, &uc);
+    Vec kA;
+    if (PDEOPT_ABL(a, 4))
+      kA = uc = *reinterpret_cast<const Vec*>(sU + (ring_r + 4) * P + ring_cv * V);
+    else
+      kA = k_at(ring_r, ring_cv, &uc);
     if constexpr (PAIR == PAIR_12)
       w_ring = uc + a.aA * kA;
     else
@@ -364,10 +407,16 @@ __global__ __launch_bounds__(256) void stage_pair_kernel(const PairArgs<T> a, co
 
   // ---- P6: k_B, stage updates, stores
   Vec kB[RPT];
-  march(kB, nullptr);
+  if (PDEOPT_ABL(a, 2)) {
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) kB[r] = *reinterpret_cast<const Vec*>(sMu + (r0 + r + 3) * P + cvo * V);
+  } else {
+    march(kB, nullptr);
+  }
 #pragma unroll
   for (int r = 0; r < RPT; ++r) {
     if (!cell_ok(r)) continue;
+    if (PDEOPT_ABL(a, 16) && kB[r][0] != T(12345.678)) continue;
     const int64_t idx = pidx0 + r * ld;
     if constexpr (PAIR == PAIR_12) {
       *reinterpret_cast<Vec*>(a.out + idx) = yown[r] + a.aB * kB[r];
@@ -391,60 +440,32 @@ bool fused_supported(const pdeopt_ctx* ctx) {
 
 template <typename T, int CL, int PAIR, int RPT>
 int launch_pair_ac_inst(pdeopt_ctx* ctx, const PairArgs<T>& s);  // stencil_fused_ac.hpp
+template <typename T, int CL, int PAIR>
+int launch_pair_pipe_inst(pdeopt_ctx* ctx, const PairArgs<T>& s);  // stencil_fused_pipe.hpp
 
 template <typename T, int CL, int PAIR, int RPT>
 int launch_pair_inst(pdeopt_ctx* ctx, const PairArgs<T>& s) {
   if (ctx->prob.equation == PDEOPT_EQ_ALLEN_CAHN) return launch_pair_ac_inst<T, CL, PAIR, RPT>(ctx, s);
+  // CH: 2 rows per thread always; 32-row tiles (RPT == 4 on this dispatch axis) are 512-thread blocks
   constexpr int V = VecOf<T>::V;
+  constexpr int NT = RPT == 4 ? 512 : 256;
+  constexpr int TX = (NT / kLanesPerRow) * 2;
   const pdeopt_problem& p = ctx->prob;
-  const int tiles_i = (p.nx + 8 * RPT - 1) / (8 * RPT);
+  const int tiles_i = (p.nx + TX - 1) / TX;
   const int tiles_j = (p.ny + kLanesPerRow * V - 1) / (kLanesPerRow * V);
   const int64_t nblk64 = (int64_t)tiles_i * tiles_j * ctx->win_n;
   if (nblk64 > 0x7fffffffLL) return fail(ctx, PDEOPT_EINVAL, "too many tiles");
   const int nblk = (int)nblk64;
-  const size_t lds = fused_lds_bytes<T, RPT>();
-  const bool ragged = p.nx % (8 * RPT) != 0 || p.ny % (kLanesPerRow * V) != 0;
+  const size_t lds = fused_lds_bytes<T, TX>();
+  const bool ragged = p.nx % TX != 0 || p.ny % (kLanesPerRow * V) != 0;
   if (ragged)
-    hipLaunchKernelGGL((stage_pair_kernel<T, CL, PAIR, RPT, true>), dim3(nblk), dim3(256), lds, ctx->stream, s, tiles_i,
+    hipLaunchKernelGGL((stage_pair_kernel<T, CL, PAIR, 2, true, NT>), dim3(nblk), dim3(NT), lds, ctx->stream, s, tiles_i,
                        tiles_j, nblk, (nblk % 8 == 0) ? 1 : 0);
   else
-    hipLaunchKernelGGL((stage_pair_kernel<T, CL, PAIR, RPT, false>), dim3(nblk), dim3(256), lds, ctx->stream, s, tiles_i,
+    hipLaunchKernelGGL((stage_pair_kernel<T, CL, PAIR, 2, false, NT>), dim3(nblk), dim3(NT), lds, ctx->stream, s, tiles_i,
                        tiles_j, nblk, (nblk % 8 == 0) ? 1 : 0);
   PDEOPT_HIP_CHECK(ctx, hipGetLastError());
   return PDEOPT_OK;
-}
-
-template <typename T>
-int launch_pair(pdeopt_ctx* ctx, int pair, const void* in, const void* y, const void* acc, void* out,
-                void* acc_out, double aA, double bA, double aB, double bB) {
-  const pdeopt_problem& p = ctx->prob;
-  PairArgs<T> s{};
-  s.g = make_geo(ctx);
-  const int64_t woff = (int64_t)ctx->win_lo * s.g.bstride;
-  s.in = static_cast<const T*>(in) + woff;
-  s.y = y ? static_cast<const T*>(y) + woff : nullptr;
-  s.acc = acc ? static_cast<const T*>(acc) + woff : nullptr;
-  s.out = static_cast<T*>(out) + woff;
-  s.acc_out = acc_out ? static_cast<T*>(acc_out) + woff : nullptr;
-  s.aA = T(aA); s.bA = T(bA); s.aB = T(aB); s.bB = T(bB);
-  s.rhx = T(0.5 / (p.hx * p.hx)); s.rhy = T(0.5 / (p.hy * p.hy));
-  s.rhx2 = T(1.0 / (p.hx * p.hx)); s.rhy2 = T(1.0 / (p.hy * p.hy));
-  s.ep = static_cast<const EnvParams<T>*>(ctx->env_params_dev) + ctx->win_lo;
-  s.mu = ClosureSpec{p.mu.kind, p.mu.flags, p.mu.n};
-  s.mob = ClosureSpec{p.mob.kind, p.mob.flags, p.mob.n};
-  ctx->n_stage_launches++;
-  const int cl = classify_closures(p.mu, p.mob);
-  const int rpt = tiled_rpt(ctx);
-  char name[96];
-  snprintf(name, sizeof(name), "stage_pair<%s,%s,%s,rows%d>", sizeof(T) == 4 ? "f32" : "f64",
-           p.equation == PDEOPT_EQ_ALLEN_CAHN ? "AC" : "CH", cl == CL_LOGIT ? "logit" : "poly", 8 * rpt);
-  ctx->last_kernel = name;
-#define PDEOPT_PAIR_DISPATCH(CLV, PAIRV)                                             \
-  (rpt == 2 ? launch_pair_inst<T, CLV, PAIRV, 2>(ctx, s) : launch_pair_inst<T, CLV, PAIRV, 4>(ctx, s))
-  if (cl == CL_LOGIT)
-    return pair == PAIR_12 ? PDEOPT_PAIR_DISPATCH(CL_LOGIT, PAIR_12) : PDEOPT_PAIR_DISPATCH(CL_LOGIT, PAIR_34);
-  return pair == PAIR_12 ? PDEOPT_PAIR_DISPATCH(CL_POLY, PAIR_12) : PDEOPT_PAIR_DISPATCH(CL_POLY, PAIR_34);
-#undef PDEOPT_PAIR_DISPATCH
 }
 
 }  // namespace pdeopt

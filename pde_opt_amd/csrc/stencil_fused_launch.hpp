@@ -1,0 +1,53 @@
+// Host-side dispatch of the fused stage-pair kernels (included after every kernel header so that the
+// kernel templates are defined before their launch sites are instantiated).
+#pragma once
+
+#include "stencil_fused.hpp"
+#include "stencil_fused_ac.hpp"
+#include "stencil_fused_pipe.hpp"
+
+namespace pdeopt {
+
+template <typename T>
+int launch_pair(pdeopt_ctx* ctx, int pair, const void* in, const void* y, const void* acc, void* out,
+                void* acc_out, double aA, double bA, double aB, double bB) {
+  const pdeopt_problem& p = ctx->prob;
+  PairArgs<T> s{};
+  s.g = make_geo(ctx);
+  const int64_t woff = (int64_t)ctx->win_lo * s.g.bstride;
+  s.in = static_cast<const T*>(in) + woff;
+  s.y = y ? static_cast<const T*>(y) + woff : nullptr;
+  s.acc = acc ? static_cast<const T*>(acc) + woff : nullptr;
+  s.out = static_cast<T*>(out) + woff;
+  s.acc_out = acc_out ? static_cast<T*>(acc_out) + woff : nullptr;
+  s.aA = T(aA); s.bA = T(bA); s.aB = T(aB); s.bB = T(bB);
+  s.rhx = T(0.5 / (p.hx * p.hx)); s.rhy = T(0.5 / (p.hy * p.hy));
+  s.rhx2 = T(1.0 / (p.hx * p.hx)); s.rhy2 = T(1.0 / (p.hy * p.hy));
+  s.ep = static_cast<const EnvParams<T>*>(ctx->env_params_dev) + ctx->win_lo;
+  s.mu = ClosureSpec{p.mu.kind, p.mu.flags, p.mu.n};
+  s.mob = ClosureSpec{p.mob.kind, p.mob.flags, p.mob.n};
+  s.dbg = (int)ctx->opt_debug_ablate;
+  ctx->n_stage_launches++;
+  const int cl = classify_closures(p.mu, p.mob);
+  const int rpt = tiled_rpt(ctx);
+  char name[96];
+  snprintf(name, sizeof(name), "stage_pair<%s,%s,%s,rows%d>", sizeof(T) == 4 ? "f32" : "f64",
+           p.equation == PDEOPT_EQ_ALLEN_CAHN ? "AC" : "CH", cl == CL_LOGIT ? "logit" : "poly", 8 * rpt);
+  ctx->last_kernel = name;
+  if (p.equation == PDEOPT_EQ_CAHN_HILLIARD && rpt == 2 && ctx->opt_fuse_stages == 2) {
+    ctx->last_kernel += "+pipe";
+    if (cl == CL_LOGIT)
+      return pair == PAIR_12 ? launch_pair_pipe_inst<T, CL_LOGIT, PAIR_12>(ctx, s)
+                             : launch_pair_pipe_inst<T, CL_LOGIT, PAIR_34>(ctx, s);
+    return pair == PAIR_12 ? launch_pair_pipe_inst<T, CL_POLY, PAIR_12>(ctx, s)
+                           : launch_pair_pipe_inst<T, CL_POLY, PAIR_34>(ctx, s);
+  }
+#define PDEOPT_PAIR_DISPATCH(CLV, PAIRV)                                             \
+  (rpt == 2 ? launch_pair_inst<T, CLV, PAIRV, 2>(ctx, s) : launch_pair_inst<T, CLV, PAIRV, 4>(ctx, s))
+  if (cl == CL_LOGIT)
+    return pair == PAIR_12 ? PDEOPT_PAIR_DISPATCH(CL_LOGIT, PAIR_12) : PDEOPT_PAIR_DISPATCH(CL_LOGIT, PAIR_34);
+  return pair == PAIR_12 ? PDEOPT_PAIR_DISPATCH(CL_POLY, PAIR_12) : PDEOPT_PAIR_DISPATCH(CL_POLY, PAIR_34);
+#undef PDEOPT_PAIR_DISPATCH
+}
+
+}  // namespace pdeopt
