@@ -209,6 +209,13 @@ int pdeopt_reduce(pdeopt_ctx* ctx, int op, double* out_per_env);
  * [env_count][nx][ny] bytes -- a quarter (fp32) / an eighth (fp64) of the D2H of the raw field. */
 int pdeopt_observe_u8(pdeopt_ctx* ctx, double lo, double hi, int env_first, int env_count,
                       uint8_t* host_out);
+/* rl_utils.detect_vortices (pde_opt/rl_utils.py:19-84) on the resident GPE wavefunction: integer phase
+ * winding of every grid plaquette, |circulation| < tol * 2 pi and cells whose corner-averaged density
+ * is below amp_thresh (if > 0) suppressed.  host_counts is [env_count][3] = {num_vortices,
+ * total_topological_charge, abs_charge_count}; host_winding ([env_count][nx][ny] int32) may be NULL
+ * when only the counts are wanted (24 bytes per environment instead of the field). */
+int pdeopt_detect_vortices(pdeopt_ctx* ctx, double amp_thresh, double tol, int env_first, int env_count,
+                           int32_t* host_winding, int64_t* host_counts);
 
 /* ---- domain decomposition of one large field (BASELINE config 5; no reference counterpart) -----
  * With PDEOPT_OPT_HALO_LAYOUT = 4 a ctx holds one rank's tile.  Per RK4 substep the caller runs

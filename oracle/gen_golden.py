@@ -102,6 +102,7 @@ def load_reference():
         "pde_opt.numerics.symbolic.allen_cahn_sym", "pde_opt/numerics/symbolic/allen_cahn_sym.py"
     )
     ns.solvers = _load("pde_opt.numerics.solvers", "pde_opt/numerics/solvers.py")
+    ns.rl_utils = _load("pde_opt.rl_utils", "pde_opt/rl_utils.py")
     return ns
 
 
@@ -346,6 +347,29 @@ def main():
             sbm[f"{tag}/norm_grad_psi"] = np.asarray(eq.norm_grad_psi)
             sbm[f"{tag}/left_half"] = np.asarray(eq.left_half)
     np.savez_compressed(os.path.join(OUT, "sbm_cases.npz"), **sbm)
+
+    # ---- rl_utils.detect_vortices ------------------------------------
+    vort = {}
+    for tag, n, m, dtype in (("48x48_c128", 48, 48, np.complex128), ("40x64_c64", 40, 64, np.complex64)):
+        xs = (np.arange(n) + 0.5) - n / 2
+        ys = (np.arange(m) + 0.5) - m / 2
+        Xv, Yv = np.meshgrid(xs, ys, indexing="ij")
+        # a vortex (+1), an antivortex (-1) and a doubly quantised vortex (+2) on a Gaussian cloud + noise
+        psi = np.exp(-(Xv**2 + Yv**2) / (2 * (0.3 * n) ** 2)).astype(complex)
+        for (cx, cy, q) in ((-6.2, -4.9, 1), (7.3, 3.1, -1), (1.4, -9.6, 2)):
+            z = (Xv - cx) + 1j * (Yv - cy)
+            psi = psi * (z / np.sqrt(np.abs(z) ** 2 + 1.0)) ** abs(q) if q > 0 else psi * np.conj(z) / np.sqrt(np.abs(z) ** 2 + 1.0)
+        psi = psi + 1e-3 * (rng.standard_normal((n, m)) + 1j * rng.standard_normal((n, m)))
+        psi = psi.astype(dtype)
+        vort[f"{tag}/psi"] = psi
+        for amp, tol in ((0.0, 0.5), (0.02, 0.5), (0.0, 1.5)):
+            r = ref.rl_utils.detect_vortices(psi, amp_thresh=amp, tol=tol)
+            key = f"{tag}/amp{amp}_tol{tol}"
+            vort[f"{key}/winding"] = np.asarray(r["winding"])
+            vort[f"{key}/positions"] = np.asarray(r["positions"])
+            vort[f"{key}/charges"] = np.asarray(r["charges"])
+            vort[f"{key}/counts"] = np.array([r["num_vortices"], r["total_topological_charge"], r["abs_charge_count"]])
+    np.savez_compressed(os.path.join(OUT, "vortices.npz"), **vort)
 
     print("wrote goldens to", os.path.abspath(OUT))
     for f in sorted(os.listdir(OUT)):

@@ -248,6 +248,27 @@ def strang_step(b_terms, t0, y0, dt, A_term, dx, time_scale):
     return np.stack([psi.real, psi.imag], axis=-1)
 
 
+def detect_vortices(psi, amp_thresh=0.0, tol=0.5):
+    """Phase-circulation vortex census, pde_opt/rl_utils.py:19-84 (winding map and the three counts)."""
+    two_pi = 2.0 * np.pi
+
+    def wrap(x):  # rl_utils.py:14-16
+        return (x + np.pi) % two_pi - np.pi
+
+    theta = np.angle(psi)
+    dth_x = wrap(nb(theta, 1, 1) - theta)
+    dth_y = wrap(nb(theta, 1, 0) - theta)
+    circulation = dth_x + nb(dth_y, 1, 1) - nb(dth_x, 1, 0) - dth_y
+    n_float = circulation / two_pi
+    n_int = np.rint(n_float).astype(np.int32)
+    n_int = np.where(np.abs(n_float) >= tol, n_int, 0)
+    if amp_thresh > 0.0:
+        rho = np.abs(psi) ** 2
+        rho_cell = 0.25 * (rho + nb(rho, 1, 0) + nb(rho, 1, 1) + nb(nb(rho, 1, 0), 1, 1))
+        n_int = np.where(rho_cell >= amp_thresh, n_int, 0)
+    return n_int, int((n_int != 0).sum()), int(n_int.sum()), int(np.abs(n_int).sum())
+
+
 # Tsitouras 5(4) tableau (Ch. Tsitouras, Comput. Math. Appl. 62 (2011) 770-775).
 # diffrax.Tsit5 (third party) uses these published coefficients.
 _TS_C = (0.161, 0.327, 0.9, 0.9800255409045097, 1.0, 1.0)

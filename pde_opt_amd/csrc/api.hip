@@ -36,7 +36,8 @@ int ensure_buffer(pdeopt_ctx* ctx, void** p, size_t bytes) {
 namespace {
 
 void free_fields(pdeopt_ctx* ctx) {
-  void** bufs[] = {&ctx->Y, &ctx->TA, &ctx->TB, &ctx->ACC, &ctx->SNAP, &ctx->KS, &ctx->obs_dev, &ctx->env_params_dev};
+  void** bufs[] = {&ctx->Y, &ctx->TA, &ctx->TB, &ctx->ACC, &ctx->SNAP, &ctx->KS, &ctx->obs_dev, &ctx->vort_dev, &ctx->env_params_dev};
+  ctx->vort_cap = 0;
   for (void** b : bufs) {
     if (*b) (void)hipFree(*b);
     *b = nullptr;
@@ -488,6 +489,17 @@ int pdeopt_observe_u8(pdeopt_ctx* ctx, double lo, double hi, int env_first, int 
   if (ctx->prob.equation == PDEOPT_EQ_GPE) return fail(ctx, PDEOPT_EINVAL, "observe_u8 needs a real field");
   PDEOPT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   return observe_u8(ctx, lo, hi, env_first, env_count, host_out);
+}
+
+int pdeopt_detect_vortices(pdeopt_ctx* ctx, double amp_thresh, double tol, int env_first, int env_count,
+                           int32_t* host_winding, int64_t* host_counts) {
+  if (!ctx || !host_counts) return PDEOPT_EINVAL;
+  int rc = check_envs(ctx, env_first, env_count);
+  if (rc) return rc;
+  if (ctx->prob.equation != PDEOPT_EQ_GPE)
+    return fail(ctx, PDEOPT_EINVAL, "detect_vortices needs a complex (GPE) state");
+  PDEOPT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  return detect_vortices(ctx, amp_thresh, tol, env_first, env_count, host_winding, host_counts);
 }
 
 int pdeopt_tsit5_trial(pdeopt_ctx* ctx, double t, double dt, double rtol, double atol,

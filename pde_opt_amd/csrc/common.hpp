@@ -93,6 +93,8 @@ struct pdeopt_ctx {
   void* ACC = nullptr;
   void* SNAP = nullptr;
   void* obs_dev = nullptr;  // uint8 observation frames
+  void* vort_dev = nullptr; // vortex counters + winding map
+  size_t vort_cap = 0;
   void* KS = nullptr;  // slope scratch of the spectral-RHS stage path
   void* K[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // Tsit5 slopes
   bool tsit5_pending = false;
@@ -175,6 +177,8 @@ void* field_ptr(pdeopt_ctx* ctx, int field);
 // reduce.hip
 int reduce_state(pdeopt_ctx* ctx, int op, double* out);
 int observe_u8(pdeopt_ctx* ctx, double lo, double hi, int env_first, int env_count, void* host_out);
+int detect_vortices(pdeopt_ctx* ctx, double amp_thresh, double tol, int env_first, int env_count,
+                    int32_t* host_winding, int64_t* host_counts);
 // spectral.hip
 int advance_imex(pdeopt_ctx* ctx, double t0, double dt, int64_t n);
 int rhs_fourier(pdeopt_ctx* ctx, const void* in, void* out);

@@ -143,6 +143,112 @@ int observe_u8(pdeopt_ctx* ctx, double lo, double hi, int env_first, int env_cou
   return PDEOPT_OK;
 }
 
+// ------------------------------------------------------------------------------------------
+// Quantised vortices of a GPE wavefunction: phase circulation around every grid plaquette
+// (pde_opt/rl_utils.py:19-84 detect_vortices).  One thread per cell evaluates the four corner
+// phases and the four wrapped edge differences of ITS plaquette in the reference's order
+//   circulation(i,j) = dth_x(i,j) + dth_y(i,j+1) - dth_x(i+1,j) - dth_y(i,j)
+// with dth_x the wrapped difference along axis 1 and dth_y along axis 0 (rl_utils.py:48-56), rounds
+// it to an integer winding, applies the tol / density masks and adds to three per-environment
+// counters {cells with winding != 0, sum winding, sum |winding|}.
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ T wrap_to_pi(T x) {
+  // (x + pi) % (2 pi) - pi with numpy's sign-of-divisor modulo: result in [-pi, pi)  (rl_utils.py:14-16)
+  const T two_pi = T(6.283185307179586476925286766559);
+  const T pi = T(3.141592653589793238462643383279);
+  T r = fmod(x + pi, two_pi);
+  if (r < T(0)) r += two_pi;
+  return r - pi;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void vortex_kernel(const T* __restrict__ psi, int32_t* __restrict__ winding,
+                                                     long long* __restrict__ counts, int nx, int ny, T amp_thresh,
+                                                     T tol) {
+  const int b = blockIdx.z;
+  const int j = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int i = blockIdx.y * 4 + (threadIdx.x >> 6);
+  int n_int = 0;
+  if (i < nx && j < ny) {
+    const T* p = psi + (int64_t)b * nx * ny * 2;
+    const int i1 = (i + 1 == nx) ? 0 : i + 1, j1 = (j + 1 == ny) ? 0 : j + 1;
+    auto at = [&](int ii, int jj, T& re, T& im) {
+      re = p[((int64_t)ii * ny + jj) * 2];
+      im = p[((int64_t)ii * ny + jj) * 2 + 1];
+    };
+    T r00, m00, r01, m01, r10, m10, r11, m11;
+    at(i, j, r00, m00);
+    at(i, j1, r01, m01);
+    at(i1, j, r10, m10);
+    at(i1, j1, r11, m11);
+    const T t00 = atan2(m00, r00), t01 = atan2(m01, r01), t10 = atan2(m10, r10), t11 = atan2(m11, r11);
+    const T dx_ij = wrap_to_pi<T>(t01 - t00);    // dth_x(i, j)
+    const T dy_ij = wrap_to_pi<T>(t10 - t00);    // dth_y(i, j)
+    const T dy_ij1 = wrap_to_pi<T>(t11 - t01);   // dth_y(i, j+1)
+    const T dx_i1j = wrap_to_pi<T>(t11 - t10);   // dth_x(i+1, j)
+    const T circ = dx_ij + dy_ij1 - dx_i1j - dy_ij;
+    const T n_float = circ / T(6.283185307179586476925286766559);
+    n_int = (int)rint(n_float);
+    if (!(fabs(n_float) >= tol)) n_int = 0;
+    if (amp_thresh > T(0)) {
+      const T rho = T(0.25) * ((r00 * r00 + m00 * m00) + (r10 * r10 + m10 * m10) + (r01 * r01 + m01 * m01) +
+                                (r11 * r11 + m11 * m11));
+      if (!(rho >= amp_thresh)) n_int = 0;
+    }
+    if (winding) winding[((int64_t)b * nx + i) * ny + j] = n_int;
+  }
+  // block totals -> three atomics per block (vortex cells are rare: most blocks add nothing)
+  int c0 = n_int != 0, c1 = n_int, c2 = n_int < 0 ? -n_int : n_int;
+#pragma unroll
+  for (int s = 32; s > 0; s >>= 1) {
+    c0 += __shfl_down(c0, s, 64);
+    c1 += __shfl_down(c1, s, 64);
+    c2 += __shfl_down(c2, s, 64);
+  }
+  if ((threadIdx.x & 63) == 0 && (c0 | c2)) {
+    atomicAdd((unsigned long long*)&counts[b * 3 + 0], (unsigned long long)(long long)c0);
+    atomicAdd((unsigned long long*)&counts[b * 3 + 1], (unsigned long long)(long long)c1);
+    atomicAdd((unsigned long long*)&counts[b * 3 + 2], (unsigned long long)(long long)c2);
+  }
+}
+
+int detect_vortices(pdeopt_ctx* ctx, double amp_thresh, double tol, int env_first, int env_count,
+                    int32_t* host_winding, int64_t* host_counts) {
+  const pdeopt_problem& p = ctx->prob;
+  const size_t cells = (size_t)p.nx * p.ny;
+  const size_t wbytes = host_winding ? cells * env_count * sizeof(int32_t) : 0;
+  const size_t need = wbytes + (size_t)env_count * 3 * sizeof(long long);
+  if (ctx->vort_dev && ctx->vort_cap < need) {
+    PDEOPT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    (void)hipFree(ctx->vort_dev);
+    ctx->vort_dev = nullptr;
+  }
+  int rc = ensure_buffer(ctx, &ctx->vort_dev, need);
+  if (rc) return rc;
+  if (ctx->vort_cap < need) ctx->vort_cap = need;
+  long long* counts = reinterpret_cast<long long*>(ctx->vort_dev);
+  int32_t* wdev = host_winding ? reinterpret_cast<int32_t*>(counts + (size_t)env_count * 3) : nullptr;
+  PDEOPT_HIP_CHECK(ctx, hipMemsetAsync(counts, 0, (size_t)env_count * 3 * sizeof(long long), ctx->stream));
+  dim3 grid((p.ny + 63) / 64, (p.nx + 3) / 4, env_count), block(256);
+  if (grid.y > 65535u || grid.z > 65535u) return fail(ctx, PDEOPT_EINVAL, "grid too large for the vortex kernel");
+  const size_t off = (size_t)env_first * ctx->env_elems;
+  if (p.dtype == PDEOPT_F32)
+    hipLaunchKernelGGL(vortex_kernel<float>, grid, block, 0, ctx->stream, (const float*)ctx->Y + off, wdev, counts,
+                       p.nx, p.ny, (float)amp_thresh, (float)tol);
+  else
+    hipLaunchKernelGGL(vortex_kernel<double>, grid, block, 0, ctx->stream, (const double*)ctx->Y + off, wdev, counts,
+                       p.nx, p.ny, amp_thresh, tol);
+  PDEOPT_HIP_CHECK(ctx, hipGetLastError());
+  static_assert(sizeof(long long) == sizeof(int64_t), "counter width");
+  PDEOPT_HIP_CHECK(ctx, hipMemcpyAsync(host_counts, counts, (size_t)env_count * 3 * sizeof(int64_t),
+                                       hipMemcpyDeviceToHost, ctx->stream));
+  if (host_winding)
+    PDEOPT_HIP_CHECK(ctx, hipMemcpyAsync(host_winding, wdev, wbytes, hipMemcpyDeviceToHost, ctx->stream));
+  PDEOPT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return PDEOPT_OK;
+}
+
 int reduce_state(pdeopt_ctx* ctx, int op, double* out) {
   const int batch = ctx->prob.batch;
   const double n = (double)ctx->env_elems;

@@ -243,6 +243,19 @@ class HipEngine:
                                                 out.ctypes.data_as(C.c_void_p)))
         return out
 
+    def detect_vortices(self, amp_thresh: float = 0.0, tol: float = 0.5, env_first: int = 0,
+                        env_count: Optional[int] = None, want_winding: bool = True):
+        """Phase-winding census of the resident GPE state (rl_utils.detect_vortices on the GPU).
+        Returns ``(counts, winding)``: counts is (envs, 3) int64 = num_vortices, total charge,
+        sum |charge|; winding is (envs, nx, ny) int32 or None."""
+        n = self.batch - env_first if env_count is None else env_count
+        counts = np.zeros((n, 3), dtype=np.int64)
+        winding = np.empty((n,) + self.state_shape[:2], dtype=np.int32) if want_winding else None
+        self._check(self._lib.pdeopt_detect_vortices(
+            self._h, float(amp_thresh), float(tol), int(env_first), int(n),
+            winding.ctypes.data_as(C.c_void_p) if want_winding else None, counts.ctypes.data_as(C.c_void_p)))
+        return counts, winding
+
     def tsit5_trial(self, t: float, dt: float, rtol: float, atol: float) -> np.ndarray:
         err = np.empty(self.batch, dtype=np.float64)
         self._check(

@@ -117,3 +117,54 @@ def test_device_observation_uint8():
     assert diff.max() <= 1 and (diff > 0).mean() < 1e-3
     np.testing.assert_allclose(rewards, states.astype(np.float64).mean(axis=(1, 2)), rtol=1e-12)
     venv.close()
+
+
+def test_detect_vortices_against_reference_goldens(golden):
+    """rl_utils.detect_vortices on the GPU: winding map, positions, charges and counts equal the
+    reference's (pde_opt/rl_utils.py:19-84) -- integers, so exactly."""
+    from pde_opt_amd import rl_utils
+
+    z = golden("vortices.npz")
+    for tag in sorted({k.split("/")[0] for k in z.files}):
+        psi = z[f"{tag}/psi"]
+        for amp, tol in ((0.0, 0.5), (0.02, 0.5), (0.0, 1.5)):
+            key = f"{tag}/amp{amp}_tol{tol}"
+            r = rl_utils.detect_vortices(psi, amp_thresh=amp, tol=tol)
+            np.testing.assert_array_equal(r["winding"], z[key + "/winding"])
+            np.testing.assert_array_equal(r["positions"], z[key + "/positions"])
+            np.testing.assert_array_equal(r["charges"], z[key + "/charges"])
+            assert [r["num_vortices"], r["total_topological_charge"], r["abs_charge_count"]] == list(z[key + "/counts"])
+    np.testing.assert_allclose(rl_utils.density(psi), np.abs(psi) ** 2)
+
+
+def test_detect_vortices_batched_counts_only():
+    """counts for a batch of resident GPE states without moving the fields (24 bytes per environment)"""
+    from oracle import np_oracle as O
+
+    n, batch = 64, 5
+    rng = np.random.default_rng(3)
+    xs = (np.arange(n) + 0.5) - n / 2
+    X, Y = np.meshgrid(xs, xs, indexing="ij")
+    states, want = [], []
+    for b in range(batch):
+        psi = np.exp(-(X**2 + Y**2) / (2 * 18.0**2)).astype(complex)
+        for _ in range(b):  # b vortices at random places
+            cx, cy = rng.uniform(-12, 12, size=2)
+            z = (X - cx) + 1j * (Y - cy)
+            psi = psi * z / np.sqrt(np.abs(z) ** 2 + 1.0)
+        psi = (psi + 1e-3 * (rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n)))).astype(np.complex64)
+        states.append(np.stack([psi.real, psi.imag], axis=-1))
+        want.append(O.detect_vortices(psi, 0.01, 0.5)[1:])
+    eng = P.HipEngine()
+    from pde_opt_amd import _lib as L
+
+    eng.configure(equation=L.EQ_GPE, dtype=np.float32, nx=n, ny=n, batch=batch, hx=1.0, hy=1.0)
+    eng.set_state(np.stack(states))
+    counts, winding = eng.detect_vortices(0.01, 0.5, want_winding=False)
+    assert winding is None
+    np.testing.assert_array_equal(counts, np.array(want))
+    assert counts[:, 0].max() >= 3
+    counts2, w2 = eng.detect_vortices(0.01, 0.5, env_first=2, env_count=2)
+    np.testing.assert_array_equal(counts2, counts[2:4])
+    assert w2.shape == (2, n, n) and (np.count_nonzero(w2, axis=(1, 2)) == counts2[:, 0]).all()
+    eng.close()

@@ -201,3 +201,18 @@ def test_sbm_rhs_matches_reference_goldens(golden):
                                    SBM_FLUX(t), lh)
             tol = 1e-12 if want.dtype == np.float64 else 2e-5
             np.testing.assert_allclose(got, want, rtol=0, atol=tol * np.abs(want).max(), err_msg=f"{key} t={t}")
+
+
+def test_detect_vortices_matches_reference(golden):
+    """oracle restatement of rl_utils.detect_vortices (pde_opt/rl_utils.py:19-84) vs the reference's output"""
+    z = golden("vortices.npz")
+    tags = sorted({k.split("/")[0] for k in z.files})
+    assert len(tags) == 2
+    for tag in tags:
+        psi = z[f"{tag}/psi"]
+        for amp, tol in ((0.0, 0.5), (0.02, 0.5), (0.0, 1.5)):
+            key = f"{tag}/amp{amp}_tol{tol}"
+            w, num, total, abs_c = O.detect_vortices(psi, amp, tol)
+            np.testing.assert_array_equal(w, z[key + "/winding"])
+            np.testing.assert_array_equal([num, total, abs_c], z[key + "/counts"])
+    assert z["48x48_c128/amp0.0_tol0.5/counts"][0] > 0
