@@ -19,6 +19,7 @@
 
 #include "common.hpp"
 #include "fft_lds.hpp"
+#include "fft_reg.hpp"
 
 namespace pdeopt {
 
@@ -43,8 +44,20 @@ enum { ROW_FIRST = 0, ROW_MID = 1, ROW_JOIN = 2, ROW_LAST = 3 };
 
 template <typename T>
 __device__ __forceinline__ void sincos_t(T x, T* s, T* c);
+// fp32: hardware v_sin_f32 / v_cos_f32 (arguments in revolutions) behind a two-term reduction of
+// x / 2 pi, instead of ocml's sincosf (~45 VALU instructions per call plus a private-memory slow
+// path): the row pass evaluates one per cell and was VALU-bound on it.  Absolute error ~2e-7 on a
+// unit-modulus factor, below the fp32 rounding of the transforms around it; fp64 keeps sincos().
 template <>
-__device__ __forceinline__ void sincos_t<float>(float x, float* s, float* c) { sincosf(x, s, c); }
+__device__ __forceinline__ void sincos_t<float>(float x, float* s, float* c) {
+  const float c1 = 0.15915494f;        // fl(1 / 2 pi)
+  const float c2 = 6.4206383e-09f;     // 1 / 2 pi - c1
+  const float hi = x * c1;
+  const float lo = __builtin_fmaf(x, c1, -hi) + x * c2;
+  const float r = __builtin_amdgcn_fractf(hi) + lo;  // revolutions, |lo| tiny: sin / cos are 1-periodic in r
+  *s = __builtin_amdgcn_sinf(r);
+  *c = __builtin_amdgcn_cosf(r);
+}
 template <>
 __device__ __forceinline__ void sincos_t<double>(double x, double* s, double* c) { sincos(x, s, c); }
 template <typename T>
@@ -128,6 +141,71 @@ __global__ __launch_bounds__(256) void strang_row_kernel(Cx<T>* __restrict__ psi
   }
 }
 
+// The row pass with the transforms in registers (fft_reg.hpp): N/8 threads per row, 256/(N/8) rows per
+// workgroup; for N <= 512 a row lives in one wave and the pass has no s_barrier except the one of the
+// norm reduction.  Spectrum side: thread j holds the frequencies j + m N/8; real-space side: the cells
+// j + m N/8 -- both coalesced.  Same modes and arithmetic as strang_row_kernel.
+template <typename T, int N, int MODE>
+__global__ __launch_bounds__(256) void strang_row_reg_kernel(Cx<T>* __restrict__ psi, T* __restrict__ dens,
+                                                             const T* __restrict__ pot, int64_t pot_env_stride,
+                                                             const EnvParams<T>* __restrict__ ep,
+                                                             const Cx<T>* __restrict__ tw, T tr, T ti, int nx,
+                                                             double* __restrict__ partial) {
+  constexpr int TT = N / 8, F = 256 / TT, NP = fft_lds_pitch<N>();
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const int tid = threadIdx.x;
+  const int f = tid / TT, j = tid - f * TT;
+  Cx<T>* const seq = reinterpret_cast<Cx<T>*>(smem_raw) + f * NP;
+  const int64_t row = (int64_t)blockIdx.x * F + f;
+  Cx<T>* const g = psi + row * N;
+  Cx<T> v[8];
+  if constexpr (MODE == ROW_FIRST) {
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      v[m] = g[j + m * TT];
+      dens[row * N + j + m * TT] = v[m].re * v[m].re + v[m].im * v[m].im;
+    }
+  } else {
+#pragma unroll
+    for (int sl = 0; sl < 8; ++sl) v[sl] = g[reg_freq<N>(j, sl)];
+    reg_fft_dit<T, N, +1>(v, seq, tw, j);  // unnormalised inverse: 1/(nx ny) sits in the column multiplier
+    if constexpr (MODE == ROW_LAST) {
+#pragma unroll
+      for (int m = 0; m < 8; ++m) g[j + m * TT] = v[m];
+      return;
+    }
+    const int env = (int)(row / nx);
+    if constexpr (MODE == ROW_MID) {
+      const T kk = ep[env].gpe_k;
+      const T* vrow = pot ? pot + (int64_t)env * pot_env_stride + (row - (int64_t)env * nx) * N : nullptr;
+      double acc = 0.0;
+#pragma unroll
+      for (int m = 0; m < 8; ++m) {
+        const int n = j + m * TT;
+        const T w = (vrow ? vrow[n] : T(0)) + kk * dens[row * N + n];
+        // exp(-i w (tr + i ti)) = exp(w ti) (cos(w tr) - i sin(w tr))
+        T sn, cs;
+        sincos_t<T>(w * tr, &sn, &cs);
+        const T mag = (ti == T(0)) ? T(1) : exp_t<T>(w * ti);
+        v[m] = cmul(v[m], Cx<T>{mag * cs, -mag * sn});
+        acc += (double)v[m].re * (double)v[m].re + (double)v[m].im * (double)v[m].im;
+      }
+      __shared__ double red[4];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+      if ((tid & 63) == 0) red[tid >> 6] = acc;
+      __syncthreads();
+      if (tid == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+    } else {  // ROW_JOIN: the real-space field is psi0 of the next step
+#pragma unroll
+      for (int m = 0; m < 8; ++m) dens[row * N + j + m * TT] = v[m].re * v[m].re + v[m].im * v[m].im;
+    }
+  }
+  reg_fft_dif<T, N, -1>(v, seq, tw, j);
+#pragma unroll
+  for (int sl = 0; sl < 8; ++sl) g[reg_freq<N>(j, sl)] = v[sl];
+}
+
 // F consecutive columns (FFT along the strided axis) per workgroup: FFT_x -> * mult (* scale) -> IFFT_x
 template <typename T, int N, int F, bool SCALED>
 __global__ __launch_bounds__(1024) void strang_col_kernel(Cx<T>* __restrict__ psi, const Cx<T>* __restrict__ mult,
@@ -180,6 +258,52 @@ __global__ __launch_bounds__(1024) void strang_col_kernel(Cx<T>* __restrict__ ps
   }
 }
 
+// The column pass with the transforms in registers: C adjacent columns x N/8 threads per workgroup,
+// the column index fastest across lanes (C x 8 bytes contiguous per row: 128-byte segments at C = 16),
+// so the threads of one column sit in different waves and the exchanges use workgroup barriers.
+template <typename T, int N, int C, bool SCALED>
+__global__ __launch_bounds__(C* N / 8) void strang_col_reg_kernel(Cx<T>* __restrict__ psi,
+                                                                  const Cx<T>* __restrict__ mult,
+                                                                  const Cx<T>* __restrict__ tw, int ny,
+                                                                  const double* __restrict__ partial,
+                                                                  int blocks_per_env, double dx2) {
+  constexpr int TT = N / 8, NP = fft_lds_pitch<N>();
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const int tid = threadIdx.x;
+  const int j = tid / C, c = tid - j * C;
+  Cx<T>* const seq = reinterpret_cast<Cx<T>*>(smem_raw) + c * NP;
+  const int env = blockIdx.y;
+  const int col = blockIdx.x * C + c;
+  Cx<T>* const g = psi + (int64_t)env * N * ny + col;
+  Cx<T> v[8];
+#pragma unroll
+  for (int m = 0; m < 8; ++m) v[m] = g[(int64_t)(j + m * TT) * ny];
+  reg_fft_dif<T, N, -1, false>(v, seq, tw, j);
+  T scale = T(1);
+  if constexpr (SCALED) {
+    __shared__ double scale_sh;
+    if (tid < 64) {
+      double sum = 0.0;
+      for (int q = tid; q < blocks_per_env; q += 64) sum += partial[(int64_t)env * blocks_per_env + q];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) sum += __shfl_down(sum, o, 64);
+      if (tid == 0) scale_sh = 1.0 / sqrt(sum * dx2);
+    }
+    __syncthreads();
+    scale = (T)scale_sh;
+  }
+#pragma unroll
+  for (int sl = 0; sl < 8; ++sl) {
+    Cx<T> m = mult[(int64_t)reg_freq<N>(j, sl) * ny + col];
+    m.re *= scale;
+    m.im *= scale;
+    v[sl] = cmul(v[sl], m);
+  }
+  reg_fft_dit<T, N, +1, false>(v, seq, tw, j);
+#pragma unroll
+  for (int m = 0; m < 8; ++m) g[(int64_t)(j + m * TT) * ny] = v[m];
+}
+
 // sequences per 256-thread workgroup.  Measured on 128 x 512^2 c64: 16 -> 1036, 8 -> 1210, 4 -> 1312
 // env-steps/s: the pass is latency-bound (load -> 3 barrier-separated stages -> store), so more,
 // smaller workgroups per CU win over wider HBM segments on the column pass (neighbouring column
@@ -194,8 +318,11 @@ constexpr int rows_per_block() { return PDEOPT_FFT_ROWS; }
 #ifndef PDEOPT_FFT_COL_THREADS
 #define PDEOPT_FFT_COL_THREADS 1024
 #endif
+#ifndef PDEOPT_FFT_COLS
+#define PDEOPT_FFT_COLS 16
+#endif
 template <typename T>
-constexpr int cols_per_block() { return sizeof(T) == 4 ? 16 : 8; }
+constexpr int cols_per_block() { return sizeof(T) == 4 ? PDEOPT_FFT_COLS : PDEOPT_FFT_COLS / 2; }
 template <typename T, int N>
 size_t col_lds_bytes() { return ((size_t)cols_per_block<T>() * fft_lds_pitch<N>() + N) * sizeof(Cx<T>); }
 
@@ -210,15 +337,38 @@ int allow_lds(pdeopt_ctx* ctx, K kernel, size_t bytes) {
   return PDEOPT_OK;
 }
 
+// rows per workgroup of the row pass that is in use for this N (the column pass sums that many partials)
+template <typename T, int N>
+constexpr bool row_in_registers() { return N <= 512; }
+template <typename T, int N>
+constexpr int row_pass_rows() { return row_in_registers<T, N>() ? 256 / (N / 8) : rows_per_block<T>(); }
+
+template <typename T>
+int row_pass_rows_rt(int ny) { return ny <= 512 ? 256 / (ny / 8) : rows_per_block<T>(); }
+
 template <typename T, int N, int MODE>
 int launch_row(pdeopt_ctx* ctx, StrangFused& sf, double tr, double ti) {
-  constexpr int F = rows_per_block<T>();
   const pdeopt_problem& p = ctx->prob;
+  const AuxField& pot = ctx->aux[PDEOPT_AUX_GPE_POTENTIAL];
+  if constexpr (row_in_registers<T, N>()) {
+    constexpr int F = row_pass_rows<T, N>();
+    const size_t lds = (size_t)F * fft_lds_pitch<N>() * sizeof(Cx<T>);
+    auto kern = strang_row_reg_kernel<T, N, MODE>;
+    int rc = allow_lds(ctx, kern, lds);
+    if (rc) return rc;
+    const int blocks = (int)((int64_t)p.batch * p.nx / F);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, ctx->stream, (Cx<T>*)ctx->Y, (T*)sf.dens,
+                       (const T*)pot.dev, pot.per_env ? (int64_t)p.nx * p.ny : (int64_t)0,
+                       (const EnvParams<T>*)ctx->env_params_dev, (const Cx<T>*)sf.tw_y, (T)tr, (T)ti, p.nx,
+                       sf.partial);
+    PDEOPT_HIP_CHECK(ctx, hipGetLastError());
+    return PDEOPT_OK;
+  }
+  constexpr int F = rows_per_block<T>();
   const size_t lds = lds_bytes<T, N>();
   auto kern = strang_row_kernel<T, N, F, MODE>;
   int rc = allow_lds(ctx, kern, lds);
   if (rc) return rc;
-  const AuxField& pot = ctx->aux[PDEOPT_AUX_GPE_POTENTIAL];
   const int blocks = (int)((int64_t)p.batch * p.nx / F);
   hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, ctx->stream, (Cx<T>*)ctx->Y, (T*)sf.dens,
                      (const T*)pot.dev, pot.per_env ? (int64_t)p.nx * p.ny : (int64_t)0,
@@ -230,14 +380,26 @@ int launch_row(pdeopt_ctx* ctx, StrangFused& sf, double tr, double ti) {
 
 template <typename T, int N, bool SCALED>
 int launch_col(pdeopt_ctx* ctx, StrangFused& sf) {
-  constexpr int F = cols_per_block<T>();
   const pdeopt_problem& p = ctx->prob;
+  if constexpr (N <= 512) {
+    constexpr int C = cols_per_block<T>();
+    const size_t lds = (size_t)C * fft_lds_pitch<N>() * sizeof(Cx<T>);
+    auto kern = strang_col_reg_kernel<T, N, C, SCALED>;
+    int rc = allow_lds(ctx, kern, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL(kern, dim3(p.ny / C, p.batch), dim3(C * N / 8), lds, ctx->stream, (Cx<T>*)ctx->Y,
+                       (const Cx<T>*)sf.mult, (const Cx<T>*)sf.tw_x, p.ny, (const double*)sf.partial,
+                       p.nx / row_pass_rows_rt<T>(p.ny), ctx->strang_dx * ctx->strang_dx);
+    PDEOPT_HIP_CHECK(ctx, hipGetLastError());
+    return PDEOPT_OK;
+  }
+  constexpr int F = cols_per_block<T>();
   const size_t lds = col_lds_bytes<T, N>();
   auto kern = strang_col_kernel<T, N, F, SCALED>;
   int rc = allow_lds(ctx, kern, lds);
   if (rc) return rc;
   hipLaunchKernelGGL(kern, dim3(p.ny / F, p.batch), dim3(PDEOPT_FFT_COL_THREADS), lds, ctx->stream, (Cx<T>*)ctx->Y,
-                     (const Cx<T>*)sf.mult, (const Cx<T>*)sf.tw_x, p.ny, (const double*)sf.partial, p.nx / rows_per_block<T>(),
+                     (const Cx<T>*)sf.mult, (const Cx<T>*)sf.tw_x, p.ny, (const double*)sf.partial, p.nx / row_pass_rows_rt<T>(p.ny),
                      ctx->strang_dx * ctx->strang_dx);
   PDEOPT_HIP_CHECK(ctx, hipGetLastError());
   return PDEOPT_OK;
