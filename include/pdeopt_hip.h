@@ -147,8 +147,9 @@ typedef enum {
                                  environments so a group's working set stays in the 256 MiB
                                  Infinity Cache across stages and substeps (0 = auto, < 0 = whole
                                  batch in one sweep) */
-  PDEOPT_OPT_IMEX_LDS_FFT = 7,/* 1 = run the IMEX transforms through the LDS FFT passes of the Strang path
-                                 instead of rocFFT R2C/C2R (measured slower; default 0) */
+  PDEOPT_OPT_IMEX_LDS_FFT = 7,/* IMEX transforms: 0 = auto (the hand-written register/LDS FFT passes, two real
+                                 environments per complex field, for power-of-two sizes 64..1024; rocFFT
+                                 real<->hermitian plans otherwise), -1 = always rocFFT */
   PDEOPT_OPT_GRAPH = 6,       /* explicit integrators: replay the substep loop from a captured hipGraph:
                                  0 = auto (launch-bound problem sizes), 1 = always, -1 = never */
   PDEOPT_OPT_HALO_LAYOUT = 5, /* layout of the NEXT pdeopt_configure: 0 = periodic field (wrap by index),

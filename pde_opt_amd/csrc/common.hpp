@@ -115,7 +115,7 @@ struct pdeopt_ctx {
   int halo = 0;                  // halo width of the configured layout
   void* halo_scratch = nullptr;  // single-rank loop-back buffer for pack/unpack
   size_t halo_scratch_bytes = 0;
-  int64_t opt_imex_lds_fft = 0;  // 1: IMEX through the LDS FFT passes (slower than rocFFT R2C; kept for study)
+  int64_t opt_imex_lds_fft = 0;  // IMEX transforms: 0 auto (hand-written passes where the size is covered), -1 rocFFT
   int64_t opt_graph = 0;         // hipGraph replay of the substep loop: 0 auto (launch-bound sizes), 1 always, -1 never
   hipGraphExec_t graph_exec = nullptr;
   pdeopt::GraphKey graph_key{};

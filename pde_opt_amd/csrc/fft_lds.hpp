@@ -1,4 +1,6 @@
-// Power-of-two FFTs of length N held entirely in LDS (gfx950), radix 8 with a radix-4/2 tail.
+// Building blocks of the power-of-two FFTs (gfx950), radix 8 with a radix-4/2 tail: complex helpers,
+// small DFTs in registers, the radix plan, the digit-reversal index maps and the padded LDS addressing.
+// The transforms themselves are in fft_reg.hpp (butterflies in registers, exchanges through LDS).
 //
 // Why not rocFFT for the split-step: a Strang step is   ifft2(fft2(psi) E) -> pointwise -> ifft2(fft2(.) E)
 // (pde_opt/numerics/solvers.py:99-122).  With a library FFT every arrow is a pass over HBM (and the
@@ -7,13 +9,11 @@
 // the CU, a row pass does IFFT_y -> *exp(b tau) (+ norm partial sums) -> FFT_y, so a whole step is
 // 4 passes of 16 B/cell instead of 8 library passes + 4 pointwise kernels.
 //
-// Two in-place transforms over F sequences stored as s[f * NP + fft_lds_addr(pos)]:
-//   dif<SIGN>: natural order in  -> position p holds X[rev(p)]       (decimation in frequency)
-//   dit<SIGN>: position p holds x[rev(p)] on entry -> natural order out (decimation in time)
+// Geometry shared by the transforms (in-place decimation-in-frequency positions):
+//   dif: natural order in  -> position p holds X[rev(p)]          dit: the reverse
 // rev() is the mixed-radix digit reversal of the radix list (8, 8, ..., tail); pos_of() its inverse.
 // A pointwise spectral multiply between dif and dit therefore needs no reordering, and the global
 // side of every pass stays in natural order (coalesced) -- only LDS addresses are permuted.
-// Index algebra checked against numpy.fft in /tmp-style prototype (see tests/test_gpu_fft.py).
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -132,56 +132,6 @@ template <typename T, int SIGN>
 __device__ __forceinline__ Cx<T> twiddle(const Cx<T>* __restrict__ tw, int n) {
   const Cx<T> w = tw[n];
   return SIGN < 0 ? w : Cx<T>{w.re, -w.im};
-}
-
-template <typename T, int N, int F, int NP, int SIGN, int STAGE, int R, bool DIT>
-__device__ __forceinline__ void fft_stage(Cx<T>* __restrict__ s, const Cx<T>* __restrict__ tw, int tid) {
-  constexpr int Ns = FftPlan<N>::sublen(STAGE);
-  constexpr int S = Ns / R;
-  constexpr int per_fft = N / R;
-  constexpr int total = F * per_fft;
-#pragma unroll 1
-  for (int id = tid; id < total; id += (int)blockDim.x) {
-    const int f = id / per_fft, j = id - f * per_fft;
-    const int blk = j / S, jj = j - blk * S;
-    Cx<T>* seq = s + f * NP;
-    const int p0 = blk * Ns + jj;
-    Cx<T> v[R];
-#pragma unroll
-    for (int m = 0; m < R; ++m) v[m] = seq[fft_lds_addr(p0 + m * S)];
-    if constexpr (DIT && S > 1) {
-#pragma unroll
-      for (int q = 1; q < R; ++q) v[q] = cmul(v[q], twiddle<T, SIGN>(tw, jj * q * (N / Ns)));
-    }
-    dft_small<T, R, SIGN>(v);
-    if constexpr (!DIT && S > 1) {
-#pragma unroll
-      for (int q = 1; q < R; ++q) v[q] = cmul(v[q], twiddle<T, SIGN>(tw, jj * q * (N / Ns)));
-    }
-#pragma unroll
-    for (int m = 0; m < R; ++m) seq[fft_lds_addr(p0 + m * S)] = v[m];
-  }
-  __syncthreads();
-}
-
-template <typename T, int N, int F, int NP, int SIGN, bool DIT, int I>
-__device__ __forceinline__ void fft_run(Cx<T>* s, const Cx<T>* tw, int tid) {
-  using P = FftPlan<N>;
-  if constexpr (I < P::stages) {
-    constexpr int STAGE = DIT ? (P::stages - 1 - I) : I;
-    fft_stage<T, N, F, NP, SIGN, STAGE, P::radix(STAGE), DIT>(s, tw, tid);
-    fft_run<T, N, F, NP, SIGN, DIT, I + 1>(s, tw, tid);
-  }
-}
-
-// in-place transforms of F sequences (barrier after every stage; call with data already visible)
-template <typename T, int N, int F, int NP, int SIGN>
-__device__ __forceinline__ void fft_dif(Cx<T>* s, const Cx<T>* tw, int tid) {
-  fft_run<T, N, F, NP, SIGN, false, 0>(s, tw, tid);
-}
-template <typename T, int N, int F, int NP, int SIGN>
-__device__ __forceinline__ void fft_dit(Cx<T>* s, const Cx<T>* tw, int tid) {
-  fft_run<T, N, F, NP, SIGN, true, 0>(s, tw, tid);
 }
 
 }  // namespace pdeopt

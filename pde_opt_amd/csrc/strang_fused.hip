@@ -1,4 +1,5 @@
-// Strang split step with the FFTs held in LDS and the pointwise operators fused into the passes.
+// Strang split step (and the IMEX step) with hand-written FFTs -- butterflies in registers, exchanges
+// through LDS (fft_reg.hpp) -- and the pointwise operators fused into the passes.
 //
 // Reference step (pde_opt/numerics/solvers.py:99-122), tau = dt * time_scale, E = exp(A_term tau / 2):
 //   psi1 = ifft2(fft2(psi0) E);  b = -i (V + k |psi0|^2)   (gross_pitaevskii.py:67-75, PRE-half-step state)
@@ -67,111 +68,39 @@ __device__ __forceinline__ float exp_t<float>(float x) { return expf(x); }
 template <>
 __device__ __forceinline__ double exp_t<double>(double x) { return exp(x); }
 
-// F consecutive rows (FFT along the contiguous axis) per 256-thread workgroup
-template <typename T, int N, int F, int MODE>
-__global__ __launch_bounds__(256) void strang_row_kernel(Cx<T>* __restrict__ psi, T* __restrict__ dens,
-                                                         const T* __restrict__ pot, int64_t pot_env_stride,
-                                                         const EnvParams<T>* __restrict__ ep,
-                                                         const Cx<T>* __restrict__ tw_g, T tr, T ti, int nx,
-                                                         double* __restrict__ partial) {
-  constexpr int NP = fft_lds_pitch<N>();
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  Cx<T>* const s = reinterpret_cast<Cx<T>*>(smem_raw);
-  Cx<T>* const tw = s + F * NP;
-  const int tid = threadIdx.x;
-  const int64_t row0 = (int64_t)blockIdx.x * F;
-  Cx<T>* const g = psi + row0 * N;
-  for (int n = tid; n < N; n += 256) tw[n] = tw_g[n];
-  for (int idx = tid; idx < F * N; idx += 256) {
-    const int f = idx / N, k = idx - f * N;
-    const Cx<T> v = g[idx];
-    if constexpr (MODE == ROW_FIRST) {
-      s[f * NP + fft_lds_addr(k)] = v;
-      dens[row0 * N + idx] = v.re * v.re + v.im * v.im;
-    } else {
-      s[f * NP + fft_lds_addr(fft_pos_of<N>(k))] = v;  // natural-order spectrum -> the layout dit() consumes
-    }
-  }
-  __syncthreads();
-  if constexpr (MODE != ROW_FIRST) {
-    fft_dit<T, N, F, NP, +1>(s, tw, tid);  // unnormalised inverse: 1/(nx ny) sits in the column multiplier
-    if constexpr (MODE == ROW_LAST) {
-      for (int idx = tid; idx < F * N; idx += 256) {
-        const int f = idx / N, k = idx - f * N;
-        g[idx] = s[f * NP + fft_lds_addr(k)];
-      }
-      return;
-    }
-    const int env = (int)(row0 / nx);
-    if constexpr (MODE == ROW_MID) {
-      const T kk = ep[env].gpe_k;
-      const T* vrow = pot ? pot + (int64_t)env * pot_env_stride + (row0 - (int64_t)env * nx) * N : nullptr;
-      double acc = 0.0;
-      for (int idx = tid; idx < F * N; idx += 256) {
-        const int f = idx / N, k = idx - f * N;
-        const T w = (vrow ? vrow[idx] : T(0)) + kk * dens[row0 * N + idx];
-        // exp(-i w (tr + i ti)) = exp(w ti) (cos(w tr) - i sin(w tr))
-        T sn, cs;
-        sincos_t<T>(w * tr, &sn, &cs);
-        const T mag = (ti == T(0)) ? T(1) : exp_t<T>(w * ti);
-        const Cx<T> e{mag * cs, -mag * sn};
-        const Cx<T> r = cmul(s[f * NP + fft_lds_addr(k)], e);
-        s[f * NP + fft_lds_addr(k)] = r;
-        acc += (double)r.re * (double)r.re + (double)r.im * (double)r.im;
-      }
-      __shared__ double red[4];
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
-      if ((tid & 63) == 0) red[tid >> 6] = acc;
-      __syncthreads();
-      if (tid == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
-    } else {  // ROW_JOIN: the real-space field is psi0 of the next step
-      for (int idx = tid; idx < F * N; idx += 256) {
-        const int f = idx / N, k = idx - f * N;
-        const Cx<T> v = s[f * NP + fft_lds_addr(k)];
-        dens[row0 * N + idx] = v.re * v.re + v.im * v.im;
-      }
-    }
-    __syncthreads();
-  }
-  fft_dif<T, N, F, NP, -1>(s, tw, tid);
-  for (int idx = tid; idx < F * N; idx += 256) {
-    const int f = idx / N, k = idx - f * N;
-    g[idx] = s[f * NP + fft_lds_addr(fft_pos_of<N>(k))];
-  }
-}
-
 // The row pass with the transforms in registers (fft_reg.hpp): N/8 threads per row, 256/(N/8) rows per
 // workgroup; for N <= 512 a row lives in one wave and the pass has no s_barrier except the one of the
 // norm reduction.  Spectrum side: thread j holds the frequencies j + m N/8; real-space side: the cells
-// j + m N/8 -- both coalesced.  Same modes and arithmetic as strang_row_kernel.
+// j + m N/8 -- both coalesced.
 template <typename T, int N, int MODE>
 __global__ __launch_bounds__(256) void strang_row_reg_kernel(Cx<T>* __restrict__ psi, T* __restrict__ dens,
                                                              const T* __restrict__ pot, int64_t pot_env_stride,
                                                              const EnvParams<T>* __restrict__ ep,
                                                              const Cx<T>* __restrict__ tw, T tr, T ti, int nx,
                                                              double* __restrict__ partial) {
-  constexpr int TT = N / 8, F = 256 / TT, NP = fft_lds_pitch<N>();
+  using E = RegFft<T, N>;
+  constexpr int PTS = reg_default_pts<N>(), TT = E::TT, F = 256 / TT, NP = fft_lds_pitch<N>();
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const int tid = threadIdx.x;
   const int f = tid / TT, j = tid - f * TT;
   Cx<T>* const seq = reinterpret_cast<Cx<T>*>(smem_raw) + f * NP;
   const int64_t row = (int64_t)blockIdx.x * F + f;
   Cx<T>* const g = psi + row * N;
-  Cx<T> v[8];
+  Cx<T> v[PTS];
   if constexpr (MODE == ROW_FIRST) {
 #pragma unroll
-    for (int m = 0; m < 8; ++m) {
-      v[m] = g[j + m * TT];
-      dens[row * N + j + m * TT] = v[m].re * v[m].re + v[m].im * v[m].im;
+    for (int m = 0; m < PTS; ++m) {
+      const int n = E::natural(j, m);
+      v[m] = g[n];
+      dens[row * N + n] = v[m].re * v[m].re + v[m].im * v[m].im;
     }
   } else {
 #pragma unroll
-    for (int sl = 0; sl < 8; ++sl) v[sl] = g[reg_freq<N>(j, sl)];
-    reg_fft_dit<T, N, +1>(v, seq, tw, j);  // unnormalised inverse: 1/(nx ny) sits in the column multiplier
+    for (int sl = 0; sl < PTS; ++sl) v[sl] = g[E::freq(j, sl)];
+    E::template dit<+1>(v, seq, tw, j);  // unnormalised inverse: 1/(nx ny) sits in the column multiplier
     if constexpr (MODE == ROW_LAST) {
 #pragma unroll
-      for (int m = 0; m < 8; ++m) g[j + m * TT] = v[m];
+      for (int m = 0; m < PTS; ++m) g[E::natural(j, m)] = v[m];
       return;
     }
     const int env = (int)(row / nx);
@@ -180,8 +109,8 @@ __global__ __launch_bounds__(256) void strang_row_reg_kernel(Cx<T>* __restrict__
       const T* vrow = pot ? pot + (int64_t)env * pot_env_stride + (row - (int64_t)env * nx) * N : nullptr;
       double acc = 0.0;
 #pragma unroll
-      for (int m = 0; m < 8; ++m) {
-        const int n = j + m * TT;
+      for (int m = 0; m < PTS; ++m) {
+        const int n = E::natural(j, m);
         const T w = (vrow ? vrow[n] : T(0)) + kk * dens[row * N + n];
         // exp(-i w (tr + i ti)) = exp(w ti) (cos(w tr) - i sin(w tr))
         T sn, cs;
@@ -198,87 +127,38 @@ __global__ __launch_bounds__(256) void strang_row_reg_kernel(Cx<T>* __restrict__
       if (tid == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
     } else {  // ROW_JOIN: the real-space field is psi0 of the next step
 #pragma unroll
-      for (int m = 0; m < 8; ++m) dens[row * N + j + m * TT] = v[m].re * v[m].re + v[m].im * v[m].im;
+      for (int m = 0; m < PTS; ++m) dens[row * N + E::natural(j, m)] = v[m].re * v[m].re + v[m].im * v[m].im;
     }
   }
-  reg_fft_dif<T, N, -1>(v, seq, tw, j);
+  E::template dif<-1>(v, seq, tw, j);
 #pragma unroll
-  for (int sl = 0; sl < 8; ++sl) g[reg_freq<N>(j, sl)] = v[sl];
-}
-
-// F consecutive columns (FFT along the strided axis) per workgroup: FFT_x -> * mult (* scale) -> IFFT_x
-template <typename T, int N, int F, bool SCALED>
-__global__ __launch_bounds__(1024) void strang_col_kernel(Cx<T>* __restrict__ psi, const Cx<T>* __restrict__ mult,
-                                                         const Cx<T>* __restrict__ tw_g, int ny,
-                                                         const double* __restrict__ partial, int blocks_per_env,
-                                                         double dx2) {
-  constexpr int NP = fft_lds_pitch<N>();
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  Cx<T>* const s = reinterpret_cast<Cx<T>*>(smem_raw);
-  Cx<T>* const tw = s + F * NP;
-  const int tid = threadIdx.x;
-  const int env = blockIdx.y;
-  const int col0 = blockIdx.x * F;
-  Cx<T>* const g = psi + (int64_t)env * N * ny + col0;
-  for (int n = tid; n < N; n += (int)blockDim.x) tw[n] = tw_g[n];
-  for (int idx = tid; idx < F * N; idx += (int)blockDim.x) {
-    const int i = idx / F, c = idx - i * F;
-    s[c * NP + fft_lds_addr(i)] = g[(int64_t)i * ny + c];
-  }
-  __syncthreads();
-  fft_dif<T, N, F, NP, -1>(s, tw, tid);
-  T scale = T(1);
-  if constexpr (SCALED) {
-    // sum of the row pass's partial norms: first wave, fixed lane assignment + fixed shuffle tree
-    // (the same order in every workgroup of the environment -> one scale per environment, bitwise)
-    __shared__ double scale_sh;
-    if (tid < 64) {
-      double sum = 0.0;
-      for (int q = tid; q < blocks_per_env; q += 64) sum += partial[(int64_t)env * blocks_per_env + q];
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) sum += __shfl_down(sum, o, 64);
-      if (tid == 0) scale_sh = 1.0 / sqrt(sum * dx2);
-    }
-    __syncthreads();
-    scale = (T)scale_sh;
-  }
-  for (int idx = tid; idx < F * N; idx += (int)blockDim.x) {
-    const int p = idx / F, c = idx - p * F;
-    const int k = fft_rev<N>(p);
-    Cx<T> m = mult[(int64_t)k * ny + col0 + c];
-    m.re *= scale;
-    m.im *= scale;
-    s[c * NP + fft_lds_addr(p)] = cmul(s[c * NP + fft_lds_addr(p)], m);
-  }
-  __syncthreads();
-  fft_dit<T, N, F, NP, +1>(s, tw, tid);
-  for (int idx = tid; idx < F * N; idx += (int)blockDim.x) {
-    const int i = idx / F, c = idx - i * F;
-    g[(int64_t)i * ny + c] = s[c * NP + fft_lds_addr(i)];
-  }
+  for (int sl = 0; sl < PTS; ++sl) g[E::freq(j, sl)] = v[sl];
 }
 
 // The column pass with the transforms in registers: C adjacent columns x N/8 threads per workgroup,
 // the column index fastest across lanes (C x 8 bytes contiguous per row: 128-byte segments at C = 16),
 // so the threads of one column sit in different waves and the exchanges use workgroup barriers.
-template <typename T, int N, int C, bool SCALED>
-__global__ __launch_bounds__(C* N / 8) void strang_col_reg_kernel(Cx<T>* __restrict__ psi,
+template <typename T, int N, int C, int PTS, bool SCALED>
+__global__ __launch_bounds__(C* N / PTS) void strang_col_reg_kernel(Cx<T>* __restrict__ psi,
                                                                   const Cx<T>* __restrict__ mult,
                                                                   const Cx<T>* __restrict__ tw, int ny,
                                                                   const double* __restrict__ partial,
                                                                   int blocks_per_env, double dx2) {
-  constexpr int TT = N / 8, NP = fft_lds_pitch<N>();
+  using E = RegFft<T, N, PTS>;
+  constexpr int NP = fft_lds_pitch<N>();
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const int tid = threadIdx.x;
   const int j = tid / C, c = tid - j * C;
   Cx<T>* const seq = reinterpret_cast<Cx<T>*>(smem_raw) + c * NP;
   const int env = blockIdx.y;
-  const int col = blockIdx.x * C + c;
-  Cx<T>* const g = psi + (int64_t)env * N * ny + col;
-  Cx<T> v[8];
+  // uniform base pointers + 32-bit per-thread offsets: one VGPR per address instead of a 64-bit pair
+  // (the 16-point threads of the N = 1024 pass run at the 128-VGPR limit of a 1024-thread workgroup)
+  Cx<T>* const gb = psi + (int64_t)env * N * ny + blockIdx.x * C;
+  const Cx<T>* const mb = mult + blockIdx.x * C;
+  Cx<T> v[PTS];
 #pragma unroll
-  for (int m = 0; m < 8; ++m) v[m] = g[(int64_t)(j + m * TT) * ny];
-  reg_fft_dif<T, N, -1, false>(v, seq, tw, j);
+  for (int m = 0; m < PTS; ++m) v[m] = gb[E::natural(j, m) * ny + c];
+  E::template dif<-1, false>(v, seq, tw, j);
   T scale = T(1);
   if constexpr (SCALED) {
     __shared__ double scale_sh;
@@ -293,41 +173,35 @@ __global__ __launch_bounds__(C* N / 8) void strang_col_reg_kernel(Cx<T>* __restr
     scale = (T)scale_sh;
   }
 #pragma unroll
-  for (int sl = 0; sl < 8; ++sl) {
-    Cx<T> m = mult[(int64_t)reg_freq<N>(j, sl) * ny + col];
+  for (int sl = 0; sl < PTS; ++sl) {
+    Cx<T> m = mb[E::freq(j, sl) * ny + c];
     m.re *= scale;
     m.im *= scale;
     v[sl] = cmul(v[sl], m);
+    if constexpr (PTS > 8) {
+      if (sl % 4 == 3) __builtin_amdgcn_sched_barrier(0);
+    }
   }
-  reg_fft_dit<T, N, +1, false>(v, seq, tw, j);
+  E::template dit<+1, false>(v, seq, tw, j);
 #pragma unroll
-  for (int m = 0; m < 8; ++m) g[(int64_t)(j + m * TT) * ny] = v[m];
+  for (int m = 0; m < PTS; ++m) gb[E::natural(j, m) * ny + c] = v[m];
 }
 
-// sequences per 256-thread workgroup.  Measured on 128 x 512^2 c64: 16 -> 1036, 8 -> 1210, 4 -> 1312
-// env-steps/s: the pass is latency-bound (load -> 3 barrier-separated stages -> store), so more,
-// smaller workgroups per CU win over wider HBM segments on the column pass (neighbouring column
-// blocks run back to back and share their 128-byte lines through L2).
-#ifndef PDEOPT_FFT_ROWS
-#define PDEOPT_FFT_ROWS 4
-#endif
-template <typename T>
-constexpr int rows_per_block() { return PDEOPT_FFT_ROWS; }
-// the column pass wants 128-byte segments (16 fp32 / 8 fp64 complex columns) and hides its strided
-// loads with many waves per workgroup instead of many workgroups
-#ifndef PDEOPT_FFT_COL_THREADS
-#define PDEOPT_FFT_COL_THREADS 1024
-#endif
+// Column pass geometry.  128-byte segments (16 fp32 / 8 fp64 complex columns) are needed -- 8 columns
+// measured 6 % slower -- but nothing beyond: 32 columns x 16 points per thread (256-byte segments) and
+// 16 x 16 (half-size workgroups) both measured within 0.5 % of 16 x 8 on 128 x 512^2 c64.  The pass runs
+// at ~3 TB/s against ~5 TB/s for the row passes: its 4 KB-strided pieces are the limit, not its shape.
 #ifndef PDEOPT_FFT_COLS
 #define PDEOPT_FFT_COLS 16
 #endif
 template <typename T>
 constexpr int cols_per_block() { return sizeof(T) == 4 ? PDEOPT_FFT_COLS : PDEOPT_FFT_COLS / 2; }
+// points per thread of the column pass (0: 8 up to N = 512, 16 at N = 1024)
+#ifndef PDEOPT_FFT_COL_PTS
+#define PDEOPT_FFT_COL_PTS 0
+#endif
 template <typename T, int N>
-size_t col_lds_bytes() { return ((size_t)cols_per_block<T>() * fft_lds_pitch<N>() + N) * sizeof(Cx<T>); }
-
-template <typename T, int N>
-size_t lds_bytes() { return ((size_t)rows_per_block<T>() * fft_lds_pitch<N>() + N) * sizeof(Cx<T>); }
+constexpr int col_pts() { return PDEOPT_FFT_COL_PTS ? PDEOPT_FFT_COL_PTS : reg_default_pts<N>(); }
 
 template <typename K>
 int allow_lds(pdeopt_ctx* ctx, K kernel, size_t bytes) {
@@ -337,36 +211,19 @@ int allow_lds(pdeopt_ctx* ctx, K kernel, size_t bytes) {
   return PDEOPT_OK;
 }
 
-// rows per workgroup of the row pass that is in use for this N (the column pass sums that many partials)
+// rows per workgroup of the row pass (the column pass sums that many norm partials per environment)
 template <typename T, int N>
-constexpr bool row_in_registers() { return N <= 512; }
-template <typename T, int N>
-constexpr int row_pass_rows() { return row_in_registers<T, N>() ? 256 / (N / 8) : rows_per_block<T>(); }
-
+constexpr int row_pass_rows() { return 256 / RegFft<T, N>::TT; }
 template <typename T>
-int row_pass_rows_rt(int ny) { return ny <= 512 ? 256 / (ny / 8) : rows_per_block<T>(); }
+int row_pass_rows_rt(int ny) { return ny <= 512 ? 256 / (ny / 8) : 256 / (ny / 16); }
 
 template <typename T, int N, int MODE>
 int launch_row(pdeopt_ctx* ctx, StrangFused& sf, double tr, double ti) {
   const pdeopt_problem& p = ctx->prob;
   const AuxField& pot = ctx->aux[PDEOPT_AUX_GPE_POTENTIAL];
-  if constexpr (row_in_registers<T, N>()) {
-    constexpr int F = row_pass_rows<T, N>();
-    const size_t lds = (size_t)F * fft_lds_pitch<N>() * sizeof(Cx<T>);
-    auto kern = strang_row_reg_kernel<T, N, MODE>;
-    int rc = allow_lds(ctx, kern, lds);
-    if (rc) return rc;
-    const int blocks = (int)((int64_t)p.batch * p.nx / F);
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, ctx->stream, (Cx<T>*)ctx->Y, (T*)sf.dens,
-                       (const T*)pot.dev, pot.per_env ? (int64_t)p.nx * p.ny : (int64_t)0,
-                       (const EnvParams<T>*)ctx->env_params_dev, (const Cx<T>*)sf.tw_y, (T)tr, (T)ti, p.nx,
-                       sf.partial);
-    PDEOPT_HIP_CHECK(ctx, hipGetLastError());
-    return PDEOPT_OK;
-  }
-  constexpr int F = rows_per_block<T>();
-  const size_t lds = lds_bytes<T, N>();
-  auto kern = strang_row_kernel<T, N, F, MODE>;
+  constexpr int F = row_pass_rows<T, N>();
+  const size_t lds = (size_t)F * fft_lds_pitch<N>() * sizeof(Cx<T>);
+  auto kern = strang_row_reg_kernel<T, N, MODE>;
   int rc = allow_lds(ctx, kern, lds);
   if (rc) return rc;
   const int blocks = (int)((int64_t)p.batch * p.nx / F);
@@ -381,26 +238,15 @@ int launch_row(pdeopt_ctx* ctx, StrangFused& sf, double tr, double ti) {
 template <typename T, int N, bool SCALED>
 int launch_col(pdeopt_ctx* ctx, StrangFused& sf) {
   const pdeopt_problem& p = ctx->prob;
-  if constexpr (N <= 512) {
-    constexpr int C = cols_per_block<T>();
-    const size_t lds = (size_t)C * fft_lds_pitch<N>() * sizeof(Cx<T>);
-    auto kern = strang_col_reg_kernel<T, N, C, SCALED>;
-    int rc = allow_lds(ctx, kern, lds);
-    if (rc) return rc;
-    hipLaunchKernelGGL(kern, dim3(p.ny / C, p.batch), dim3(C * N / 8), lds, ctx->stream, (Cx<T>*)ctx->Y,
-                       (const Cx<T>*)sf.mult, (const Cx<T>*)sf.tw_x, p.ny, (const double*)sf.partial,
-                       p.nx / row_pass_rows_rt<T>(p.ny), ctx->strang_dx * ctx->strang_dx);
-    PDEOPT_HIP_CHECK(ctx, hipGetLastError());
-    return PDEOPT_OK;
-  }
-  constexpr int F = cols_per_block<T>();
-  const size_t lds = col_lds_bytes<T, N>();
-  auto kern = strang_col_kernel<T, N, F, SCALED>;
+  constexpr int C = cols_per_block<T>();
+  constexpr int PTS = col_pts<T, N>();
+  const size_t lds = (size_t)C * fft_lds_pitch<N>() * sizeof(Cx<T>);
+  auto kern = strang_col_reg_kernel<T, N, C, PTS, SCALED>;
   int rc = allow_lds(ctx, kern, lds);
   if (rc) return rc;
-  hipLaunchKernelGGL(kern, dim3(p.ny / F, p.batch), dim3(PDEOPT_FFT_COL_THREADS), lds, ctx->stream, (Cx<T>*)ctx->Y,
-                     (const Cx<T>*)sf.mult, (const Cx<T>*)sf.tw_x, p.ny, (const double*)sf.partial, p.nx / row_pass_rows_rt<T>(p.ny),
-                     ctx->strang_dx * ctx->strang_dx);
+  hipLaunchKernelGGL(kern, dim3(p.ny / C, p.batch), dim3(C * N / PTS), lds, ctx->stream, (Cx<T>*)ctx->Y,
+                     (const Cx<T>*)sf.mult, (const Cx<T>*)sf.tw_x, p.ny, (const double*)sf.partial,
+                     p.nx / row_pass_rows_rt<T>(p.ny), ctx->strang_dx * ctx->strang_dx);
   PDEOPT_HIP_CHECK(ctx, hipGetLastError());
   return PDEOPT_OK;
 }
@@ -427,7 +273,7 @@ int col_dispatch(pdeopt_ctx* ctx, StrangFused& sf) {
   }
 }
 
-bool size_ok(int n, bool f64) { return n == 64 || n == 128 || n == 256 || n == 512 || (n == 1024 && !f64); }
+bool size_ok(int n, bool) { return n == 64 || n == 128 || n == 256 || n == 512 || n == 1024; }
 
 template <typename T>
 int upload_table(pdeopt_ctx* ctx, void** dev, int n) {
@@ -502,72 +348,93 @@ int strang_fused_t(pdeopt_ctx* ctx, double dt, int64_t n) {
 // IMEX (SemiImplicitFourierSpectral.step, solvers.py:56-63) on the same LDS transforms:
 //   k = rhs(y)  (stencil kernel)  ->  row pass: FFT_y of the real k  ->  column pass:
 //   FFT_x -> * 1/((1 + A dt symbol) nx ny) -> IFFT_x  ->  row pass: IFFT_y, y += dt Re(.)
-// Full complex transforms of the real field like the reference (cahn_hilliard.py:72-73), so any
-// complex fourier_symbol is honoured as is; 4 kernels per substep.
+// Complex transforms carrying two real environments each (see imex_row_fwd_reg_kernel); the result is
+// Re ifft2(M fft2 f) for ANY complex fourier_symbol, as the reference's `.real` (solvers.py:63); 4 kernels
+// per substep.
 // ---------------------------------------------------------------------------------------------
 
-template <typename T, int N, int F>
-__global__ __launch_bounds__(256) void imex_row_fwd_kernel(const T* __restrict__ k, Cx<T>* __restrict__ c,
-                                                           const Cx<T>* __restrict__ tw_g) {
-  constexpr int NP = fft_lds_pitch<N>();
+// IMEX row passes on the register engine, two ENVIRONMENTS per complex sequence: the operator
+// f -> Re ifft2(M fft2 f) equals ifft2(M_h fft2 f) with the symmetrised multiplier
+// M_h(k) = (M(k) + conj M(-k)) / 2, which maps real fields to real fields, so by linearity
+//   z = f_a + i f_b   ->   ifft2(M_h fft2 z) = L f_a + i L f_b :
+// plain complex transforms move the bytes of a real<->hermitian plan (8 per cell and pass instead of
+// 16) with no hermitian packing.  An odd batch leaves the last sequence with a zero imaginary part.
+template <typename T, int N>
+__global__ __launch_bounds__(256) void imex_row_fwd_reg_kernel(const T* __restrict__ k, Cx<T>* __restrict__ c,
+                                                               const Cx<T>* __restrict__ tw, int nx, int batch) {
+  using E = RegFft<T, N>;
+  constexpr int PTS = reg_default_pts<N>(), TT = E::TT, F = 256 / TT, NP = fft_lds_pitch<N>();
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  Cx<T>* const s = reinterpret_cast<Cx<T>*>(smem_raw);
-  Cx<T>* const tw = s + F * NP;
   const int tid = threadIdx.x;
-  const int64_t o = (int64_t)blockIdx.x * F * N;
-  for (int n = tid; n < N; n += 256) tw[n] = tw_g[n];
-  for (int idx = tid; idx < F * N; idx += 256) {
-    const int f = idx / N, j = idx - f * N;
-    s[f * NP + fft_lds_addr(j)] = Cx<T>{k[o + idx], T(0)};
+  const int f = tid / TT, j = tid - f * TT;
+  Cx<T>* const seq = reinterpret_cast<Cx<T>*>(smem_raw) + f * NP;
+  const int64_t prow = (int64_t)blockIdx.x * F + f;  // row index in the pair-packed field
+  const int pair = (int)(prow / nx);
+  const int64_t r = prow - (int64_t)pair * nx;
+  const T* const ka = k + ((int64_t)(2 * pair) * nx + r) * N;
+  const bool has_b = 2 * pair + 1 < batch;
+  const T* const kb = ka + (int64_t)nx * N;
+  Cx<T> v[PTS];
+#pragma unroll
+  for (int m = 0; m < PTS; ++m) {
+    const int n = E::natural(j, m);
+    v[m] = Cx<T>{ka[n], has_b ? kb[n] : T(0)};
   }
-  __syncthreads();
-  fft_dif<T, N, F, NP, -1>(s, tw, tid);
-  for (int idx = tid; idx < F * N; idx += 256) {
-    const int f = idx / N, j = idx - f * N;
-    c[o + idx] = s[f * NP + fft_lds_addr(fft_pos_of<N>(j))];
-  }
+  E::template dif<-1>(v, seq, tw, j);
+  Cx<T>* const g = c + prow * N;
+#pragma unroll
+  for (int sl = 0; sl < PTS; ++sl) g[E::freq(j, sl)] = v[sl];
 }
 
-template <typename T, int N, int F>
-__global__ __launch_bounds__(256) void imex_row_inv_kernel(const Cx<T>* __restrict__ c, T* __restrict__ y,
-                                                           const Cx<T>* __restrict__ tw_g, T dt) {
-  constexpr int NP = fft_lds_pitch<N>();
+template <typename T, int N>
+__global__ __launch_bounds__(256) void imex_row_inv_reg_kernel(const Cx<T>* __restrict__ c, T* __restrict__ y,
+                                                               const Cx<T>* __restrict__ tw, T dt, int nx,
+                                                               int batch) {
+  using E = RegFft<T, N>;
+  constexpr int PTS = reg_default_pts<N>(), TT = E::TT, F = 256 / TT, NP = fft_lds_pitch<N>();
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  Cx<T>* const s = reinterpret_cast<Cx<T>*>(smem_raw);
-  Cx<T>* const tw = s + F * NP;
   const int tid = threadIdx.x;
-  const int64_t o = (int64_t)blockIdx.x * F * N;
-  for (int n = tid; n < N; n += 256) tw[n] = tw_g[n];
-  for (int idx = tid; idx < F * N; idx += 256) {
-    const int f = idx / N, j = idx - f * N;
-    s[f * NP + fft_lds_addr(fft_pos_of<N>(j))] = c[o + idx];
-  }
-  __syncthreads();
-  fft_dit<T, N, F, NP, +1>(s, tw, tid);
-  for (int idx = tid; idx < F * N; idx += 256) {
-    const int f = idx / N, j = idx - f * N;
-    y[o + idx] += dt * s[f * NP + fft_lds_addr(j)].re;  // y1 = y0 + dt Re ifft(...)   solvers.py:63
+  const int f = tid / TT, j = tid - f * TT;
+  Cx<T>* const seq = reinterpret_cast<Cx<T>*>(smem_raw) + f * NP;
+  const int64_t prow = (int64_t)blockIdx.x * F + f;
+  const int pair = (int)(prow / nx);
+  const int64_t r = prow - (int64_t)pair * nx;
+  const Cx<T>* const g = c + prow * N;
+  Cx<T> v[PTS];
+#pragma unroll
+  for (int sl = 0; sl < PTS; ++sl) v[sl] = g[E::freq(j, sl)];
+  E::template dit<+1>(v, seq, tw, j);
+  T* const ya = y + ((int64_t)(2 * pair) * nx + r) * N;
+  const bool has_b = 2 * pair + 1 < batch;
+  T* const yb = ya + (int64_t)nx * N;
+#pragma unroll
+  for (int m = 0; m < PTS; ++m) {
+    const int n = E::natural(j, m);
+    ya[n] += dt * v[m].re;  // y1 = y0 + dt Re ifft(...)   solvers.py:63
+    if (has_b) yb[n] += dt * v[m].im;
   }
 }
 
 template <typename T, int N>
 int imex_rows(pdeopt_ctx* ctx, StrangFused& sf, bool forward, double dt) {
-  constexpr int F = rows_per_block<T>();
+  using E = RegFft<T, N>;
+  constexpr int F = 256 / E::TT;
   const pdeopt_problem& p = ctx->prob;
-  const size_t lds = lds_bytes<T, N>();
-  const int blocks = (int)((int64_t)p.batch * p.nx / F);
+  const int npairs = (p.batch + 1) / 2;
+  const size_t lds = (size_t)F * fft_lds_pitch<N>() * sizeof(Cx<T>);
+  const int blocks = (int)((int64_t)npairs * p.nx / F);
   if (forward) {
-    auto kern = imex_row_fwd_kernel<T, N, F>;
+    auto kern = imex_row_fwd_reg_kernel<T, N>;
     int rc = allow_lds(ctx, kern, lds);
     if (rc) return rc;
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, ctx->stream, (const T*)ctx->TA, (Cx<T>*)sf.cwork,
-                       (const Cx<T>*)sf.tw_y);
+                       (const Cx<T>*)sf.tw_y, p.nx, p.batch);
   } else {
-    auto kern = imex_row_inv_kernel<T, N, F>;
+    auto kern = imex_row_inv_reg_kernel<T, N>;
     int rc = allow_lds(ctx, kern, lds);
     if (rc) return rc;
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, ctx->stream, (const Cx<T>*)sf.cwork, (T*)ctx->Y,
-                       (const Cx<T>*)sf.tw_y, (T)dt);
+                       (const Cx<T>*)sf.tw_y, (T)dt, p.nx, p.batch);
   }
   PDEOPT_HIP_CHECK(ctx, hipGetLastError());
   return PDEOPT_OK;
@@ -575,15 +442,16 @@ int imex_rows(pdeopt_ctx* ctx, StrangFused& sf, bool forward, double dt) {
 
 template <typename T, int N>
 int imex_cols(pdeopt_ctx* ctx, StrangFused& sf) {
-  constexpr int F = cols_per_block<T>();
+  constexpr int C = cols_per_block<T>();
+  constexpr int PTS = col_pts<T, N>();
   const pdeopt_problem& p = ctx->prob;
-  const size_t lds = col_lds_bytes<T, N>();
-  auto kern = strang_col_kernel<T, N, F, false>;  // FFT_x -> * multiplier -> IFFT_x, in place
+  const int npairs = (p.batch + 1) / 2;
+  const size_t lds = (size_t)C * fft_lds_pitch<N>() * sizeof(Cx<T>);
+  auto kern = strang_col_reg_kernel<T, N, C, PTS, false>;  // FFT_x -> * multiplier -> IFFT_x, in place
   int rc = allow_lds(ctx, kern, lds);
   if (rc) return rc;
-  hipLaunchKernelGGL(kern, dim3(p.ny / F, p.batch), dim3(PDEOPT_FFT_COL_THREADS), lds, ctx->stream,
-                     (Cx<T>*)sf.cwork, (const Cx<T>*)sf.imex_mult, (const Cx<T>*)sf.tw_x, p.ny,
-                     (const double*)nullptr, 0, 1.0);
+  hipLaunchKernelGGL(kern, dim3(p.ny / C, npairs), dim3(C * N / PTS), lds, ctx->stream, (Cx<T>*)sf.cwork,
+                     (const Cx<T>*)sf.imex_mult, (const Cx<T>*)sf.tw_x, p.ny, (const double*)nullptr, 0, 1.0);
   PDEOPT_HIP_CHECK(ctx, hipGetLastError());
   return PDEOPT_OK;
 }
@@ -600,7 +468,7 @@ int imex_fused_t(pdeopt_ctx* ctx, double dt, int64_t n) {
     if ((rc = upload_table<T>(ctx, &sf.tw_y, p.ny))) return rc;
   }
   if ((rc = ensure_buffer(ctx, &ctx->TA, ctx->total_bytes))) return rc;
-  if ((rc = ensure_buffer(ctx, &sf.cwork, (size_t)cells * p.batch * sizeof(Cx<T>)))) return rc;
+  if ((rc = ensure_buffer(ctx, &sf.cwork, (size_t)cells * ((p.batch + 1) / 2) * sizeof(Cx<T>)))) return rc;
   if (!sf.imex_valid || sf.imex_dt != dt || sf.imex_A != ctx->imex_A) {
     // 1 / ((1 + A dt fourier_symbol) nx ny): solvers.py:62-63 with the 1/N of the inverse folded in
     const AuxField& a = ctx->aux[PDEOPT_AUX_IMEX_SYMBOL];
@@ -612,11 +480,20 @@ int imex_fused_t(pdeopt_ctx* ctx, double dt, int64_t n) {
     } else {
       PDEOPT_HIP_CHECK(ctx, hipMemcpy(sym.data(), a.dev, (size_t)cells * 16, hipMemcpyDeviceToHost));
     }
-    std::vector<Cx<T>> m((size_t)cells);
+    // M(k) = 1 / ((1 + A dt symbol(k)) nx ny), then M_h(k) = (M(k) + conj M(-k)) / 2: the transforms carry
+    // two real environments per complex field (imex_row_fwd_reg_kernel), which needs the real-to-real form
+    std::vector<std::complex<double>> mfull((size_t)cells);
     const double inv_n = 1.0 / (double)cells;
-    for (int64_t i = 0; i < cells; ++i) {
-      const std::complex<double> v = inv_n / (1.0 + ctx->imex_A * dt * sym[i]);
-      m[i] = Cx<T>{(T)v.real(), (T)v.imag()};
+    for (int64_t i = 0; i < cells; ++i) mfull[i] = inv_n / (1.0 + ctx->imex_A * dt * sym[i]);
+    std::vector<Cx<T>> m((size_t)cells);
+    for (int kx = 0; kx < p.nx; ++kx) {
+      const int mx = (p.nx - kx) % p.nx;
+      for (int ky = 0; ky < p.ny; ++ky) {
+        const int my = (p.ny - ky) % p.ny;
+        const std::complex<double> v =
+            0.5 * (mfull[(size_t)kx * p.ny + ky] + std::conj(mfull[(size_t)mx * p.ny + my]));
+        m[(size_t)kx * p.ny + ky] = Cx<T>{(T)v.real(), (T)v.imag()};
+      }
     }
     if ((rc = ensure_buffer(ctx, &sf.imex_mult, (size_t)cells * sizeof(Cx<T>)))) return rc;
     PDEOPT_HIP_CHECK(ctx, hipMemcpyAsync(sf.imex_mult, m.data(), (size_t)cells * sizeof(Cx<T>), hipMemcpyHostToDevice, ctx->stream));
@@ -655,9 +532,9 @@ int imex_fused_t(pdeopt_ctx* ctx, double dt, int64_t n) {
 bool imex_fused_supported(const pdeopt_ctx* ctx) {
   const pdeopt_problem& p = ctx->prob;
   const bool f64 = p.dtype == PDEOPT_F64;
-  // Opt-in (PDEOPT_OPT_IMEX_LDS_FFT): measured on CH 1024^2 x 32 the full-complex LDS transforms run
-  // 408 env-steps/s against 496 for rocFFT's real<->hermitian plans, which move half the bytes.
-  if (ctx->opt_imex_lds_fft <= 0) return false;
+  // PDEOPT_OPT_IMEX_LDS_FFT: 0 auto (these transforms where the size is covered), -1 rocFFT real<->hermitian
+  // plans (csrc/spectral.hip), 1 as 0.  The "generic" kernel path also means the library pipeline.
+  if (ctx->opt_imex_lds_fft < 0 || ctx->opt_kernel_path == 1) return false;
   if (!size_ok(p.nx, f64) || !size_ok(p.ny, f64)) return false;
   return !ctx->aux[PDEOPT_AUX_IMEX_SYMBOL].per_env;
 }

@@ -74,8 +74,8 @@ def test_fused_zero_A_term_matches_committed_reference_behaviour():
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
-@pytest.mark.parametrize("shape", [(64, 64), (128, 256)])
-def test_fused_imex_vs_oracle_and_rocfft(dtype, shape):
+@pytest.mark.parametrize("shape,batch", [((64, 64), 2), ((128, 256), 3), ((1024, 128), 1), ((256, 1024), 2)])
+def test_fused_imex_vs_oracle_and_rocfft(dtype, shape, batch):
     from util import MOB, MU, std_domain
 
     rng = np.random.default_rng(40)
@@ -83,14 +83,12 @@ def test_fused_imex_vs_oracle_and_rocfft(dtype, shape):
     dom = std_domain(P, nx, ny)
     eq = P.CahnHilliard2DPeriodic(dom, 0.002, MU["regsol"], MOB["c1mc"])
     solver = P.SemiImplicitFourierSpectral(0.5, eq.fourier_symbol, eq.fft, eq.ifft)
-    y0 = np.clip(0.5 + 0.01 * rng.standard_normal((2, nx, ny)), 0.05, 0.95).astype(dtype)
+    y0 = np.clip(0.5 + 0.01 * rng.standard_normal((batch, nx, ny)), 0.05, 0.95).astype(dtype)
     n, dt = 6, 1e-6
     outs = {}
     for path in (L.PATH_AUTO, L.PATH_GENERIC):
         eng = P.HipEngine()
-        if path == L.PATH_AUTO:  # the LDS-FFT IMEX is opt-in (rocFFT R2C is faster)
-            eng._check(eng._lib.pdeopt_set_option(eng._h, L.OPT_IMEX_LDS_FFT, 1))
-        else:
+        if path != L.PATH_AUTO:  # "generic" = rocFFT's real<->hermitian plans
             eng.set_kernel_path(path)
         outs[path] = P.diffeqsolve(eq, solver, 0.0, n * dt, dt, y0, engine=eng).ys[-1]
         assert ("imex_fused_lds_fft" in eng.last_kernel) == (path == L.PATH_AUTO), eng.last_kernel
@@ -98,7 +96,7 @@ def test_fused_imex_vs_oracle_and_rocfft(dtype, shape):
     hx, hy = dom.dx
     sym = O.ch_fourier_symbol(nx, ny, hx, hy, 0.002)
     rhs = lambda t, u: O.ch_rhs_fd(u, hx, hy, 0.002, MU["regsol"], MOB["c1mc"])
-    for b in range(2):
+    for b in range(batch):
         ref = y0[b].astype(np.float64)
         for i in range(n):
             ref = O.imex_step(rhs, i * dt, ref, dt, 0.5, sym)
