@@ -45,6 +45,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.
 # algorithmic words per cell per substep; a word is one real scalar
 WORDS = {"rk4": 16, "euler": 2, "imex": 9, "strang": 22}  # strang: 88 B / 4 B at c64
 
+METRIC = "env-steps/sec (Cahn-Hilliard 1024^2 RK4, 100 substeps/env-step) & achieved HBM GB/s"
 WORKLOADS = {
     "ch_rk4_1024_f32": dict(eq="ch", n=1024, dtype=np.float32, integ="rk4", dt=2e-7, substeps=100, batch=32),
     # same kernel with the double-well closures (mu = c^3 - c, D = 1 + c^2: no log / rcp in mu)
@@ -244,7 +245,8 @@ def main():
             except Exception:
                 traffic = None
         line = {
-            "metric": "env-steps/sec (Cahn-Hilliard 1024^2 RK4, 100 substeps/env-step) & achieved HBM GB/s",
+            "metric": METRIC if args.workload == "ch_rk4_1024_f32" else
+                      f"env-steps/sec ({args.workload}, {substeps} substeps/env-step) & achieved HBM GB/s",
             "value": args.gpus * batch * args.steps / elapsed,
             "unit": "env-steps/s",
             "n_gpus": args.gpus,

@@ -1,0 +1,15 @@
+#!/bin/bash
+# End-of-round evidence run on the GPU box (via gpurun): full PMC profile of the headline workload,
+# kernel traces of the secondary workloads, and the default bench line.  Output under gpurun_out/round/.
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+cd $ROOT
+bash tools/profile_gpu.sh round/ch_rk4_1024_f32 > /dev/null 2>&1
+for w in ac_rk4_512_f32 ch_imex_1024_f32 gpe_strang_512_c64 ch_rk4_1024_f64; do
+  bash tools/trace_only.sh round/$w --workload $w > gpurun_out/round/${w}_trace_summary.txt 2>&1
+done
+cd $ROOT
+python bench.py > gpurun_out/round/bench.json 2> gpurun_out/round/bench.err
+for w in ac_rk4_512_f32 ch_imex_1024_f32 gpe_strang_512_c64 ch_rk4_1024_f64; do
+  python bench.py --workload $w --no-cpu-baseline --steps 5 --warmup 2 2>/dev/null | tail -1 > gpurun_out/round/bench_$w.json
+done
+tail -c 600 gpurun_out/round/bench.json
