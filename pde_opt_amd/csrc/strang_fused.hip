@@ -189,8 +189,9 @@ __global__ __launch_bounds__(C* N / PTS) void strang_col_reg_kernel(Cx<T>* __res
 
 // Column pass geometry.  128-byte segments (16 fp32 / 8 fp64 complex columns) are needed -- 8 columns
 // measured 6 % slower -- but nothing beyond: 32 columns x 16 points per thread (256-byte segments) and
-// 16 x 16 (half-size workgroups) both measured within 0.5 % of 16 x 8 on 128 x 512^2 c64.  The pass runs
-// at ~3 TB/s against ~5 TB/s for the row passes: its 4 KB-strided pieces are the limit, not its shape.
+// 16 x 16 (half-size workgroups) both measured within 0.5 % of 16 x 8 on 128 x 512^2 c64, and padding the
+// row pitch of the IMEX work field by 128 / 576 bytes changed nothing (0 % / -4 %).  The pass runs at
+// ~3 TB/s against ~5 TB/s for the row passes whatever its shape.
 #ifndef PDEOPT_FFT_COLS
 #define PDEOPT_FFT_COLS 16
 #endif
