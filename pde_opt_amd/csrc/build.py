@@ -29,6 +29,7 @@ HEADERS = [
     "stencil_fused.hpp",
     "stencil_fused_ac.hpp",
     "stencil_fused_pipe.hpp",
+    "stencil_fused_wave.hpp",
     "stencil_fused_launch.hpp",
     "fft_lds.hpp",
     os.path.join(ROOT, "include", "pdeopt_hip.h"),

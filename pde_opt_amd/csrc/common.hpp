@@ -121,7 +121,7 @@ struct pdeopt_ctx {
   pdeopt::GraphKey graph_key{};
   int64_t graph_launches_per_replay = 0;
   std::string graph_name;
-  int64_t opt_fuse_stages = 0;   // RK4 stage-pair fusion: 0 auto, -1 off, 1 one tile per workgroup, 2 persistent + LDS-DMA pipeline
+  int64_t opt_fuse_stages = 0;   // RK4 stage-pair fusion: 0 auto, -1 off, 1 one tile per workgroup, 2 persistent + LDS-DMA pipeline, 3 wave-local tiles
   int64_t opt_debug_ablate = 0;  // timing-only ablations, results are wrong when set
   int win_lo = 0, win_n = 0;  // environment window the stage launchers operate on
   double imex_A = 0.5, ts_re = 1.0, ts_im = 0.0, strang_dx = 1.0;

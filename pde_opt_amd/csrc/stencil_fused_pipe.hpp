@@ -53,18 +53,6 @@ __device__ __forceinline__ void glds16(const void* src, void* lds_wave_base) {
 #endif
 }
 
-// wave-uniform value -> scalar register (the compiler cannot prove uniformity through the tile decode)
-__device__ __forceinline__ int uniform_i(int x) { return __builtin_amdgcn_readfirstlane(x); }
-__device__ __forceinline__ float uniform_f(float x) {
-  return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x)));
-}
-__device__ __forceinline__ double uniform_f(double x) {
-  const long long b = __double_as_longlong(x);
-  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)b);
-  const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((unsigned long long)b >> 32));
-  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
-}
-
 template <typename T>
 struct PipeGeom {
   static constexpr int V = VecOf<T>::V;
