@@ -104,3 +104,46 @@ def test_fused_imex_vs_oracle_and_rocfft(dtype, shape, batch):
         tol = 1e-9 if dtype is np.float64 else 5e-4
         assert rel_l2(outs[L.PATH_AUTO][b].astype(np.float64) - y0[b], inc_ref) < tol
         assert rel_l2(outs[L.PATH_GENERIC][b].astype(np.float64) - y0[b], inc_ref) < tol
+
+
+def test_imex_full_size_properties():
+    """BASELINE config 3 size (1024^2 fp32, odd batch so one complex field carries a single environment):
+    the IMEX step conserves the mean (the k = 0 mode of the multiplier is 1 and the flux-form RHS sums
+    to zero), pairs do not leak into each other (each environment equals its solo run), and the batch is
+    linear in nothing it should not be (a constant field stays constant)."""
+    from util import MOB, MU, std_domain
+
+    rng = np.random.default_rng(7)
+    n = 1024
+    dom = std_domain(P, n, n)
+    eq = P.CahnHilliard2DPeriodic(dom, 0.002, MU["regsol"], MOB["c1mc"])
+    solver = P.SemiImplicitFourierSpectral(0.5, eq.fourier_symbol, eq.fft, eq.ifft)
+    y0 = np.clip(0.5 + 0.01 * rng.standard_normal((3, n, n)), 0.05, 0.95).astype(np.float32)
+    y0[2] = 0.37  # constant field: rhs = 0, must stay put bit for bit
+    eng = P.HipEngine()
+    y1 = P.diffeqsolve(eq, solver, 0.0, 20e-6, 1e-6, y0, engine=eng).ys[-1]
+    assert "imex_fused_lds_fft" in eng.last_kernel
+    assert np.isfinite(y1).all()
+    for b in range(2):
+        assert abs(y1[b].astype(np.float64).mean() - y0[b].astype(np.float64).mean()) < 2e-7
+        assert np.linalg.norm(y1[b] - y0[b]) > 0
+    np.testing.assert_array_equal(y1[2], y0[2])
+    solo = P.diffeqsolve(eq, solver, 0.0, 20e-6, 1e-6, y0[1], engine=eng).ys[-1]
+    # env 1 rode in the imaginary part of pair 0 above and in the real part here
+    assert rel_l2(y1[1].astype(np.float64) - y0[1], solo.astype(np.float64) - y0[1]) < 5e-4
+    eng.close()
+
+
+def test_strang_full_size_properties():
+    """BASELINE config 4 size (512^2 c64): real-time Strang steps keep the norm at 1 (renormalised every
+    step, with the reference's dx[0]^2 cell area, solvers.py:111) for every environment of the batch."""
+    dom, eq, y0, _ = _setup(512, 512)
+    solver = P.StrangSplitting(eq.A_term, eq.dx, eq.fft, eq.ifft, 1.0)
+    yb = np.stack([y0, y0[::-1].copy()]).astype(np.float32)
+    eng = P.HipEngine()
+    fwd = P.diffeqsolve(eq, solver, 0.0, 10e-3, 1e-3, yb, engine=eng).ys[-1]
+    assert eng.last_kernel == "strang_fused_lds_fft"
+    dens = fwd[..., 0].astype(np.float64) ** 2 + fwd[..., 1].astype(np.float64) ** 2
+    np.testing.assert_allclose(dens.sum(axis=(1, 2)) * dom.dx[0] ** 2, 1.0, rtol=2e-6)
+    assert rel_l2(fwd, yb) > 1e-3  # it moved
+    eng.close()
