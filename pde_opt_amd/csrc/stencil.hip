@@ -154,6 +154,25 @@ int launch_stage(pdeopt_ctx* ctx, const void* in, const void* y, void* out, void
   return launch_stage_t<double>(ctx, in, y, out, acc, a, b, out_mode, acc_mode);
 }
 
+// k = rhs(in) -> kout, and  next = y + sum_{j<n} c[j] K[j] + c[n] k  in the same pass (OUT_K_LC)
+template <typename T>
+int launch_stage_lc(pdeopt_ctx* ctx, const void* in, const void* y, void* kout, void* const* ks, const double* c,
+                    int n, void* next) {
+  StageArgs<T> s = make_args<T>(ctx, in, y, kout, nullptr, 0.0, 0.0, OUT_K_LC, ACC_NONE);
+  const int64_t woff = (int64_t)ctx->win_lo * s.g.bstride;
+  for (int j = 0; j < n; ++j) {
+    s.lc.k[j] = static_cast<const T*>(ks[j]) + woff;
+    s.lc.c[j] = T(c[j]);
+  }
+  s.lc.c[n] = T(c[n]);
+  s.lc.n = n;
+  s.lc.next = static_cast<T*>(next) + woff;
+  ctx->n_stage_launches++;
+  if (ctx->prob.derivs == PDEOPT_DERIVS_FOURIER) return launch_stage_fourier<T>(ctx, s, in, kout);
+  if (ctx->opt_kernel_path != 1 && tiled_supported<T>(ctx)) return launch_tiled<T>(ctx, s);
+  return launch_generic<T>(ctx, s);
+}
+
 int launch_pair_dt(pdeopt_ctx* ctx, int pair, const void* in, const void* y, const void* acc, void* out,
                    void* acc_out, double aA, double bA, double aB, double bB) {
   if (ctx->prob.dtype == PDEOPT_F32)
@@ -453,20 +472,29 @@ int tsit5_trial_t(pdeopt_ctx* ctx, double t, double dt, double rtol, double atol
     ctx->cur_t = t;
     if ((rc = launch_stage(ctx, ctx->Y, ctx->Y, ctx->K[0], nullptr, 0, 0, OUT_K, ACC_NONE))) return rc;
   }
-  for (int s = 0; s < 6; ++s) {
+  // stage 2 input from k1 alone (k1 is the previous step's k7 under FSAL, so nothing could form it earlier)
+  {
     LinComb<T> lc{};
     lc.y = (const T*)ctx->Y;
-    lc.n = s + 1;
-    for (int j = 0; j <= s; ++j) {
-      lc.k[j] = (const T*)ctx->K[j];
-      lc.c[j] = T(dt * kTsA[s][j]);
-    }
-    void* dst = (s == 5) ? ctx->TB : ctx->TA;  // the last stage input is the 5th-order solution
-    lc.out = (T*)dst;
+    lc.n = 1;
+    lc.k[0] = (const T*)ctx->K[0];
+    lc.c[0] = T(dt * kTsA[0][0]);
+    lc.out = (T*)ctx->TA;
     hipLaunchKernelGGL(lincomb_kernel<T>, dim3(blocks), dim3(256), 0, ctx->stream, lc, total);
-    ctx->cur_t = t + kTsC[s] * dt;
-    if ((rc = launch_stage(ctx, dst, dst, ctx->K[s + 1], nullptr, 0, 0, OUT_K, ACC_NONE))) return rc;
   }
+  // stages 2..6: k_s = f(in_s) and, in the same pass, in_{s+1} = y + dt sum_j a_{s+1,j} k_j  (ping-pong
+  // TA / TB; in_7 -- the 5th-order solution -- lands in TB).  Stage 7 evaluates k7 = f(in_7) for the
+  // error estimate and the next step's FSAL.  8 launches per step instead of 13.
+  for (int s = 1; s <= 5; ++s) {
+    void* in_s = (s & 1) ? ctx->TA : ctx->TB;
+    void* in_next = (s & 1) ? ctx->TB : ctx->TA;
+    double c[kMaxLc + 1];
+    for (int j = 0; j <= s; ++j) c[j] = dt * kTsA[s][j];
+    ctx->cur_t = t + kTsC[s - 1] * dt;
+    if ((rc = launch_stage_lc<T>(ctx, in_s, ctx->Y, ctx->K[s], ctx->K, c, s, in_next))) return rc;
+  }
+  ctx->cur_t = t + kTsC[5] * dt;
+  if ((rc = launch_stage(ctx, ctx->TB, ctx->TB, ctx->K[6], nullptr, 0, 0, OUT_K, ACC_NONE))) return rc;
   ctx->tsit5_pending = true;
   if (err) {
     double* part = nullptr;

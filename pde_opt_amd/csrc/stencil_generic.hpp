@@ -16,8 +16,19 @@
 namespace pdeopt {
 
 // out/acc update performed after k = rhs(in) has been formed for a cell
-enum { OUT_NONE = 0, OUT_K = 1, OUT_Y_PLUS_AK = 2, OUT_ACC_PLUS_BK = 3 };
+// OUT_K_LC: out = k, and next = y + sum_j c_j K_j + c_n k  (the input of the following stage of an
+// embedded Runge-Kutta method, formed where k is still in registers; Tsit5)
+enum { OUT_NONE = 0, OUT_K = 1, OUT_Y_PLUS_AK = 2, OUT_ACC_PLUS_BK = 3, OUT_K_LC = 4 };
 enum { ACC_NONE = 0, ACC_INIT = 1, ACC_ADD = 2 };
+
+constexpr int kMaxLc = 6;
+template <typename T>
+struct LcArgs {
+  const T* k[kMaxLc];  // earlier slopes
+  T c[kMaxLc + 1];     // their coefficients (already multiplied by dt); c[n] belongs to this stage's k
+  int n;
+  T* next;
+};
 
 template <typename T>
 struct StageArgs {
@@ -38,6 +49,7 @@ struct StageArgs {
   const T* mask;
   T tw_a, tw_b, tsrc;  // cos(theta(t)) on / off the mask, flux(t): scalars of this RHS evaluation
   ClosureSpec fe;
+  LcArgs<T> lc;  // OUT_K_LC only
   int out_mode, acc_mode;
   int dbg;  // timing ablations (PDEOPT_OPT_DEBUG_ABLATE): bit0 skip mu phase, bit1 skip flux phase
 };
@@ -155,6 +167,11 @@ __device__ __forceinline__ void stage_update(const StageArgs<T>& a, int64_t idx,
     a.out[idx] = a.y[idx] + a.a * k;
   } else if (a.out_mode == OUT_ACC_PLUS_BK) {
     a.out[idx] = a.acc[idx] + a.b * k;
+  } else if (a.out_mode == OUT_K_LC) {
+    a.out[idx] = k;
+    T r = a.y[idx];
+    for (int j = 0; j < a.lc.n; ++j) r += a.lc.c[j] * a.lc.k[j][idx];
+    a.lc.next[idx] = r + a.lc.c[a.lc.n] * k;
   }
   if (a.acc_mode == ACC_ADD) a.acc[idx] += a.b * k;
 }

@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256) void stage_tiled_kernel(const StageArgs<T> a, 
   constexpr int P = PV * V;  // LDS row pitch in elements
   constexpr bool kIsCH = (EQ == PDEOPT_EQ_CAHN_HILLIARD);
   constexpr bool kMobInPlace = kIsCH && (CL == CL_GENERIC);
-  constexpr bool kNeedY = (OUT_MODE == OUT_Y_PLUS_AK) || (ACC_MODE == ACC_INIT);
+  constexpr bool kNeedY = (OUT_MODE == OUT_Y_PLUS_AK) || (ACC_MODE == ACC_INIT) || (OUT_MODE == OUT_K_LC);
   constexpr bool kNeedAcc = (ACC_MODE == ACC_ADD) || (OUT_MODE == OUT_ACC_PLUS_BK);
 
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -300,6 +300,12 @@ __global__ __launch_bounds__(256) void stage_tiled_kernel(const StageArgs<T> a, 
     }
     if constexpr (ACC_MODE == ACC_INIT) *reinterpret_cast<Vec*>(a.acc + idx) = yv[r] + a.b * k;
     if constexpr (OUT_MODE == OUT_K) *reinterpret_cast<Vec*>(a.out + idx) = k;
+    if constexpr (OUT_MODE == OUT_K_LC) {
+      *reinterpret_cast<Vec*>(a.out + idx) = k;
+      Vec nxt = yv[r];
+      for (int j = 0; j < a.lc.n; ++j) nxt += a.lc.c[j] * *reinterpret_cast<const Vec*>(a.lc.k[j] + idx);
+      *reinterpret_cast<Vec*>(a.lc.next + idx) = nxt + a.lc.c[a.lc.n] * k;
+    }
     if constexpr (OUT_MODE == OUT_Y_PLUS_AK) *reinterpret_cast<Vec*>(a.out + idx) = yv[r] + a.a * k;
     if constexpr (OUT_MODE == OUT_ACC_PLUS_BK) *reinterpret_cast<Vec*>(a.out + idx) = av[r] + a.b * k;
     if constexpr (ACC_MODE == ACC_ADD) *reinterpret_cast<Vec*>(a.acc + idx) = av[r] + a.b * k;
@@ -361,6 +367,8 @@ int launch_tiled_modes(pdeopt_ctx* ctx, const StageArgs<T>& s) {
   const int om = s.out_mode, am = s.acc_mode;
   if (om == OUT_K && am == ACC_NONE)
     return launch_tiled_inst<T, EQ, CL, OUT_K, ACC_NONE, false>(ctx, s);
+  if (om == OUT_K_LC && am == ACC_NONE)
+    return launch_tiled_inst<T, EQ, CL, OUT_K_LC, ACC_NONE, false>(ctx, s);
   if (om == OUT_Y_PLUS_AK && am == ACC_NONE) {
     if constexpr (kCanReuseTile)
       if (in_is_y) return launch_tiled_inst<T, EQ, CL, OUT_Y_PLUS_AK, ACC_NONE, true>(ctx, s);

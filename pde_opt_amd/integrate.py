@@ -169,8 +169,8 @@ def _solve_adaptive(eng, equation, solver, t0, t1, dt0, saveat, c: PIDController
                 raise RuntimeError(f"max_steps={max_steps} reached at t={t}")
             break
         h = min(dt, t1 - t)
-        if qi < len(ts_req):
-            eng.snapshot()
+        if qi < len(ts_req) and ts_req[qi] <= t + h + 1e-14 * max(1.0, abs(t + h)):
+            eng.snapshot()  # a save point falls inside this step: keep the start state for the interpolation
         err = float(np.max(eng.tsit5_trial(t, h, c.rtol, c.atol)))
         keep = bool(err < 1.0)  # NaN error norm rejects
         inv = 1.0 / err if err > 0 and math.isfinite(err) else (np.inf if err == 0 else 0.0)
