@@ -55,7 +55,8 @@ typedef enum {
   PDEOPT_EQ_GPE = 3,             /* gross_pitaevskii.py:67-75 (Strang only)                         */
   /* smoothed-boundary variants: psi = domain.geometry.smooth is an aux field */
   PDEOPT_EQ_ALLEN_CAHN_SBM = 4,     /* allen_cahn.py:88-159    -R (mu_h - kappa/psi div(psi grad u) - wall sqrt(2 f)) */
-  PDEOPT_EQ_CAHN_HILLIARD_SBM = 5   /* cahn_hilliard.py:204-289 div(psi D grad(inner))/psi + source                  */
+  PDEOPT_EQ_CAHN_HILLIARD_SBM = 5,  /* cahn_hilliard.py:204-289 div(psi D grad(inner))/psi + source                  */
+  PDEOPT_EQ_CAHN_HILLIARD_3D = 6    /* cahn_hilliard.py:113-200: fields are [batch][nx][ny][nz] */
 } pdeopt_equation;
 
 /* which solver.step() is fused around it */
@@ -106,6 +107,9 @@ typedef struct {
   /* GPE (gross_pitaevskii.py:35-44): b = -i (V + k |psi|^2); V is an auxiliary field */
   double gpe_k;
   pdeopt_closure fe;  /* free-energy density f(u) of the smoothed-boundary equations (allen_cahn.py:112) */
+  int32_t nz;         /* third extent (contiguous axis) of the 3-D equations; 0 or 1 for 2-D problems */
+  int32_t reserved2;
+  double hz;
 } pdeopt_problem;
 
 /* auxiliary read-only fields (pdeopt_set_aux) */

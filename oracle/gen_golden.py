@@ -371,6 +371,20 @@ def main():
             vort[f"{key}/counts"] = np.array([r["num_vortices"], r["total_topological_charge"], r["abs_charge_count"]])
     np.savez_compressed(os.path.join(OUT, "vortices.npz"), **vort)
 
+    # ---- CahnHilliard3DPeriodic ------------------------------------------
+    c3 = {}
+    for (nx, ny, nz) in ((16, 12, 20), (32, 32, 32), (8, 64, 72)):
+        for dtype in (np.float64, np.float32):
+            dom3 = Domain((nx, ny, nz), ((-0.005 * nx, 0.005 * nx), (-0.005 * ny, 0.005 * ny), (0.0, 0.012 * nz)), "dimensionless")
+            u = np.clip(0.5 + 0.2 * rng.standard_normal((nx, ny, nz)), 0.05, 0.95).astype(dtype)
+            eq = ref.ch.CahnHilliard3DPeriodic(dom3, 0.002, MU["regsol"], MOB["c1mc"], derivs="fd")
+            tag = f"{nx}x{ny}x{nz}_{np.dtype(dtype).name}"
+            c3[f"{tag}/u"] = u
+            c3[f"{tag}/rhs"] = np.asarray(eq.rhs(u, 0.0))
+            if dtype is np.float64 and nx * ny * nz <= 4096:
+                c3[f"{tag}/symbol"] = np.asarray(eq.fourier_symbol)
+    np.savez_compressed(os.path.join(OUT, "ch3d_cases.npz"), **c3)
+
     print("wrote goldens to", os.path.abspath(OUT))
     for f in sorted(os.listdir(OUT)):
         print("  ", f, os.path.getsize(os.path.join(OUT, f)))

@@ -94,6 +94,19 @@ def ch_rhs_fd(u, hx, hy, kappa, mu_h, D):
     return div_face(Fx, hx, 0) + div_face(Fy, hy, 1)
 
 
+def ch3d_rhs_fd(u, hx, hy, hz, kappa, mu_h, D):
+    """3-D Cahn-Hilliard ``div(D(u) grad mu)``, cahn_hilliard.py:180-200 (7-point Laplacian
+    derivatives.py:15-21; the face operators of axis 2 are :34-36,49-51,64-66)."""
+    h = (hx, hy, hz)
+    lap = sum((nb(u, 1, ax) - 2 * u + nb(u, -1, ax)) / h[ax] ** 2 for ax in range(3))
+    mu = mu_h(u) - kappa * lap
+    Du = D(u)
+    out = 0.0
+    for ax in range(3):
+        out = out + div_face(avg_face(Du, ax) * grad_face(mu, h[ax], ax), h[ax], ax)
+    return out
+
+
 def ac_rhs_fd(u, hx, hy, kappa, mu_h, R):
     """Allen-Cahn ``-R(u) mu``, allen_cahn.py:81-84."""
     return -R(u) * chem_potential(u, hx, hy, kappa, mu_h)

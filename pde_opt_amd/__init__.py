@@ -18,6 +18,7 @@ from .numerics.equations import (
     BaseEquation,
     CahnHilliard2DPeriodic,
     CahnHilliard2DSmoothedBoundary,
+    CahnHilliard3DPeriodic,
     GPE2DTSControl,
 )
 from .numerics.functions import (
@@ -41,7 +42,7 @@ from .pde_model import PDEModel
 __all__ = [
     "PDEModel", "PDEEnv", "VectorPDEEnv", "HipEngine", "diffeqsolve", "Solution",
     "BaseEquation", "AllenCahn2DPeriodic", "CahnHilliard2DPeriodic", "AdvectionDiffusion2D", "GPE2DTSControl",
-    "AllenCahn2DSmoothedBoundary", "CahnHilliard2DSmoothedBoundary",
+    "AllenCahn2DSmoothedBoundary", "CahnHilliard2DSmoothedBoundary", "CahnHilliard3DPeriodic",
     "Domain", "LegendrePolynomialExpansion", "DiffusionLegendrePolynomials", "ChemicalPotentialLegendrePolynomials",
     "SemiImplicitFourierSpectral", "StrangSplitting", "Euler", "RK4", "Tsit5",
     "ConstantStepSize", "PIDController", "SaveAt",

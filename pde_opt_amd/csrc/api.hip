@@ -228,19 +228,28 @@ int pdeopt_configure(pdeopt_ctx* ctx, const pdeopt_problem* pr) {
   // parameters change.
   const bool same_shape = ctx->configured && pr->equation == ctx->prob.equation &&
                           pr->dtype == ctx->prob.dtype && pr->nx == ctx->prob.nx &&
-                          pr->ny == ctx->prob.ny && pr->batch == ctx->prob.batch &&
+                          pr->ny == ctx->prob.ny && pr->nz == ctx->prob.nz && pr->batch == ctx->prob.batch &&
                           (int)ctx->opt_halo == ctx->halo;
   if (!same_shape) free_fields(ctx);
   ctx->configured = false;
   if (pr->dtype != PDEOPT_F32 && pr->dtype != PDEOPT_F64)
     return fail(ctx, PDEOPT_EINVAL, "unknown dtype %d", pr->dtype);
-  if (pr->equation < PDEOPT_EQ_CAHN_HILLIARD || pr->equation > PDEOPT_EQ_CAHN_HILLIARD_SBM)
+  if (pr->equation < PDEOPT_EQ_CAHN_HILLIARD || pr->equation > PDEOPT_EQ_CAHN_HILLIARD_3D)
     return fail(ctx, PDEOPT_EINVAL, "unknown equation %d", pr->equation);
   if (pr->nx < 1 || pr->ny < 1 || pr->batch < 1)
     return fail(ctx, PDEOPT_EINVAL, "bad extents nx=%d ny=%d batch=%d", pr->nx, pr->ny, pr->batch);
   if (!(pr->hx > 0) || !(pr->hy > 0)) return fail(ctx, PDEOPT_EINVAL, "grid spacing must be > 0");
   const bool sbm = pr->equation == PDEOPT_EQ_ALLEN_CAHN_SBM || pr->equation == PDEOPT_EQ_CAHN_HILLIARD_SBM;
-  if (pr->equation == PDEOPT_EQ_CAHN_HILLIARD || pr->equation == PDEOPT_EQ_ALLEN_CAHN || sbm) {
+  const bool is3d = pr->equation == PDEOPT_EQ_CAHN_HILLIARD_3D;
+  if (is3d) {
+    if (pr->nz < 1 || !(pr->hz > 0)) return fail(ctx, PDEOPT_EINVAL, "3-D problem needs nz >= 1 and hz > 0");
+    if (pr->derivs != PDEOPT_DERIVS_FD)
+      return fail(ctx, PDEOPT_EINVAL, "CahnHilliard3DPeriodic: only derivs=\"fd\" has a kernel");
+    if (ctx->halo) return fail(ctx, PDEOPT_EINVAL, "the padded layout is 2-D only");
+  } else if (pr->nz > 1) {
+    return fail(ctx, PDEOPT_EINVAL, "nz=%d with a 2-D equation", pr->nz);
+  }
+  if (pr->equation == PDEOPT_EQ_CAHN_HILLIARD || pr->equation == PDEOPT_EQ_ALLEN_CAHN || sbm || is3d) {
     int rc;
     if ((rc = check_closure(ctx, pr->mu, "mu"))) return rc;
     if ((rc = check_closure(ctx, pr->mob, "mob"))) return rc;
@@ -263,6 +272,7 @@ int pdeopt_configure(pdeopt_ctx* ctx, const pdeopt_problem* pr) {
   if (ctx->halo && pr->equation != PDEOPT_EQ_CAHN_HILLIARD && pr->equation != PDEOPT_EQ_ALLEN_CAHN)
     return fail(ctx, PDEOPT_EINVAL, "the padded (domain-decomposition) layout covers CH / AC only");
   ctx->env_elems = (size_t)(pr->nx + 2 * ctx->halo) * (pr->ny + 2 * ctx->halo) * ctx->comps;
+  if (pr->equation == PDEOPT_EQ_CAHN_HILLIARD_3D) ctx->env_elems *= (size_t)pr->nz;
   ctx->total_bytes = ctx->env_elems * pr->batch * ctx->esize;
   int rc;
   if (!same_shape) {
@@ -301,8 +311,8 @@ int pdeopt_set_aux(pdeopt_ctx* ctx, int which, const void* host, int per_env) {
   if (which < 0 || which >= kNumAux) return fail(ctx, PDEOPT_EINVAL, "unknown aux field %d", which);
   PDEOPT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   const bool cplx = which == PDEOPT_AUX_IMEX_SYMBOL || which == PDEOPT_AUX_GPE_A_TERM;
-  const size_t bytes = (size_t)ctx->prob.nx * ctx->prob.ny * (cplx ? 2 : 1) * ctx->esize *
-                       (per_env ? (size_t)ctx->prob.batch : 1);
+  const size_t bytes = (size_t)ctx->prob.nx * ctx->prob.ny * (ctx->prob.nz > 1 ? ctx->prob.nz : 1) *
+                       (cplx ? 2 : 1) * ctx->esize * (per_env ? (size_t)ctx->prob.batch : 1);
   AuxField& a = ctx->aux[which];
   if (a.dev && a.bytes != bytes) {
     PDEOPT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
@@ -425,7 +435,7 @@ int pdeopt_advance(pdeopt_ctx* ctx, int integrator, double t0, double dt, int64_
         return fail(ctx, PDEOPT_EINVAL, "the GPE is integrated by Strang splitting only");
       return advance_explicit(ctx, integrator, t0, dt, n_substeps);
     case PDEOPT_INT_IMEX:
-      if (eq != PDEOPT_EQ_CAHN_HILLIARD && eq != PDEOPT_EQ_ALLEN_CAHN)
+      if (eq != PDEOPT_EQ_CAHN_HILLIARD && eq != PDEOPT_EQ_ALLEN_CAHN && eq != PDEOPT_EQ_CAHN_HILLIARD_3D)
         return fail(ctx, PDEOPT_EINVAL, "IMEX needs a periodic Cahn-Hilliard/Allen-Cahn equation");
       return advance_imex(ctx, t0, dt, n_substeps);
     case PDEOPT_INT_STRANG:

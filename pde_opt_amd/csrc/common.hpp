@@ -44,6 +44,7 @@ struct Geo {
   int64_t off;      // element offset of cell (0,0) inside one environment's array
   int64_t bstride;  // elements between environments
   int periodic;     // 1: wrap indices; 0: read halo cells at i in [-2, nx+1], j in [-2, ny+1]
+  int nz;           // 3-D equations: extent of the contiguous axis (1 otherwise)
 };
 
 struct AuxField {
@@ -144,6 +145,8 @@ inline Geo make_geo(const pdeopt_ctx* ctx) {
   g.off = (int64_t)h * g.ld + h;
   g.bstride = (int64_t)(ctx->prob.nx + 2 * h) * g.ld;
   g.periodic = h == 0 ? 1 : 0;
+  g.nz = ctx->prob.nz > 1 ? ctx->prob.nz : 1;
+  if (g.nz > 1) g.bstride *= g.nz;  // [nx][ny][nz], no halo layout in 3-D
   return g;
 }
 

@@ -100,12 +100,14 @@ int ensure_real_plans(pdeopt_ctx* ctx) {
   Spectral& sp = *ctx->spectral;
   if (sp.r2c) return PDEOPT_OK;
   const pdeopt_problem& p = ctx->prob;
-  size_t lengths[2];
+  size_t lengths[3];
   size_t dims = 0;
+  if (p.nz > 1) lengths[dims++] = (size_t)p.nz;  // 3-D equations: z is the contiguous axis
   if (p.ny > 1) lengths[dims++] = (size_t)p.ny;
   if (p.nx > 1) lengths[dims++] = (size_t)p.nx;
   if (dims == 0) lengths[dims++] = 1;
-  sp.half_cells = (int64_t)(lengths[0] / 2 + 1) * (dims > 1 ? (int64_t)lengths[1] : 1);
+  sp.half_cells = (int64_t)(lengths[0] / 2 + 1);
+  for (size_t d = 1; d < dims; ++d) sp.half_cells *= (int64_t)lengths[d];
   const rocfft_precision prec =
       p.dtype == PDEOPT_F32 ? rocfft_precision_single : rocfft_precision_double;
   PDEOPT_FFT_CHECK(ctx, rocfft_plan_create(&sp.r2c, rocfft_placement_notinplace,
@@ -284,7 +286,7 @@ int upload_mult(pdeopt_ctx* ctx, const std::vector<std::complex<double>>& m) {
 // host copy of a complex aux field as complex<double>
 int fetch_complex_aux(pdeopt_ctx* ctx, int which, std::vector<std::complex<double>>& out) {
   const AuxField& a = ctx->aux[which];
-  const size_t cells = (size_t)ctx->prob.nx * ctx->prob.ny;
+  const size_t cells = (size_t)ctx->prob.nx * ctx->prob.ny * (ctx->prob.nz > 1 ? ctx->prob.nz : 1);
   out.resize(cells);
   if (a.per_env) return fail(ctx, PDEOPT_EINVAL, "spectral aux fields must be shared across the batch");
   if (ctx->prob.dtype == PDEOPT_F32) {
@@ -314,7 +316,8 @@ template <typename T>
 int imex_t(pdeopt_ctx* ctx, double dt, int64_t n) {
   Spectral& sp = *ctx->spectral;
   const pdeopt_problem& p = ctx->prob;
-  const int64_t cells = (int64_t)p.nx * p.ny;
+  const int nzz = p.nz > 1 ? p.nz : 1;
+  const int64_t cells = (int64_t)p.nx * p.ny * nzz;
   const int64_t total = cells * p.batch;
   int rc;
   if ((rc = ensure_real_plans(ctx))) return rc;
@@ -325,17 +328,23 @@ int imex_t(pdeopt_ctx* ctx, double dt, int64_t n) {
     std::vector<std::complex<double>> sym;
     if ((rc = fetch_complex_aux(ctx, PDEOPT_AUX_IMEX_SYMBOL, sym))) return rc;
     const double inv_n = 1.0 / (double)cells;
-    auto m = [&](int i, int j) { return inv_n / (1.0 + ctx->imex_A * dt * sym[(size_t)i * p.ny + j]); };
+    const int n3[3] = {p.nx, p.ny, nzz};
+    auto m = [&](int i, int j, int k) {
+      return inv_n / (1.0 + ctx->imex_A * dt * sym[((size_t)i * p.ny + j) * nzz + k]);
+    };
     std::vector<C2<T>> h((size_t)hc);
-    // half-spectrum layout [slow][fast/2+1]; the halved (fastest non-trivial) axis is y unless ny == 1
-    const bool y_fast = p.ny > 1;
-    const int nfast = y_fast ? p.ny : p.nx, nslow = y_fast ? p.nx : 1, nh = nfast / 2 + 1;
-    for (int sidx = 0; sidx < nslow; ++sidx)
-      for (int f = 0; f < nh; ++f) {
-        const int i = y_fast ? sidx : f, j = y_fast ? f : 0;
-        const std::complex<double> v = 0.5 * (m(i, j) + std::conj(m((p.nx - i) % p.nx, (p.ny - j) % p.ny)));
-        h[(size_t)sidx * nh + f] = C2<T>{(T)v.real(), (T)v.imag()};
-      }
+    // half-spectrum layout [slow ...][fast/2+1]: the halved axis is the fastest non-trivial one
+    // (z for the 3-D equations, else y, else x for the ny == 1 "1-D" runs)
+    const int fast = nzz > 1 ? 2 : (p.ny > 1 ? 1 : 0);
+    const int nh = n3[fast] / 2 + 1;
+    int64_t o = 0;
+    for (int i = 0; i < (fast == 0 ? nh : p.nx); ++i)
+      for (int j = 0; j < (fast == 1 ? nh : (fast == 0 ? 1 : p.ny)); ++j)
+        for (int k = 0; k < (fast == 2 ? nh : 1); ++k) {
+          const std::complex<double> v =
+              0.5 * (m(i, j, k) + std::conj(m((p.nx - i) % p.nx, (p.ny - j) % p.ny, (nzz - k) % nzz)));
+          h[(size_t)o++] = C2<T>{(T)v.real(), (T)v.imag()};
+        }
     if ((rc = ensure_buffer(ctx, &sp.hmult, (size_t)hc * sizeof(C2<T>)))) return rc;
     PDEOPT_HIP_CHECK(ctx, hipMemcpyAsync(sp.hmult, h.data(), (size_t)hc * sizeof(C2<T>), hipMemcpyHostToDevice, ctx->stream));
     PDEOPT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));

@@ -37,6 +37,9 @@ StageArgs<T> make_args(pdeopt_ctx* ctx, const void* in, const void* y, void* out
   s.rhy = T(1.0 / p.hy);
   s.rhx2 = T(1.0 / (p.hx * p.hx));
   s.rhy2 = T(1.0 / (p.hy * p.hy));
+  s.rhz = p.nz > 1 ? T(1.0 / p.hz) : T(0);
+  s.rhz2 = p.nz > 1 ? T(1.0 / (p.hz * p.hz)) : T(0);
+  s.mu3 = nullptr;
   s.ep = static_cast<const EnvParams<T>*>(ctx->env_params_dev) + ctx->win_lo;
   s.mu = ClosureSpec{p.mu.kind, p.mu.flags, p.mu.n};
   s.mob = ClosureSpec{p.mob.kind, p.mob.flags, p.mob.n};
@@ -70,6 +73,21 @@ int launch_generic(pdeopt_ctx* ctx, const StageArgs<T>& s) {
   if (grid.y > 65535u || grid.z > 65535u)
     return fail(ctx, PDEOPT_EINVAL, "grid too large for the generic kernel (nx=%d batch=%d)", p.nx,
                 p.batch);
+  if (p.equation == PDEOPT_EQ_CAHN_HILLIARD_3D) {
+    // two passes: chemical potential into the work field, then the flux divergence + stage update
+    const int nz = s.g.nz;
+    dim3 g3((nz + 63) / 64, (p.ny + 3) / 4, (unsigned)(p.nx * ctx->win_n));
+    if (g3.y > 65535u || g3.z > 65535u) return fail(ctx, PDEOPT_EINVAL, "grid too large for the 3-D kernels");
+    int rc = ensure_buffer(ctx, &ctx->KS, ctx->total_bytes);
+    if (rc) return rc;
+    StageArgs<T> s3 = s;
+    s3.mu3 = static_cast<const T*>(ctx->KS) + (int64_t)ctx->win_lo * s.g.bstride;
+    hipLaunchKernelGGL(ch3d_mu_kernel<T>, g3, block, 0, ctx->stream, s3, const_cast<T*>(s3.mu3));
+    hipLaunchKernelGGL(ch3d_stage_kernel<T>, g3, block, 0, ctx->stream, s3);
+    ctx->last_kernel = "stage_generic<CH-3D>";
+    PDEOPT_HIP_CHECK(ctx, hipGetLastError());
+    return PDEOPT_OK;
+  }
   switch (p.equation) {
     case PDEOPT_EQ_CAHN_HILLIARD:
       hipLaunchKernelGGL((stage_generic_kernel<T, PDEOPT_EQ_CAHN_HILLIARD>), grid, block, 0,

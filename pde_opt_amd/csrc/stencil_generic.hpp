@@ -38,6 +38,8 @@ struct StageArgs {
   T* acc;        // running RK accumulator (pointwise)
   T a, b;        // already multiplied by dt
   T rhx, rhy, rhx2, rhy2;
+  T rhz, rhz2;   // 3-D equations
+  const T* mu3;  // 3-D: chemical potential field of the first pass
   Geo g;
   const EnvParams<T>* ep;
   ClosureSpec mu, mob;
@@ -186,6 +188,60 @@ __global__ __launch_bounds__(256) void stage_generic_kernel(const StageArgs<T> a
   const EnvParams<T>& p = a.ep[b];
   const T k = rhs_generic_point<T, EQ>(a, a.in + base, p, i, j, b);
   stage_update<T>(a, base + (int64_t)i * a.g.ld + j, k);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// CahnHilliard3DPeriodic.rhs_fd (cahn_hilliard.py:180-200), fields [b][nx][ny][nz] with z contiguous.
+// Two passes: mu = mu_h(u) - kappa lap7(u) into a work field, then k = div(D grad mu) from the 7-point
+// neighbourhoods of mu and u with the stage update fused in.  (One thread per cell; the 32^3 - 64^3
+// problems this class is used for upstream are launch-bound, not bandwidth-bound.)
+// ---------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void ch3d_mu_kernel(const StageArgs<T> a, T* __restrict__ mu_out) {
+  const int nx = a.g.nx, ny = a.g.ny, nz = a.g.nz;
+  const int k = blockIdx.x * 64 + threadIdx.x;
+  const int j = blockIdx.y * 4 + threadIdx.y;
+  const int i = blockIdx.z % nx, b = blockIdx.z / nx;
+  if (k >= nz || j >= ny) return;
+  const T* __restrict__ u = a.in + (int64_t)b * a.g.bstride;
+  const EnvParams<T>& p = a.ep[b];
+  auto U = [&](int ii, int jj, int kk) -> T { return u[((int64_t)ii * ny + jj) * nz + kk]; };
+  const int ip = (i + 1 == nx) ? 0 : i + 1, im = (i == 0) ? nx - 1 : i - 1;
+  const int jp = (j + 1 == ny) ? 0 : j + 1, jm = (j == 0) ? ny - 1 : j - 1;
+  const int kp = (k + 1 == nz) ? 0 : k + 1, km = (k == 0) ? nz - 1 : k - 1;
+  const T c = U(i, j, k);
+  const T lap = (U(ip, j, k) - T(2) * c + U(im, j, k)) * a.rhx2 + (U(i, jp, k) - T(2) * c + U(i, jm, k)) * a.rhy2 +
+                (U(i, j, kp) - T(2) * c + U(i, j, km)) * a.rhz2;
+  mu_out[(int64_t)b * a.g.bstride + ((int64_t)i * ny + j) * nz + k] = closure_generic<T>(a.mu, p.mu, c) - p.kappa * lap;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void ch3d_stage_kernel(const StageArgs<T> a) {
+  const int nx = a.g.nx, ny = a.g.ny, nz = a.g.nz;
+  const int k = blockIdx.x * 64 + threadIdx.x;
+  const int j = blockIdx.y * 4 + threadIdx.y;
+  const int i = blockIdx.z % nx, b = blockIdx.z / nx;
+  if (k >= nz || j >= ny) return;
+  const int64_t base = (int64_t)b * a.g.bstride;
+  const T* __restrict__ u = a.in + base;
+  const T* __restrict__ m = a.mu3 + base;
+  const EnvParams<T>& p = a.ep[b];
+  auto at = [&](int ii, int jj, int kk) -> int64_t { return ((int64_t)ii * ny + jj) * nz + kk; };
+  const int ip = (i + 1 == nx) ? 0 : i + 1, im = (i == 0) ? nx - 1 : i - 1;
+  const int jp = (j + 1 == ny) ? 0 : j + 1, jm = (j == 0) ? ny - 1 : j - 1;
+  const int kp = (k + 1 == nz) ? 0 : k + 1, km = (k == 0) ? nz - 1 : k - 1;
+  const int64_t c0 = at(i, j, k);
+  const T m0 = m[c0], d0 = closure_generic<T>(a.mob, p.mob, u[c0]);
+  // flux through the face between this cell and a neighbour: avg_face(D) * grad_face(mu)
+  auto flux = [&](int64_t n, T rh, bool plus) -> T {
+    const T dn = closure_generic<T>(a.mob, p.mob, u[n]);
+    const T g = plus ? (m[n] - m0) * rh : (m0 - m[n]) * rh;
+    return (T(0.5) * (plus ? (d0 + dn) : (dn + d0))) * g;
+  };
+  const T kx = (flux(at(ip, j, k), a.rhx, true) - flux(at(im, j, k), a.rhx, false)) * a.rhx;
+  const T ky = (flux(at(i, jp, k), a.rhy, true) - flux(at(i, jm, k), a.rhy, false)) * a.rhy;
+  const T kz = (flux(at(i, j, kp), a.rhz, true) - flux(at(i, j, km), a.rhz, false)) * a.rhz;
+  stage_update<T>(a, base + c0, kx + ky + kz);
 }
 
 }  // namespace pdeopt

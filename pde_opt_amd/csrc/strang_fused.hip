@@ -536,6 +536,7 @@ bool imex_fused_supported(const pdeopt_ctx* ctx) {
   // PDEOPT_OPT_IMEX_LDS_FFT: 0 auto (these transforms where the size is covered), -1 rocFFT real<->hermitian
   // plans (csrc/spectral.hip), 1 as 0.  The "generic" kernel path also means the library pipeline.
   if (ctx->opt_imex_lds_fft < 0 || ctx->opt_kernel_path == 1) return false;
+  if (p.nz > 1) return false;  // 3-D fields go through rocFFT's 3-D real<->hermitian plans
   if (!size_ok(p.nx, f64) || !size_ok(p.ny, f64)) return false;
   return !ctx->aux[PDEOPT_AUX_IMEX_SYMBOL].per_env;
 }

@@ -112,8 +112,11 @@ class HipEngine:
         gpe_k: float = 0.0,
         derivs: int = 0,
         fe: Optional[ClosureDesc] = None,
+        nz: int = 0,
+        hz: float = 0.0,
     ):
         p = L.Problem()
+        p.nz, p.hz = int(nz), float(hz)
         p.derivs = int(derivs)
         p.fe = _closure_struct(fe)
         p.equation, p.dtype = int(equation), L.dtype_code(dtype)
@@ -124,7 +127,7 @@ class HipEngine:
         self.problem = p
         self.dtype = L.np_dtype(p.dtype)
         self.batch = int(batch)
-        comps = (2,) if equation == L.EQ_GPE else ()
+        comps = (2,) if equation == L.EQ_GPE else ((int(nz),) if equation == L.EQ_CAHN_HILLIARD_3D else ())
         self.state_shape = (int(nx), int(ny)) + comps
 
     def set_env_params(self, env_first: int, kappa=None, mu_coef=None, mob_coef=None):
@@ -160,7 +163,7 @@ class HipEngine:
             a = np.asarray(field, dtype=np.complex128 if self.dtype == np.float64 else np.complex64)
         else:
             a = np.asarray(field, dtype=self.dtype)
-        want = ((p.batch,) if per_env else ()) + (p.nx, p.ny)
+        want = ((p.batch,) if per_env else ()) + (p.nx, p.ny) + ((p.nz,) if p.nz > 1 else ())
         if a.shape != want:
             a = np.broadcast_to(a, want)
         a = np.ascontiguousarray(a)

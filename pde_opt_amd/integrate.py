@@ -53,10 +53,11 @@ def _prepare(equation, solver, y0, engine: Optional[HipEngine], t_aux: float):
         raise ValueError("complex states are stored as (..., 2) real/imag pairs (gross_pitaevskii.py:75)")
     if y0.dtype not in (np.float32, np.float64):
         y0 = y0.astype(np.float64)
-    nd = 2 + len(equation._state_trailing)
+    npts = len(equation.domain.points)  # 2, or 3 for the 3-D equations
+    nd = npts + len(equation._state_trailing)
     single = y0.ndim == nd
     yb = y0[None] if single else y0
-    if yb.ndim != nd + 1 or tuple(yb.shape[1:3]) != tuple(equation.domain.points):
+    if yb.ndim != nd + 1 or tuple(yb.shape[1:1 + npts]) != tuple(equation.domain.points):
         raise ValueError(f"y0 shape {y0.shape} does not match domain points {equation.domain.points}")
     if engine is None:
         from .engine import default_engine

@@ -3,7 +3,7 @@
 from .advection_diffusion import AdvectionDiffusion2D
 from .base_eq import BaseEquation, TimeSplittingEquation
 from .gross_pitaevskii import GPE2DTSControl
-from .phase_field import AllenCahn2DPeriodic, CahnHilliard2DPeriodic
+from .phase_field import AllenCahn2DPeriodic, CahnHilliard2DPeriodic, CahnHilliard3DPeriodic
 from .smoothed_boundary import AllenCahn2DSmoothedBoundary, CahnHilliard2DSmoothedBoundary
 
 __all__ = [
@@ -11,6 +11,7 @@ __all__ = [
     "TimeSplittingEquation",
     "AllenCahn2DPeriodic",
     "CahnHilliard2DPeriodic",
+    "CahnHilliard3DPeriodic",
     "AllenCahn2DSmoothedBoundary",
     "CahnHilliard2DSmoothedBoundary",
     "AdvectionDiffusion2D",

@@ -32,11 +32,12 @@ class BaseEquation(ABC):
         a = np.asarray(state)
         if a.dtype not in (np.float32, np.float64):
             a = a.astype(np.float64)
-        nd = 2 + len(self._state_trailing)
+        npts = len(self.domain.points)  # 2, or 3 for the 3-D equations
+        nd = npts + len(self._state_trailing)
         single = a.ndim == nd
         if single:
             a = a[None]
-        if a.ndim != nd + 1 or tuple(a.shape[1:3]) != tuple(self.domain.points):
+        if a.ndim != nd + 1 or tuple(a.shape[1:1 + npts]) != tuple(self.domain.points):
             raise ValueError(
                 f"state shape {np.shape(state)} does not match domain points {self.domain.points}"
             )

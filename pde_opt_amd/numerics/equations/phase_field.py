@@ -150,3 +150,60 @@ class AllenCahn2DPeriodic(BaseEquation):
 
     def rhs_fourier(self, state, t):
         return self._run_rhs(state, t)  # 3 batched rocFFT transforms (allen_cahn.py:74-79)
+
+
+@dataclasses.dataclass
+class CahnHilliard3DPeriodic(BaseEquation):
+    """du/dt = div( D(u) grad( mu_h(u) - kappa lap u ) ) on a periodic 3-D box
+    (pde_opt/numerics/equations/cahn_hilliard.py:113-200).  Fields are ``(Nx, Ny, Nz)`` (or batched
+    ``(B, Nx, Ny, Nz)``); ``rhs_fd`` runs in two HIP passes (csrc/stencil_generic.hpp, CH-3D), the IMEX
+    solver on rocFFT's 3-D real<->hermitian plans.  ``derivs="fourier"`` has no kernel."""
+
+    domain: Domain
+    kappa: float
+    mu: Any
+    D: Any
+    derivs: str = "fd"
+    # class-level placeholders, as upstream (cahn_hilliard.py:138-140): check_equation_solver_compatibility
+    # looks the solver's required attributes up on the CLASS
+    fft = None
+    ifft = None
+    fourier_symbol = None
+
+    def rhs(self, state, t):  # replaced in __post_init__, as upstream
+        raise NotImplementedError("rhs method not implemented")
+
+    def __post_init__(self):
+        if len(self.domain.points) != 3:
+            raise ValueError("CahnHilliard3DPeriodic needs a 3-D domain")
+        self.kx, self.ky, self.kz = self.domain.fft_mesh()
+        self.two_pi_i_kx = 2j * np.pi * self.kx
+        self.two_pi_i_ky = 2j * np.pi * self.ky
+        self.two_pi_i_kz = 2j * np.pi * self.kz
+        self.two_pi_i_kx_2 = self.two_pi_i_kx**2
+        self.two_pi_i_ky_2 = self.two_pi_i_ky**2
+        self.two_pi_i_kz_2 = self.two_pi_i_kz**2
+        self.two_pi_i_k_2 = self.two_pi_i_kx_2 + self.two_pi_i_ky_2 + self.two_pi_i_kz_2
+        self.two_pi_i_k_4 = self.two_pi_i_k_2**2
+        self.fft = np.fft.fftn
+        self.ifft = np.fft.ifftn
+        self.fourier_symbol = self.kappa * self.two_pi_i_k_4
+        self._mu_desc = as_closure(self.mu)
+        self._mob_desc = as_closure(self.D)
+        if self.derivs == "fd":
+            self.rhs = self.rhs_fd
+        elif self.derivs == "fourier":
+            raise NotImplementedError("CahnHilliard3DPeriodic: derivs=\"fourier\" has no HIP kernel (use \"fd\")")
+        else:
+            raise ValueError(f"Invalid derivative type: {self.derivs}")
+
+    _state_trailing = ()
+
+    def _engine_problem(self):
+        nx, ny, nz = self.domain.points
+        hx, hy, hz = self.domain.dx
+        return dict(equation=L.EQ_CAHN_HILLIARD_3D, nx=nx, ny=ny, nz=nz, hx=hx, hy=hy, hz=hz,
+                    kappa=float(self.kappa), mu=self._mu_desc, mob=self._mob_desc, derivs=L.DERIVS_FD)
+
+    def rhs_fd(self, state, t):
+        return self._run_rhs(state, t)

@@ -33,7 +33,7 @@ def test_struct_layout_matches_header():
     import ctypes as C
 
     assert C.sizeof(L.Closure) == 16 + 128
-    assert C.sizeof(L.Problem) == 24 + 24 + 2 * 144 + 8 + 144
+    assert C.sizeof(L.Problem) == 24 + 24 + 2 * 144 + 8 + 144 + 16
 
 
 def test_no_gpu_is_loud_not_silent():

@@ -1,0 +1,92 @@
+"""CahnHilliard3DPeriodic (pde_opt/numerics/equations/cahn_hilliard.py:113-200) on
+the MI355X: RHS against the reference's goldens, explicit and IMEX trajectories against the oracle."""
+import numpy as np
+import pytest
+
+import pde_opt_amd as P
+from oracle import np_oracle as O
+from util import MOB, MU, TOL, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+def _dom(nx, ny, nz):
+    return P.Domain((nx, ny, nz), ((-0.005 * nx, 0.005 * nx), (-0.005 * ny, 0.005 * ny), (0.0, 0.012 * nz)), "dimensionless")
+
+
+def test_rhs_against_reference_goldens(golden):
+    z = golden("ch3d_cases.npz")
+    tags = sorted(k[: -len("/rhs")] for k in z.files if k.endswith("/rhs"))
+    assert len(tags) == 6
+    for tag in tags:
+        nx, ny, nz = (int(v) for v in tag.split("_")[0].split("x"))
+        u, want = z[tag + "/u"], z[tag + "/rhs"]
+        eq = P.CahnHilliard3DPeriodic(_dom(nx, ny, nz), 0.002, MU["regsol"], MOB["c1mc"], derivs="fd")
+        got = eq.rhs(u, 0.0)
+        assert got.dtype == want.dtype and got.shape == want.shape
+        assert rel_l2(got, want) < TOL[want.dtype], (tag, rel_l2(got, want))
+        if tag + "/symbol" in z.files:
+            np.testing.assert_allclose(eq.fourier_symbol, z[tag + "/symbol"], rtol=1e-13)
+    assert "CH-3D" in P.engine.default_engine().last_kernel
+    # a batch equals its members
+    eq = P.CahnHilliard3DPeriodic(_dom(16, 12, 20), 0.002, MU["regsol"], MOB["c1mc"])
+    u = z["16x12x20_float64/u"]
+    ub = np.stack([u, 0.5 * u + 0.2])
+    np.testing.assert_array_equal(eq.rhs(ub, 0.0)[0], eq.rhs(u, 0.0))
+
+
+@pytest.mark.parametrize("solver", ["euler", "rk4", "tsit5"])
+def test_explicit_trajectory_vs_oracle(solver):
+    rng = np.random.default_rng(5)
+    nx, ny, nz = 24, 16, 40
+    dom = _dom(nx, ny, nz)
+    hx, hy, hz = dom.dx
+    eq = P.CahnHilliard3DPeriodic(dom, 0.002, MU["regsol"], MOB["c1mc"])
+    y0 = np.clip(0.5 + 0.05 * rng.standard_normal((2, nx, ny, nz)), 0.05, 0.95)
+    f = lambda t, u: O.ch3d_rhs_fd(u, hx, hy, hz, 0.002, MU["regsol"], MOB["c1mc"])
+    dt, n = 1e-7, 5
+    s = {"euler": P.Euler(), "rk4": P.RK4(), "tsit5": P.Tsit5()}[solver]
+    sol = P.diffeqsolve(eq, s, 0.0, n * dt, dt, y0)
+    for b in range(2):
+        ref = y0[b]
+        for i in range(n):
+            ref = O.euler_step(f, 0.0, ref, dt) if solver == "euler" else (
+                O.rk4_step(f, 0.0, ref, dt) if solver == "rk4" else O.tsit5_step(f, 0.0, ref, dt)[0])
+        assert rel_l2(sol.ys[-1][b] - y0[b], ref - y0[b]) < 1e-10, (solver, b)
+        assert abs(sol.ys[-1][b].mean() - y0[b].mean()) < 1e-14  # flux form conserves the mean
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_imex_3d_vs_oracle_and_pde_model(dtype):
+    """docs/notebooks/optimization_3D.ipynb set-up: PDEModel(CahnHilliard3DPeriodic, SemiImplicitFourierSpectral)"""
+    rng = np.random.default_rng(9)
+    n = 32
+    dom = P.Domain((n, n, n), ((-0.16, 0.16),) * 3, "dimensionless")
+    params = {"kappa": 0.002, "mu": MU["regsol"], "D": lambda c: 0.15 * np.ones_like(c)}
+    y0 = np.clip(0.01 * rng.standard_normal((n, n, n)) + 0.5, 0.0, 1.0).astype(dtype)
+    model = P.PDEModel(equation_type=P.CahnHilliard3DPeriodic, domain=dom, solver_type=P.SemiImplicitFourierSpectral)
+    ts = np.linspace(0.0, 2e-5, 3)
+    sol = model.solve(params, y0, ts, {"A": 0.5}, dt0=0.000001, max_steps=1000000)
+    assert sol.shape == (3, n, n, n) and sol.dtype == dtype
+    eq = P.CahnHilliard3DPeriodic(dom, **params)
+    hx, hy, hz = dom.dx
+    rhs = lambda t, u: O.ch3d_rhs_fd(u, hx, hy, hz, 0.002, MU["regsol"], params["D"])
+    ref = y0.astype(np.float64)
+    for i in range(20):
+        ref = O.imex_step(rhs, i * 1e-6, ref, 1e-6, 0.5, eq.fourier_symbol)
+    tol = 1e-9 if dtype is np.float64 else 5e-4
+    assert rel_l2(sol[-1].astype(np.float64) - y0, ref - y0) < tol
+    assert abs(sol[-1].astype(np.float64).mean() - y0.astype(np.float64).mean()) < (1e-14 if dtype is np.float64 else 2e-7)
+
+
+def test_errors():
+    dom = _dom(8, 8, 8)
+    with pytest.raises(NotImplementedError, match="fourier"):
+        P.CahnHilliard3DPeriodic(dom, 0.002, MU["regsol"], MOB["c1mc"], derivs="fourier")
+    with pytest.raises(ValueError, match="Invalid derivative type"):
+        P.CahnHilliard3DPeriodic(dom, 0.002, MU["regsol"], MOB["c1mc"], derivs="spectral")
+    with pytest.raises(ValueError, match="3-D"):
+        P.CahnHilliard3DPeriodic(P.Domain((8, 8), ((0, 1), (0, 1)), "d"), 0.002, MU["regsol"], MOB["c1mc"])
+    eq = P.CahnHilliard3DPeriodic(dom, 0.002, MU["regsol"], MOB["c1mc"])
+    with pytest.raises(ValueError, match="does not match"):
+        eq.rhs(np.zeros((8, 8)), 0.0)

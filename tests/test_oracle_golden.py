@@ -216,3 +216,20 @@ def test_detect_vortices_matches_reference(golden):
             np.testing.assert_array_equal(w, z[key + "/winding"])
             np.testing.assert_array_equal([num, total, abs_c], z[key + "/counts"])
     assert z["48x48_c128/amp0.0_tol0.5/counts"][0] > 0
+
+
+def _dx3(tag):
+    nx, ny, nz = (int(v) for v in tag.split("_")[0].split("x"))
+    # Domain of gen_golden: box (-0.005 nx, 0.005 nx) x (-0.005 ny, 0.005 ny) x (0, 0.012 nz)
+    return (0.01 * nx) / nx, (0.01 * ny) / ny, (0.012 * nz) / nz
+
+
+def test_ch3d_rhs_matches_reference_goldens(golden):
+    """CahnHilliard3DPeriodic.rhs_fd (cahn_hilliard.py:180-200): same operations, same order -> bitwise"""
+    z = golden("ch3d_cases.npz")
+    tags = sorted(k[: -len("/rhs")] for k in z.files if k.endswith("/rhs"))
+    assert len(tags) == 6
+    for tag in tags:
+        hx, hy, hz = _dx3(tag)
+        got = O.ch3d_rhs_fd(z[tag + "/u"], hx, hy, hz, 0.002, MU["regsol"], MOB["c1mc"])
+        np.testing.assert_array_equal(got, z[tag + "/rhs"], err_msg=tag)
