@@ -58,15 +58,15 @@ struct StrangFused;  // LDS-FFT split-step state (strang_fused.hip)
 
 // what a captured substep graph depends on (explicit integrators, stencil.hip)
 struct GraphStructure {
-  int equation, dtype, nx, ny, batch, derivs;
-  double hx, hy;
+  int equation, dtype, nx, ny, nz, batch, derivs;
+  double hx, hy, hz;
   int mu_kind, mu_flags, mu_n, mob_kind, mob_flags, mob_n;
 };
 struct GraphKey {
   int integrator;
   int fused;
   double dt;
-  void *Y, *TA, *TB, *ACC, *ep, *vx, *vy;
+  void *Y, *TA, *TB, *ACC, *KS, *ep, *vx, *vy;
   int64_t kernel_path, tile_rows, ablate;
   GraphStructure structure;
 };

@@ -220,7 +220,7 @@ constexpr int kGraphUnit = 16;  // substeps per captured graph (even: ping-pong 
 GraphStructure graph_structure(const pdeopt_problem& p) {
   GraphStructure g{};
   g.equation = p.equation; g.dtype = p.dtype; g.nx = p.nx; g.ny = p.ny; g.batch = p.batch; g.derivs = p.derivs;
-  g.hx = p.hx; g.hy = p.hy;
+  g.nz = p.nz; g.hx = p.hx; g.hy = p.hy; g.hz = p.hz;
   g.mu_kind = p.mu.kind; g.mu_flags = p.mu.flags; g.mu_n = p.mu.n;
   g.mob_kind = p.mob.kind; g.mob_flags = p.mob.flags; g.mob_n = p.mob.n;
   return g;
@@ -236,6 +236,9 @@ int advance_explicit(pdeopt_ctx* ctx, int integrator, double t0, double dt, int6
   } else if (integrator != PDEOPT_INT_EULER) {
     return fail(ctx, PDEOPT_EINVAL, "integrator %d is not an explicit fixed-step integrator", integrator);
   }
+  // work field of the two-pass 3-D right-hand side: allocated here, never inside a stream capture
+  if (ctx->prob.equation == PDEOPT_EQ_CAHN_HILLIARD_3D && (rc = ensure_buffer(ctx, &ctx->KS, ctx->total_bytes)))
+    return rc;
   // Environments are independent, so the substep loop may run group by group: a group whose
   // working set (4 fields x group x nx x ny) fits the 256 MiB Infinity Cache keeps every stage's
   // reads and writes on-die for all n substeps instead of streaming the whole batch through HBM
@@ -308,7 +311,7 @@ int advance_explicit(pdeopt_ctx* ctx, int integrator, double t0, double dt, int6
     key.integrator = integrator;
     key.fused = fused ? (int)(1 + ctx->opt_fuse_stages) : 0;
     key.dt = dt;
-    key.Y = ctx->Y; key.TA = ctx->TA; key.TB = ctx->TB; key.ACC = ctx->ACC;
+    key.Y = ctx->Y; key.TA = ctx->TA; key.TB = ctx->TB; key.ACC = ctx->ACC; key.KS = ctx->KS;
     key.ep = ctx->env_params_dev;
     key.vx = ctx->aux[PDEOPT_AUX_VX_FACE].dev; key.vy = ctx->aux[PDEOPT_AUX_VY_FACE].dev;
     key.kernel_path = ctx->opt_kernel_path; key.tile_rows = ctx->opt_tile_rows; key.ablate = ctx->opt_debug_ablate;

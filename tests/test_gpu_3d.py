@@ -56,6 +56,24 @@ def test_explicit_trajectory_vs_oracle(solver):
         assert abs(sol.ys[-1][b].mean() - y0[b].mean()) < 1e-14  # flux form conserves the mean
 
 
+def test_long_run_replays_the_substep_graph():
+    """>= 32 substeps of a small grid replay a captured hipGraph (two kernels per stage in 3-D)"""
+    rng = np.random.default_rng(6)
+    nx, ny, nz = 16, 16, 24
+    dom = _dom(nx, ny, nz)
+    hx, hy, hz = dom.dx
+    eq = P.CahnHilliard3DPeriodic(dom, 0.002, MU["regsol"], MOB["c1mc"])
+    y0 = np.clip(0.5 + 0.05 * rng.standard_normal((nx, ny, nz)), 0.05, 0.95)
+    f = lambda t, u: O.ch3d_rhs_fd(u, hx, hy, hz, 0.002, MU["regsol"], MOB["c1mc"])
+    dt, n = 1e-7, 64  # four replays of the 16-substep graph, no eager remainder
+    sol = P.diffeqsolve(eq, P.RK4(), 0.0, n * dt, dt, y0)
+    assert "hipGraph" in sol.stats["kernel"], sol.stats
+    ref = y0
+    for i in range(n):
+        ref = O.rk4_step(f, 0.0, ref, dt)
+    assert rel_l2(sol.ys[-1] - y0, ref - y0) < 1e-10
+
+
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 def test_imex_3d_vs_oracle_and_pde_model(dtype):
     """docs/notebooks/optimization_3D.ipynb set-up: PDEModel(CahnHilliard3DPeriodic, SemiImplicitFourierSpectral)"""
