@@ -21,7 +21,7 @@ def _setup(nx, ny, kinetic=True):
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
-@pytest.mark.parametrize("shape", [(64, 64), (128, 64), (64, 256), (512, 128)])
+@pytest.mark.parametrize("shape", [(64, 64), (128, 64), (64, 256), (512, 128), (1024, 64), (128, 1024)])
 @pytest.mark.parametrize("tscale", [1.0, -1j])
 def test_fused_strang_vs_oracle(dtype, shape, tscale):
     nx, ny = shape
