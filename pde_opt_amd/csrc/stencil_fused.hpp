@@ -372,8 +372,23 @@ __global__ __launch_bounds__(NT) PDEOPT_PAIR_WAVES_ATTR void stage_pair_kernel(c
   mu_pass(0, TX + 6);
   __syncthreads();
 
-  // ---- P3: k_A on the own micro-tile and on one ring vector
+  // ---- P3: k_A on one ring vector, then on the own micro-tile.  The ring goes FIRST: its non-marching
+  // flux_divergence needs ~60 transient registers, and after the march w_own / yown / accp are live --
+  // in the other order this phase is the VGPR peak of the kernel (v95 / v115).
   Vec w_own[RPT], yown[RPT], w_ring;
+  if (has_ring) {
+    Vec uc;
+    Vec kA;
+    if (PDEOPT_ABL(a, 4))
+      kA = uc = *reinterpret_cast<const Vec*>(sU + (ring_r + 4) * P + ring_cv * V);
+    else
+      kA = k_at(ring_r, ring_cv, &uc);
+    if constexpr (PAIR == PAIR_12)
+      w_ring = uc + a.aA * kA;
+    else
+      w_ring = yring + a.aA * kA;
+  }
+  __builtin_amdgcn_sched_barrier(0);
   {
     Vec kA[RPT];
     if (PDEOPT_ABL(a, 2)) {
@@ -392,18 +407,6 @@ __global__ __launch_bounds__(NT) PDEOPT_PAIR_WAVES_ATTR void stage_pair_kernel(c
         accp[r] = accp[r] + a.bA * kA[r];
       }
     }
-  }
-  if (has_ring) {
-    Vec uc;
-    Vec kA;
-    if (PDEOPT_ABL(a, 4))
-      kA = uc = *reinterpret_cast<const Vec*>(sU + (ring_r + 4) * P + ring_cv * V);
-    else
-      kA = k_at(ring_r, ring_cv, &uc);
-    if constexpr (PAIR == PAIR_12)
-      w_ring = uc + a.aA * kA;
-    else
-      w_ring = yring + a.aA * kA;
   }
   __syncthreads();
 
