@@ -255,7 +255,12 @@ __global__ __launch_bounds__(NT) PDEOPT_PAIR_WAVES_ATTR void stage_pair_kernel(c
   auto mu_pass = [&](const int rm0, const int nrows) {
     const int nvec = nrows * PV;
     const int lane = tid & 63;
-#pragma unroll 1
+    // all (<= 3 at fp32) trips unrolled: independent closure evaluations interleave and hide the
+    // v_rcp / v_log latencies; +1.7 % same-box against one trip at a time, same VGPR count
+#ifndef PDEOPT_MU_UNROLL
+#define PDEOPT_MU_UNROLL 3
+#endif
+#pragma unroll PDEOPT_MU_UNROLL
     for (int base0 = 0; base0 < nvec; base0 += NT) {
       const int idx_raw = base0 + tid;
 #ifdef PDEOPT_DPP_EXCHANGE

@@ -143,6 +143,7 @@ def test_rccl_allgather_path_single_rank():
     port = s.getsockname()[1]
     s.close()
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")  # single node: no interface probing
     torch.cuda.set_device(0)
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     try:
