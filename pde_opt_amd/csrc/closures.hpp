@@ -49,7 +49,10 @@ __device__ __forceinline__ double t_logit<double>(double c) {
 //   CL_GENERIC : any kind / flags / n, decided at run time (wave-uniform branches)
 //   CL_POLY    : mu = cubic polynomial, mobility = quadratic polynomial, fully unrolled
 //   CL_LOGIT   : as CL_POLY with the log(c/(1-c)) prior added to mu (regular-solution model)
-enum { CL_GENERIC = 0, CL_POLY = 1, CL_LOGIT = 2 };
+//   CL_LOGIT1  : CL_LOGIT whose polynomial part is linear (the regular-solution model 3 (1 - 2c) of the
+//                headline workload): two FMAs less per evaluation in the VALU-bound fused CH kernel; bitwise
+//                equal to CL_LOGIT there, because coefficients past n are stored as zeros
+enum { CL_GENERIC = 0, CL_POLY = 1, CL_LOGIT = 2, CL_LOGIT1 = 3 };
 
 template <typename T>
 __device__ __forceinline__ T series_generic(const ClosureSpec& s, const T* __restrict__ coef, T c) {
@@ -87,6 +90,8 @@ template <typename T, int CL>
 __device__ __forceinline__ T eval_mu(const ClosureSpec& s, const T* __restrict__ coef, T c) {
   if constexpr (CL == CL_GENERIC) {
     return closure_generic<T>(s, coef, c);
+  } else if constexpr (CL == CL_LOGIT1) {
+    return coef[1] * c + coef[0] + t_logit<T>(c);
   } else {
     T r = ((coef[3] * c + coef[2]) * c + coef[1]) * c + coef[0];
     if constexpr (CL == CL_LOGIT) r += t_logit<T>(c);

@@ -464,8 +464,16 @@ template <typename T, int CL, int PAIR>
 int launch_pair_pipe_inst(pdeopt_ctx* ctx, const PairArgs<T>& s);  // stencil_fused_pipe.hpp
 
 template <typename T, int CL, int PAIR, int RPT>
+int launch_pair_ch_inst(pdeopt_ctx* ctx, const PairArgs<T>& s);
+
+template <typename T, int CL, int PAIR, int RPT>
 int launch_pair_inst(pdeopt_ctx* ctx, const PairArgs<T>& s) {
   if (ctx->prob.equation == PDEOPT_EQ_ALLEN_CAHN) return launch_pair_ac_inst<T, CL, PAIR, RPT>(ctx, s);
+  return launch_pair_ch_inst<T, CL, PAIR, RPT>(ctx, s);
+}
+
+template <typename T, int CL, int PAIR, int RPT>
+int launch_pair_ch_inst(pdeopt_ctx* ctx, const PairArgs<T>& s) {
   // CH: 2 rows per thread always; 32-row tiles (RPT == 4 on this dispatch axis) are 512-thread blocks
   constexpr int V = VecOf<T>::V;
   constexpr int NT = RPT == 4 ? 512 : 256;

@@ -51,6 +51,14 @@ int launch_pair(pdeopt_ctx* ctx, int pair, const void* in, const void* y, const 
     return pair == PAIR_12 ? launch_pair_pipe_inst<T, CL_POLY, PAIR_12>(ctx, s)
                            : launch_pair_pipe_inst<T, CL_POLY, PAIR_34>(ctx, s);
   }
+  if (cl == CL_LOGIT && p.mu.n <= 2 && p.equation == PDEOPT_EQ_CAHN_HILLIARD) {
+    // linear polynomial part: the shorter closure (same bits, see closures.hpp)
+    if (rpt == 2)
+      return pair == PAIR_12 ? launch_pair_ch_inst<T, CL_LOGIT1, PAIR_12, 2>(ctx, s)
+                             : launch_pair_ch_inst<T, CL_LOGIT1, PAIR_34, 2>(ctx, s);
+    return pair == PAIR_12 ? launch_pair_ch_inst<T, CL_LOGIT1, PAIR_12, 4>(ctx, s)
+                           : launch_pair_ch_inst<T, CL_LOGIT1, PAIR_34, 4>(ctx, s);
+  }
 #define PDEOPT_PAIR_DISPATCH(CLV, PAIRV)                                             \
   (rpt == 2 ? launch_pair_inst<T, CLV, PAIRV, 2>(ctx, s) : launch_pair_inst<T, CLV, PAIRV, 4>(ctx, s))
   if (cl == CL_LOGIT)

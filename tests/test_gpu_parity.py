@@ -634,3 +634,22 @@ def test_pipelined_pair_equals_classic(dtype, shape, batch, closures):
     for mode in (2, 3):
         np.testing.assert_allclose(outs[mode], outs[1], rtol=0, atol=8 * eps)
         assert np.mean(outs[mode] != outs[1]) < 0.5
+
+
+def test_linear_logit_class_is_bitwise_the_cubic_one():
+    """CL_LOGIT1 (csrc/closures.hpp): the regular-solution closure written with 2 coefficients runs the
+    shorter in-kernel form, with 4 coefficients (two of them zero) the cubic one -- same bits."""
+    from pde_opt_amd.numerics.closures import LOGIT_PRIOR, POLY, ClosureDesc
+
+    rng = np.random.default_rng(23)
+    dom = std_domain(P, 128, 256)
+    y0 = np.clip(0.5 + 0.05 * rng.standard_normal((2, 128, 256)), 0.05, 0.95).astype(np.float32)
+    outs = []
+    for coef in ((3.0, -6.0), (3.0, -6.0, 0.0, 0.0)):
+        eq = P.CahnHilliard2DPeriodic(dom, 0.002, ClosureDesc(POLY, LOGIT_PRIOR, coef), MOB["c1mc"])
+        sol = P.diffeqsolve(eq, P.RK4(), 0.0, 8 * 2e-7, 2e-7, y0)
+        assert "pair" in sol.stats["kernel"]
+        outs.append(sol.ys[-1])
+    np.testing.assert_array_equal(outs[0], outs[1])
+    ref = P.diffeqsolve(P.CahnHilliard2DPeriodic(dom, 0.002, MU["regsol"], MOB["c1mc"]), P.RK4(), 0.0, 8 * 2e-7, 2e-7, y0).ys[-1]
+    np.testing.assert_array_equal(outs[0], ref)
