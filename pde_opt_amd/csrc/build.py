@@ -28,6 +28,7 @@ HEADERS = [
     "stencil_tiled.hpp",
     "stencil_fused.hpp",
     "stencil_fused_ac.hpp",
+    "stencil_fused_ac4.hpp",
     "stencil_fused_pipe.hpp",
     "stencil_fused_wave.hpp",
     "stencil_fused_launch.hpp",

@@ -12,6 +12,7 @@
 #include "stencil_tiled.hpp"
 #include "stencil_fused.hpp"
 #include "stencil_fused_ac.hpp"
+#include "stencil_fused_ac4.hpp"
 #include "stencil_fused_pipe.hpp"
 #include "stencil_fused_launch.hpp"
 
@@ -264,6 +265,9 @@ int advance_explicit(pdeopt_ctx* ctx, int integrator, double t0, double dt, int6
                      ctx->prob.derivs == PDEOPT_DERIVS_FD &&
                      (ctx->prob.dtype == PDEOPT_F32 ? fused_supported<float>(ctx) : fused_supported<double>(ctx));
 
+  // Allen-Cahn fp32: the whole RK4 substep in one pass (2 words per cell instead of 7)
+  const bool quad = integrator == PDEOPT_INT_RK4 && ac_quad_supported(ctx);
+
   // one substep on the current window; Y / TA are swapped where the integrator ping-pongs
   auto substep = [&](void*& Y, void*& TA, int64_t step) -> int {
     int r;
@@ -271,6 +275,11 @@ int advance_explicit(pdeopt_ctx* ctx, int integrator, double t0, double dt, int6
     ctx->cur_t = ts;
     if (integrator == PDEOPT_INT_EULER) {
       r = launch_stage(ctx, Y, Y, TA, nullptr, dt, 0.0, OUT_Y_PLUS_AK, ACC_NONE);
+      std::swap(Y, TA);
+      return r;
+    }
+    if (quad) {
+      r = launch_ac_quad(ctx, Y, TA, dt);
       std::swap(Y, TA);
       return r;
     }
@@ -309,7 +318,7 @@ int advance_explicit(pdeopt_ctx* ctx, int integrator, double t0, double dt, int6
     GraphKey key;
     memset(&key, 0, sizeof(key));  // padding bytes take part in the memcmp below
     key.integrator = integrator;
-    key.fused = fused ? (int)(1 + ctx->opt_fuse_stages) : 0;
+    key.fused = quad ? 100 : (fused ? (int)(1 + ctx->opt_fuse_stages) : 0);
     key.dt = dt;
     key.Y = ctx->Y; key.TA = ctx->TA; key.TB = ctx->TB; key.ACC = ctx->ACC; key.KS = ctx->KS;
     key.ep = ctx->env_params_dev;

@@ -158,7 +158,7 @@ def test_allen_cahn_rk4_config2_slice(engine):
     y0 = (0.01 * rng.standard_normal((4, nx, ny))).astype(np.float32)
     dt, n = 5e-5, 20
     sol = P.diffeqsolve(eq, P.RK4(), 0.0, n * dt, dt, y0)
-    assert "pair" in sol.stats["kernel"]  # fused stage pairs for Allen-Cahn
+    assert "rk4_quad" in sol.stats["kernel"]  # the whole RK4 substep in one pass for Allen-Cahn fp32
     hx, hy = dom.dx
     f = lambda t, u: O.ac_rhs_fd(u, hx, hy, 0.002, MU["cubic"], MOB["one"])
     ref = y0[1].astype(np.float64)
@@ -590,13 +590,19 @@ def test_ragged_tiles_match_generic_and_oracle(engine, dtype, shape):
             assert rel_l2(got[b], fn(u[b], hx, hy, 0.002, mu_fn, mob_fn)) < TOL[np.dtype(dtype)]
         # RK4 through the fused stage pairs == per-stage generic kernels to rounding
         sol = P.diffeqsolve(eq, P.RK4(), 0.0, 4 * 2e-7, 2e-7, u)
-        assert "pair" in sol.stats["kernel"]
+        assert "pair" in sol.stats["kernel"] or "rk4_quad" in sol.stats["kernel"]
         eng = P.HipEngine()
         eng.set_kernel_path(L.PATH_GENERIC)
         ref = P.diffeqsolve(eq, P.RK4(), 0.0, 4 * 2e-7, 2e-7, u, engine=eng).ys[-1]
         eng.close()
         inc, inc_ref = sol.ys[-1].astype(np.float64) - u, ref.astype(np.float64) - u
-        assert rel_l2(inc, inc_ref) < (1e-10 if dtype is np.float64 else 5e-4), (shape, cls.__name__)
+        if dtype is np.float64:
+            assert rel_l2(inc, inc_ref) < 1e-10, (shape, cls.__name__)
+        else:
+            # fp32: 4 substeps of 2e-7 move the state by ~1e-5, a few hundred ulps; kernels that round the RK
+            # combination in a different order differ by an ulp of the STATE, so compare states
+            assert np.max(np.abs(sol.ys[-1].astype(np.float64) - ref)) < 5e-7, (shape, cls.__name__)
+            assert rel_l2(inc, inc_ref) < 2e-2, (shape, cls.__name__)
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
@@ -653,3 +659,34 @@ def test_linear_logit_class_is_bitwise_the_cubic_one():
     np.testing.assert_array_equal(outs[0], outs[1])
     ref = P.diffeqsolve(P.CahnHilliard2DPeriodic(dom, 0.002, MU["regsol"], MOB["c1mc"]), P.RK4(), 0.0, 8 * 2e-7, 2e-7, y0).ys[-1]
     np.testing.assert_array_equal(outs[0], ref)
+
+
+@pytest.mark.parametrize("shape,batch", [((512, 512), 2), ((100, 100), 3), ((64, 128), 5), ((48, 40), 1)])
+def test_allen_cahn_single_pass_rk4_equals_stage_pairs(shape, batch):
+    """csrc/stencil_fused_ac4.hpp (all four RK4 stages in one pass, fp32) against the stage-pair kernels and
+    the per-stage kernels: the same arithmetic per stage, results equal to rounding; ragged grids included."""
+    rng = np.random.default_rng(29)
+    nx, ny = shape
+    dom = std_domain(P, nx, ny)
+    eq = P.AllenCahn2DPeriodic(dom, 0.002, MU["cubic"], MOB["one_plus_sq"])
+    u = white_noise_state(rng, (batch, nx, ny), np.float32, "sym")
+    outs = {}
+    for fuse in (0, 1, -1):  # auto (single pass), stage pairs, one launch per stage
+        eng = P.HipEngine()
+        eng.set_fuse_stages(fuse)
+        eng.configure(dtype=np.float32, batch=batch, **eq._engine_problem())
+        eng.set_env_params(0, kappa=0.002 * (1.0 + 0.1 * np.arange(batch)))
+        eng.set_state(u)
+        eng.advance(L.INT_RK4, 5e-5, 40)
+        outs[fuse] = eng.get_state()
+        assert ("rk4_quad" in eng.last_kernel) == (fuse == 0), eng.last_kernel
+        eng.close()
+    assert np.isfinite(outs[0]).all()
+    for other in (1, -1):
+        assert rel_l2(outs[0].astype(np.float64) - u, outs[other].astype(np.float64) - u) < 2e-5
+    hx, hy = dom.dx
+    f = lambda t, v: O.ac_rhs_fd(v, hx, hy, 0.002, MU["cubic"], MOB["one_plus_sq"])
+    ref = u[0].astype(np.float64)
+    for i in range(40):
+        ref = O.rk4_step(f, 0.0, ref, 5e-5)
+    assert rel_l2(outs[0][0].astype(np.float64) - u[0], ref - u[0]) < 5e-4
