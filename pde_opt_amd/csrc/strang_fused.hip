@@ -15,6 +15,7 @@
 // path (csrc/spectral.hip, which stays the path for sizes that are not powers of two in 64..1024).
 // The normalisation scalar is folded into the second spectral multiply (the FFT is linear), the
 // reduction is deterministic (fixed partition, fp64 partials summed in a fixed order).
+#include <algorithm>
 #include <cmath>
 #include <complex>
 
@@ -227,11 +228,13 @@ int launch_row(pdeopt_ctx* ctx, StrangFused& sf, double tr, double ti) {
   auto kern = strang_row_reg_kernel<T, N, MODE>;
   int rc = allow_lds(ctx, kern, lds);
   if (rc) return rc;
-  const int blocks = (int)((int64_t)p.batch * p.nx / F);
-  hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, ctx->stream, (Cx<T>*)ctx->Y, (T*)sf.dens,
-                     (const T*)pot.dev, pot.per_env ? (int64_t)p.nx * p.ny : (int64_t)0,
-                     (const EnvParams<T>*)ctx->env_params_dev, (const Cx<T>*)sf.tw_y, (T)tr, (T)ti, p.nx,
-                     sf.partial);
+  // environment window [win_lo, win_lo + win_n): all pointers pre-offset, the kernel sees win_n environments
+  const int64_t cells = (int64_t)p.nx * p.ny, w0 = ctx->win_lo;
+  const int blocks = (int)((int64_t)ctx->win_n * p.nx / F);
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, ctx->stream, (Cx<T>*)ctx->Y + w0 * cells,
+                     (T*)sf.dens + w0 * cells, pot.dev ? (const T*)pot.dev + (pot.per_env ? w0 * cells : 0) : nullptr,
+                     pot.per_env ? cells : (int64_t)0, (const EnvParams<T>*)ctx->env_params_dev + w0,
+                     (const Cx<T>*)sf.tw_y, (T)tr, (T)ti, p.nx, sf.partial + w0 * (p.nx / F));
   PDEOPT_HIP_CHECK(ctx, hipGetLastError());
   return PDEOPT_OK;
 }
@@ -245,9 +248,11 @@ int launch_col(pdeopt_ctx* ctx, StrangFused& sf) {
   auto kern = strang_col_reg_kernel<T, N, C, PTS, SCALED>;
   int rc = allow_lds(ctx, kern, lds);
   if (rc) return rc;
-  hipLaunchKernelGGL(kern, dim3(p.ny / C, p.batch), dim3(C * N / PTS), lds, ctx->stream, (Cx<T>*)ctx->Y,
-                     (const Cx<T>*)sf.mult, (const Cx<T>*)sf.tw_x, p.ny, (const double*)sf.partial,
-                     p.nx / row_pass_rows_rt<T>(p.ny), ctx->strang_dx * ctx->strang_dx);
+  const int64_t cells = (int64_t)p.nx * p.ny, w0 = ctx->win_lo;
+  const int bpe = p.nx / row_pass_rows_rt<T>(p.ny);  // norm partials per environment
+  hipLaunchKernelGGL(kern, dim3(p.ny / C, ctx->win_n), dim3(C * N / PTS), lds, ctx->stream, (Cx<T>*)ctx->Y + w0 * cells,
+                     (const Cx<T>*)sf.mult, (const Cx<T>*)sf.tw_x, p.ny, (const double*)sf.partial + w0 * bpe, bpe,
+                     ctx->strang_dx * ctx->strang_dx);
   PDEOPT_HIP_CHECK(ctx, hipGetLastError());
   return PDEOPT_OK;
 }
@@ -330,17 +335,37 @@ int strang_fused_t(pdeopt_ctx* ctx, double dt, int64_t n) {
     sf.key_ti = ctx->ts_im;
   }
   const double tr = tau.real(), ti = tau.imag();
-  if ((rc = row_dispatch<T, ROW_FIRST>(ctx, sf, tr, ti))) return rc;
-  for (int64_t s = 0; s < n; ++s) {
-    if ((rc = col_dispatch<T, false>(ctx, sf))) return rc;
-    if ((rc = row_dispatch<T, ROW_MID>(ctx, sf, tr, ti))) return rc;
-    if ((rc = col_dispatch<T, true>(ctx, sf))) return rc;
-    if (s + 1 < n)
-      rc = row_dispatch<T, ROW_JOIN>(ctx, sf, tr, ti);
-    else
-      rc = row_dispatch<T, ROW_LAST>(ctx, sf, tr, ti);
-    if (rc) return rc;
+  // Environments are independent: run the whole n-step pipeline group by group, a group's wavefunction +
+  // density (12 B/cell at fp32) sized to stay in the 256 MiB Infinity Cache between its passes.
+  int group = p.batch;
+  if (ctx->opt_group_envs > 0) {
+    group = (int)std::min<int64_t>(ctx->opt_group_envs, p.batch);
+  } else if (ctx->opt_group_envs == 0) {
+    const size_t per_env = (size_t)cells * (sizeof(Cx<T>) + sizeof(T));
+    const int64_t fit = std::max<int64_t>(1, (int64_t)((192ull << 20) / per_env));
+    if (fit < p.batch && n > 1) {
+      const int ngroups = (int)((p.batch + fit - 1) / fit);
+      group = (p.batch + ngroups - 1) / ngroups;
+    }
   }
+  for (int lo = 0; lo < p.batch && !rc; lo += group) {
+    ctx->win_lo = lo;
+    ctx->win_n = std::min(group, p.batch - lo);
+    if ((rc = row_dispatch<T, ROW_FIRST>(ctx, sf, tr, ti))) break;
+    for (int64_t s = 0; s < n; ++s) {
+      if ((rc = col_dispatch<T, false>(ctx, sf))) break;
+      if ((rc = row_dispatch<T, ROW_MID>(ctx, sf, tr, ti))) break;
+      if ((rc = col_dispatch<T, true>(ctx, sf))) break;
+      if (s + 1 < n)
+        rc = row_dispatch<T, ROW_JOIN>(ctx, sf, tr, ti);
+      else
+        rc = row_dispatch<T, ROW_LAST>(ctx, sf, tr, ti);
+      if (rc) break;
+    }
+  }
+  ctx->win_lo = 0;
+  ctx->win_n = p.batch;
+  if (rc) return rc;
   ctx->last_kernel = "strang_fused_lds_fft";
   return PDEOPT_OK;
 }
@@ -421,21 +446,24 @@ int imex_rows(pdeopt_ctx* ctx, StrangFused& sf, bool forward, double dt) {
   using E = RegFft<T, N>;
   constexpr int F = 256 / E::TT;
   const pdeopt_problem& p = ctx->prob;
-  const int npairs = (p.batch + 1) / 2;
+  // environment window (win_lo even): pointers pre-offset, the kernels see win_n environments
+  const int64_t cells = (int64_t)p.nx * p.ny, w0 = ctx->win_lo;
+  const int npairs = (ctx->win_n + 1) / 2;
   const size_t lds = (size_t)F * fft_lds_pitch<N>() * sizeof(Cx<T>);
   const int blocks = (int)((int64_t)npairs * p.nx / F);
+  Cx<T>* const cw = (Cx<T>*)sf.cwork + (w0 / 2) * cells;
   if (forward) {
     auto kern = imex_row_fwd_reg_kernel<T, N>;
     int rc = allow_lds(ctx, kern, lds);
     if (rc) return rc;
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, ctx->stream, (const T*)ctx->TA, (Cx<T>*)sf.cwork,
-                       (const Cx<T>*)sf.tw_y, p.nx, p.batch);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, ctx->stream, (const T*)ctx->TA + w0 * cells, cw,
+                       (const Cx<T>*)sf.tw_y, p.nx, ctx->win_n);
   } else {
     auto kern = imex_row_inv_reg_kernel<T, N>;
     int rc = allow_lds(ctx, kern, lds);
     if (rc) return rc;
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, ctx->stream, (const Cx<T>*)sf.cwork, (T*)ctx->Y,
-                       (const Cx<T>*)sf.tw_y, (T)dt, p.nx, p.batch);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, ctx->stream, (const Cx<T>*)cw, (T*)ctx->Y + w0 * cells,
+                       (const Cx<T>*)sf.tw_y, (T)dt, p.nx, ctx->win_n);
   }
   PDEOPT_HIP_CHECK(ctx, hipGetLastError());
   return PDEOPT_OK;
@@ -446,12 +474,13 @@ int imex_cols(pdeopt_ctx* ctx, StrangFused& sf) {
   constexpr int C = cols_per_block<T>();
   constexpr int PTS = col_pts<T, N>();
   const pdeopt_problem& p = ctx->prob;
-  const int npairs = (p.batch + 1) / 2;
+  const int npairs = (ctx->win_n + 1) / 2;
   const size_t lds = (size_t)C * fft_lds_pitch<N>() * sizeof(Cx<T>);
   auto kern = strang_col_reg_kernel<T, N, C, PTS, false>;  // FFT_x -> * multiplier -> IFFT_x, in place
   int rc = allow_lds(ctx, kern, lds);
   if (rc) return rc;
-  hipLaunchKernelGGL(kern, dim3(p.ny / C, npairs), dim3(C * N / PTS), lds, ctx->stream, (Cx<T>*)sf.cwork,
+  hipLaunchKernelGGL(kern, dim3(p.ny / C, npairs), dim3(C * N / PTS), lds, ctx->stream,
+                     (Cx<T>*)sf.cwork + (int64_t)(ctx->win_lo / 2) * p.nx * p.ny,
                      (const Cx<T>*)sf.imex_mult, (const Cx<T>*)sf.tw_x, p.ny, (const double*)nullptr, 0, 1.0);
   PDEOPT_HIP_CHECK(ctx, hipGetLastError());
   return PDEOPT_OK;
@@ -503,27 +532,45 @@ int imex_fused_t(pdeopt_ctx* ctx, double dt, int64_t n) {
     sf.imex_dt = dt;
     sf.imex_A = ctx->imex_A;
   }
-  for (int64_t s = 0; s < n; ++s) {
-    if ((rc = launch_rhs(ctx, ctx->Y, ctx->TA, 0.0))) return rc;
-    switch (p.ny) {
-#define X(NN) case NN: rc = imex_rows<T, NN>(ctx, sf, true, dt); break;
-      PDEOPT_FFT_SIZES(X)
-#undef X
+  // group by group (an even number of environments each): state + slope + spectrum work field are 12 B/cell
+  int group = p.batch;
+  if (ctx->opt_group_envs > 0) {
+    group = (int)std::min<int64_t>((ctx->opt_group_envs + 1) & ~1LL, p.batch);
+  } else if (ctx->opt_group_envs == 0) {
+    const size_t per_env = (size_t)cells * 3 * sizeof(T);
+    const int64_t fit = std::max<int64_t>(2, (int64_t)((192ull << 20) / per_env) & ~1LL);
+    if (fit < p.batch && n > 1) {
+      const int ngroups = (int)((p.batch + fit - 1) / fit);
+      group = ((p.batch + ngroups - 1) / ngroups + 1) & ~1;
     }
-    if (rc) return rc;
-    switch (p.nx) {
-#define X(NN) case NN: rc = imex_cols<T, NN>(ctx, sf); break;
-      PDEOPT_FFT_SIZES(X)
-#undef X
-    }
-    if (rc) return rc;
-    switch (p.ny) {
-#define X(NN) case NN: rc = imex_rows<T, NN>(ctx, sf, false, dt); break;
-      PDEOPT_FFT_SIZES(X)
-#undef X
-    }
-    if (rc) return rc;
   }
+  for (int lo = 0; lo < p.batch && !rc; lo += group) {
+    ctx->win_lo = lo;
+    ctx->win_n = std::min(group, p.batch - lo);
+    for (int64_t s = 0; s < n && !rc; ++s) {
+      if ((rc = launch_rhs(ctx, ctx->Y, ctx->TA, 0.0))) break;
+      switch (p.ny) {
+#define X(NN) case NN: rc = imex_rows<T, NN>(ctx, sf, true, dt); break;
+        PDEOPT_FFT_SIZES(X)
+#undef X
+      }
+      if (rc) break;
+      switch (p.nx) {
+#define X(NN) case NN: rc = imex_cols<T, NN>(ctx, sf); break;
+        PDEOPT_FFT_SIZES(X)
+#undef X
+      }
+      if (rc) break;
+      switch (p.ny) {
+#define X(NN) case NN: rc = imex_rows<T, NN>(ctx, sf, false, dt); break;
+        PDEOPT_FFT_SIZES(X)
+#undef X
+      }
+    }
+  }
+  ctx->win_lo = 0;
+  ctx->win_n = p.batch;
+  if (rc) return rc;
   ctx->last_kernel += "+imex_fused_lds_fft";
   return PDEOPT_OK;
 }
