@@ -30,7 +30,11 @@ int launch_pair(pdeopt_ctx* ctx, int pair, const void* in, const void* y, const 
   s.dbg = (int)ctx->opt_debug_ablate;
   ctx->n_stage_launches++;
   const int cl = classify_closures(p.mu, p.mob);
-  const int rpt = tiled_rpt(ctx);
+  // tile height of the pair kernels.  CH: 32 rows (512-thread workgroups) where they divide the grid --
+  // less redundant ring work at the same VGPR count, +4.5 % on 1024^2 same-box once the kernel sat at
+  // 78 / 88 VGPRs -- otherwise 16; PDEOPT_OPT_TILE_ROWS overrides.  AC follows the per-stage kernels.
+  int rpt = tiled_rpt(ctx);
+  if (p.equation == PDEOPT_EQ_CAHN_HILLIARD && ctx->opt_tile_rows == 0) rpt = (p.nx % 32 == 0) ? 4 : 2;
   char name[96];
   snprintf(name, sizeof(name), "stage_pair<%s,%s,%s,rows%d>", sizeof(T) == 4 ? "f32" : "f64",
            p.equation == PDEOPT_EQ_ALLEN_CAHN ? "AC" : "CH", cl == CL_LOGIT ? "logit" : "poly", 8 * rpt);

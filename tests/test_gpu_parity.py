@@ -627,6 +627,7 @@ def test_pipelined_pair_equals_classic(dtype, shape, batch, closures):
     for mode in (1, 2, 3):
         eng = P.HipEngine()
         eng.set_fuse_stages(mode)
+        eng.set_tile_rows(16)  # the persistent / wave-local variants are 16-row kernels
         eng.configure(dtype=dtype, batch=batch, **eq._engine_problem())
         eng.set_env_params(0, kappa=0.002 * (1.0 + 0.1 * np.arange(batch)))
         eng.set_state(u)
@@ -690,3 +691,28 @@ def test_allen_cahn_single_pass_rk4_equals_stage_pairs(shape, batch):
     for i in range(40):
         ref = O.rk4_step(f, 0.0, ref, 5e-5)
     assert rel_l2(outs[0][0].astype(np.float64) - u[0], ref - u[0]) < 5e-4
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_pair_kernel_tile_heights_agree(dtype):
+    """16-row (256-thread) and 32-row (512-thread, the default where 32 divides nx) tiles of the fused CH
+    pair kernel run the same per-cell arithmetic; they are different template instantiations, so hipcc's
+    FMA contraction may differ in an ulp on a few cells (spelling every FMA out costs 4.5 %)."""
+    rng = np.random.default_rng(41)
+    dom = std_domain(P, 256, 384)
+    eq = P.CahnHilliard2DPeriodic(dom, 0.002, MU["regsol"], MOB["c1mc"])
+    u = white_noise_state(rng, (3, 256, 384), dtype, "c")
+    outs = {}
+    for rows in (16, 32, 0):
+        eng = P.HipEngine()
+        eng.set_tile_rows(rows)
+        eng.configure(dtype=dtype, batch=3, **eq._engine_problem())
+        eng.set_state(u)
+        eng.advance(L.INT_RK4, 2e-7, 6)
+        outs[rows] = eng.get_state()
+        assert f"rows{rows or 32}" in eng.last_kernel, eng.last_kernel
+        eng.close()
+    eps = np.finfo(dtype).eps
+    np.testing.assert_allclose(outs[32], outs[16], rtol=0, atol=4 * eps)
+    assert np.mean(outs[32] != outs[16]) < 0.01
+    np.testing.assert_array_equal(outs[0], outs[32])
