@@ -32,8 +32,13 @@ struct QuadArgs {
   ClosureSpec mu, mob;
 };
 
+#ifndef PDEOPT_AC4_THREADS
+#define PDEOPT_AC4_THREADS 512
+#endif
 struct Ac4Geom {
-  static constexpr int V = 4, RPT = 2, TX = 16, PV = kLanesPerRow + 2, P = PV * V, TY = kLanesPerRow * V;
+  static constexpr int NT = PDEOPT_AC4_THREADS;  // 256 -> 16-row tiles, 512 -> 32-row tiles
+  static constexpr int V = 4, RPT = 2, TX = (NT / kLanesPerRow) * RPT, PV = kLanesPerRow + 2, P = PV * V,
+                       TY = kLanesPerRow * V;
   static constexpr int kRows = TX + 8;  // LDS rows: tile row + 4
   static constexpr size_t lds_bytes() { return (size_t)(2 * kRows * P + 3 * V) * sizeof(float); }
   // ring of stage with halo h (the region tile+h minus the tile): 2h full rows + 2 side vectors per tile row
@@ -41,13 +46,14 @@ struct Ac4Geom {
 };
 
 template <int CL, bool RAGGED>
-__global__ __launch_bounds__(256) void ac_rk4_quad_kernel(const QuadArgs<float> a, const int tiles_i, const int tiles_j,
+__global__ __launch_bounds__(Ac4Geom::NT) void ac_rk4_quad_kernel(const QuadArgs<float> a, const int tiles_i, const int tiles_j,
                                                           const int nblk, const int xcd_remap) {
   using T = float;
   using Vec = typename VecOf<T>::type;
   using G = Ac4Geom;
   constexpr int V = G::V, RPT = G::RPT, TX = G::TX, PV = G::PV, P = G::P, TY = G::TY;
-  static_assert(G::ring(3) <= 256, "largest ring must fit one pass");
+  constexpr int NT = G::NT;
+  static_assert(G::ring(3) <= NT, "largest ring must fit one pass");
 
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   T* const sY = reinterpret_cast<T*>(smem_raw) + V;  // rows: tile row + 4, cols: tile col + V
@@ -83,8 +89,8 @@ __global__ __launch_bounds__(256) void ac_rk4_quad_kernel(const QuadArgs<float> 
   // ---- load y on tile + 4 into both arrays' source (sY); stage 1 reads sY directly
   constexpr int kLoadVecs = G::kRows * PV;
 #pragma unroll
-  for (int it = 0; it < (kLoadVecs + 255) / 256; ++it) {
-    const int idx = tid + it * 256;
+  for (int it = 0; it < (kLoadVecs + NT - 1) / NT; ++it) {
+    const int idx = tid + it * NT;
     if (idx < kLoadVecs) {
       const int row = idx / PV;
       const int cv = idx - row * PV;
@@ -200,12 +206,12 @@ inline int launch_ac_quad(pdeopt_ctx* ctx, const void* y, void* out, double dt) 
   const int nblk = (int)nblk64;
   const bool ragged = p.nx % G::TX != 0 || p.ny % G::TY != 0;
   ctx->n_stage_launches++;
-  ctx->last_kernel = "rk4_quad<f32,AC,poly,rows16>";
+  ctx->last_kernel = G::TX == 32 ? "rk4_quad<f32,AC,poly,rows32>" : "rk4_quad<f32,AC,poly,rows16>";
   if (ragged)
-    hipLaunchKernelGGL((ac_rk4_quad_kernel<CL_POLY, true>), dim3(nblk), dim3(256), G::lds_bytes(), ctx->stream, s, tiles_i,
+    hipLaunchKernelGGL((ac_rk4_quad_kernel<CL_POLY, true>), dim3(nblk), dim3(G::NT), G::lds_bytes(), ctx->stream, s, tiles_i,
                        tiles_j, nblk, (nblk % 8 == 0) ? 1 : 0);
   else
-    hipLaunchKernelGGL((ac_rk4_quad_kernel<CL_POLY, false>), dim3(nblk), dim3(256), G::lds_bytes(), ctx->stream, s, tiles_i,
+    hipLaunchKernelGGL((ac_rk4_quad_kernel<CL_POLY, false>), dim3(nblk), dim3(G::NT), G::lds_bytes(), ctx->stream, s, tiles_i,
                        tiles_j, nblk, (nblk % 8 == 0) ? 1 : 0);
   PDEOPT_HIP_CHECK(ctx, hipGetLastError());
   return PDEOPT_OK;
