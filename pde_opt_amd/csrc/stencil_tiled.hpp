@@ -78,7 +78,7 @@ __device__ __forceinline__ int tile_wrap(int i, int n, bool ragged) {
 
 constexpr int kLanesPerRow = 32;   // vectors per tile row
 constexpr int kPV = kLanesPerRow + 2;  // vectors per LDS row (one halo vector each side)
-// RPT = rows per thread; a tile has TX = 8 * RPT rows (8 row groups of 32 lanes = 256 threads)
+// RPT selects the tile height TX = 8 * RPT (2: 16 rows / 256 threads, 4: 32 rows / 512 threads)
 
 template <typename T, int EQ, int RPT>
 constexpr size_t tiled_lds_bytes() {
@@ -90,14 +90,17 @@ constexpr size_t tiled_lds_bytes() {
 }
 
 template <typename T, int EQ, int CL, int OUT_MODE, int ACC_MODE, bool Y_FROM_TILE, int RPT>
-__global__ __launch_bounds__(256) void stage_tiled_kernel(const StageArgs<T> a, const int tiles_i,
+__global__ __launch_bounds__(RPT == 4 ? 512 : 256) void stage_tiled_kernel(const StageArgs<T> a, const int tiles_i,
                                                           const int tiles_j, const int nblk,
                                                           const int xcd_remap) {
   using Vec = typename VecOf<T>::type;
   constexpr int V = VecOf<T>::V;
   constexpr int HR = (EQ == PDEOPT_EQ_CAHN_HILLIARD) ? 2 : 1;
+  // RPT selects the tile height: 2 -> 16 rows x 256 threads, 4 -> 32 rows x 512 threads; a thread always
+  // owns 2 rows (taller tiles by more threads, not more registers)
+  constexpr int NT = RPT == 4 ? 512 : 256;
   constexpr int TX = 8 * RPT;
-  constexpr int kRowsPerThread = RPT;
+  constexpr int kRowsPerThread = 2;
   constexpr int PV = kPV;
   constexpr int P = PV * V;  // LDS row pitch in elements
   constexpr bool kIsCH = (EQ == PDEOPT_EQ_CAHN_HILLIARD);
@@ -152,8 +155,8 @@ __global__ __launch_bounds__(256) void stage_tiled_kernel(const StageArgs<T> a, 
   // ---- phase 1: tile + halo -> LDS
   constexpr int kLoadVecs = (TX + 2 * HR) * PV;
 #pragma unroll
-  for (int it = 0; it < (kLoadVecs + 255) / 256; ++it) {
-    const int idx = tid + it * 256;
+  for (int it = 0; it < (kLoadVecs + NT - 1) / NT; ++it) {
+    const int idx = tid + it * NT;
     if (idx < kLoadVecs) {
       const int row = idx / PV;
       const int cv = idx - row * PV;
@@ -175,7 +178,7 @@ __global__ __launch_bounds__(256) void stage_tiled_kernel(const StageArgs<T> a, 
     // ---- phase 2: mu on the tile + 1 ring (rows -1..TX), one closure evaluation per point
     constexpr int kMuVecs = (TX + 2) * PV;
 #pragma unroll 1
-    for (int idx = tid; idx < kMuVecs; idx += 256) {
+    for (int idx = tid; idx < kMuVecs; idx += NT) {
       const int r = idx / PV;  // mu row r <-> tile row r-1 <-> su row r+1
       const int cv = idx - r * PV;
       const T* c_ = su + (r + 1) * P + cv * V;
@@ -197,7 +200,7 @@ __global__ __launch_bounds__(256) void stage_tiled_kernel(const StageArgs<T> a, 
     if constexpr (kMobInPlace) {
       // expensive mobility closures: evaluate once per point, in place over u (rows -1..TX)
 #pragma unroll 1
-      for (int idx = tid; idx < kMuVecs; idx += 256) {
+      for (int idx = tid; idx < kMuVecs; idx += NT) {
         const int r = idx / PV;
         const int cv = idx - r * PV;
         T* c_ = su + (r + 1) * P + cv * V;
@@ -346,7 +349,7 @@ int launch_tiled_rpt(pdeopt_ctx* ctx, const StageArgs<T>& s) {
   const int nblk = (int)nblk64;
   const size_t lds = tiled_lds_bytes<T, EQ, RPT>();
   hipLaunchKernelGGL((stage_tiled_kernel<T, EQ, CL, OUT_MODE, ACC_MODE, Y_FROM_TILE, RPT>), dim3(nblk),
-                     dim3(256), lds, ctx->stream, s, tiles_i, tiles_j, nblk,
+                     dim3(RPT == 4 ? 512 : 256), lds, ctx->stream, s, tiles_i, tiles_j, nblk,
                      (nblk % 8 == 0) ? 1 : 0);
   PDEOPT_HIP_CHECK(ctx, hipGetLastError());
   return PDEOPT_OK;
