@@ -231,9 +231,14 @@ GraphStructure graph_structure(const pdeopt_problem& p) {
 int advance_explicit(pdeopt_ctx* ctx, int integrator, double t0, double dt, int64_t n) {
   int rc;
   if ((rc = ensure_buffer(ctx, &ctx->TA, ctx->total_bytes))) return rc;
-  if (integrator == PDEOPT_INT_RK4) {
+  // Euler: two substeps per launch through the stage-pair kernels where they exist
+  //   PAIR_12 with aA = bA = bB = dt:  w = y + dt f(y),  ACC = y + dt f(y) + dt f(w) = two Euler steps
+  const bool euler2 = integrator == PDEOPT_INT_EULER && ctx->opt_kernel_path != 1 &&
+                      ctx->prob.derivs == PDEOPT_DERIVS_FD && n >= 2 &&
+                      (ctx->prob.dtype == PDEOPT_F32 ? fused_supported<float>(ctx) : fused_supported<double>(ctx));
+  if (integrator == PDEOPT_INT_RK4 || euler2) {
     if ((rc = ensure_buffer(ctx, &ctx->TB, ctx->total_bytes))) return rc;
-    if ((rc = ensure_buffer(ctx, &ctx->ACC, ctx->total_bytes))) return rc;
+    if (integrator == PDEOPT_INT_RK4 && (rc = ensure_buffer(ctx, &ctx->ACC, ctx->total_bytes))) return rc;
   } else if (integrator != PDEOPT_INT_EULER) {
     return fail(ctx, PDEOPT_EINVAL, "integrator %d is not an explicit fixed-step integrator", integrator);
   }
@@ -267,6 +272,13 @@ int advance_explicit(pdeopt_ctx* ctx, int integrator, double t0, double dt, int6
 
   // Allen-Cahn fp32: the whole RK4 substep in one pass (2 words per cell instead of 7)
   const bool quad = integrator == PDEOPT_INT_RK4 && ac_quad_supported(ctx);
+
+  // two Euler substeps in one launch (result into TA, TB takes the kernel's unused y + dt k2 output)
+  auto euler_pair = [&](void*& Y, void*& TA) -> int {
+    const int r = launch_pair_dt(ctx, PAIR_12, Y, nullptr, nullptr, ctx->TB, TA, dt, dt, dt, dt);
+    std::swap(Y, TA);
+    return r;
+  };
 
   // one substep on the current window; Y / TA are swapped where the integrator ping-pongs
   auto substep = [&](void*& Y, void*& TA, int64_t step) -> int {
@@ -318,7 +330,7 @@ int advance_explicit(pdeopt_ctx* ctx, int integrator, double t0, double dt, int6
     GraphKey key;
     memset(&key, 0, sizeof(key));  // padding bytes take part in the memcmp below
     key.integrator = integrator;
-    key.fused = quad ? 100 : (fused ? (int)(1 + ctx->opt_fuse_stages) : 0);
+    key.fused = quad ? 100 : (euler2 ? 50 : (fused ? (int)(1 + ctx->opt_fuse_stages) : 0));
     key.dt = dt;
     key.Y = ctx->Y; key.TA = ctx->TA; key.TB = ctx->TB; key.ACC = ctx->ACC; key.KS = ctx->KS;
     key.ep = ctx->env_params_dev;
@@ -332,7 +344,14 @@ int advance_explicit(pdeopt_ctx* ctx, int integrator, double t0, double dt, int6
       const int64_t launches_before = ctx->n_stage_launches;
       hipGraph_t graph = nullptr;
       PDEOPT_HIP_CHECK(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
-      for (int u = 0; u < kGraphUnit && !rc; ++u) rc = substep(Y, TA, u);
+      for (int u = 0; u < kGraphUnit && !rc; ++u) {
+        if (euler2) {
+          rc = euler_pair(Y, TA);
+          ++u;
+        } else {
+          rc = substep(Y, TA, u);
+        }
+      }
       const hipError_t e_end = hipStreamEndCapture(ctx->stream, &graph);
       ctx->graph_launches_per_replay = ctx->n_stage_launches - launches_before;
       ctx->n_stage_launches = launches_before;
@@ -362,7 +381,14 @@ int advance_explicit(pdeopt_ctx* ctx, int integrator, double t0, double dt, int6
     ctx->win_n = std::min(group, batch - lo);
     void* Y = ctx->Y;
     void* TA = ctx->TA;
-    for (int64_t s = done; s < n && !rc; ++s) rc = substep(Y, TA, s);
+    for (int64_t s = done; s < n && !rc; ++s) {
+      if (euler2 && s + 1 < n) {
+        rc = euler_pair(Y, TA);
+        ++s;
+      } else {
+        rc = substep(Y, TA, s);
+      }
+    }
     y_final = Y;  // every group performs the same number of swaps
     ta_final = TA;
     if (rc) break;
