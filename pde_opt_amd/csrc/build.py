@@ -42,6 +42,11 @@ CXXFLAGS = [
     "-fPIC",
     f"--offload-arch={ARCH}",
     "-fno-gpu-rdc",
+    # no SLP packing of fp32 pairs into v_pk_* instructions: on gfx950 a packed fp32 FMA issues in 2.4 ns per
+    # wave against 2 x 1.45 ns for the two scalar ones it replaces only when nothing else is waiting, and the
+    # register pairing it needs costs moves (tools/valubench.hip).  Same-box A/B with the flag: CH RK4 pair
+    # kernel +6.5 %, Strang +5 %, IMEX +6 %.
+    "-fno-slp-vectorize",
     "-Wall",
     "-Wno-unused-function",
     "-I/opt/rocm/include",

@@ -4,7 +4,7 @@ import collections, os, re, subprocess, sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 src = os.path.join(HERE, "..", "pde_opt_amd", "csrc", sys.argv[1])
 out = "/tmp/_isa.s"
-subprocess.run(["hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-I/opt/rocm/include", "-S",
+subprocess.run(["hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-I/opt/rocm/include", "-fno-slp-vectorize", "-S",
                 "--cuda-device-only", src, "-o", out], check=True, stderr=subprocess.DEVNULL)
 lines = open(out).read().splitlines()
 starts = [i for i, l in enumerate(lines) if re.match(r"^_Z\w+:", l)]

@@ -6,7 +6,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "..", "pde_opt_amd", "csrc")
 src = sys.argv[1]
 flt = sys.argv[2] if len(sys.argv) > 2 else ""
-cmd = ["hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-I/opt/rocm/include", "-c",
+cmd = ["hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-I/opt/rocm/include", "-fno-slp-vectorize", "-c",
        os.path.join(CSRC, src), "-o", "/tmp/_kr.o", "-Rpass-analysis=kernel-resource-usage"]
 err = subprocess.run(cmd, capture_output=True, text=True).stderr
 rows, cur = [], {}

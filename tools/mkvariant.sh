@@ -8,7 +8,7 @@ SRC=${SRC:-stencil}
 ROOT=$(cd $(dirname $0)/.. && pwd)
 mkdir -p $ROOT/variants
 C=$ROOT/pde_opt_amd/csrc
-hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-gpu-rdc -Wno-unused-function -I/opt/rocm/include "$@" -c $C/$SRC.hip -o $ROOT/variants/${SRC}_$NAME.o
+hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-gpu-rdc -fno-slp-vectorize -Wno-unused-function -I/opt/rocm/include "$@" -c $C/$SRC.hip -o $ROOT/variants/${SRC}_$NAME.o
 OBJS=""
 for o in api stencil reduce spectral halo strang_fused; do
   if [ $o = $SRC ]; then OBJS="$OBJS $ROOT/variants/${SRC}_$NAME.o"; else OBJS="$OBJS $C/build/$o.o"; fi
