@@ -120,24 +120,35 @@ struct RegFft {
     }
   }
 
-  // re-group from the slot layout of stage FROM to that of stage TO through the sequence's LDS image
+  // the two halves of a re-grouping through the sequence's LDS image: put() stores the registers in
+  // the slot layout of stage ST, get() loads them in the slot layout of stage ST
+  template <int ST>
+  static __device__ __forceinline__ void put(const C (&v)[PTS], C* __restrict__ seq, int j) {
+    constexpr int R = P::radix(ST);
+#pragma unroll
+    for (int u = 0; u < PTS / R; ++u) {
+      C* const b = seq + base<ST>(j, u);
+#pragma unroll
+      for (int m = 0; m < R; ++m) b[off<ST>(m)] = v[u * R + m];
+    }
+  }
+  template <int ST>
+  static __device__ __forceinline__ void get(C (&v)[PTS], const C* __restrict__ seq, int j) {
+    constexpr int R = P::radix(ST);
+#pragma unroll
+    for (int u = 0; u < PTS / R; ++u) {
+      const C* const b = seq + base<ST>(j, u);
+#pragma unroll
+      for (int m = 0; m < R; ++m) v[u * R + m] = b[off<ST>(m)];
+    }
+  }
+  // re-group from the slot layout of stage FROM to that of stage TO
   // (WL: the threads of the sequence are lanes of one wave)
   template <int FROM, int TO, bool WL>
   static __device__ __forceinline__ void exchange(C (&v)[PTS], C* __restrict__ seq, int j) {
-    constexpr int RF = P::radix(FROM), RT = P::radix(TO);
-#pragma unroll
-    for (int u = 0; u < PTS / RF; ++u) {
-      C* const b = seq + base<FROM>(j, u);
-#pragma unroll
-      for (int m = 0; m < RF; ++m) b[off<FROM>(m)] = v[u * RF + m];
-    }
+    put<FROM>(v, seq, j);
     reg_fft_sync<WL>();
-#pragma unroll
-    for (int u = 0; u < PTS / RT; ++u) {
-      const C* const b = seq + base<TO>(j, u);
-#pragma unroll
-      for (int m = 0; m < RT; ++m) v[u * RT + m] = b[off<TO>(m)];
-    }
+    get<TO>(v, seq, j);
     reg_fft_sync<WL>();  // the next exchange overwrites the image
   }
 
@@ -159,6 +170,43 @@ struct RegFft {
       exchange<ST, ST - 1, WL>(v, seq, j);
       dit<SIGN, WL, ST - 1>(v, seq, tw, j);
     }
+  }
+
+  // The same transforms for a workgroup whose GLOBAL side wants one thread layout (thread jo of a
+  // sequence anywhere in the workgroup, e.g. the sequence index fastest across lanes for a strided
+  // pass) while stages 1 .. L-1 run with the TT threads of a sequence inside one wave (thread ji):
+  // stage 0 only needs the registers, so the exchange between stages 0 and 1 is where the layout
+  // changes and the only place that needs a workgroup barrier -- one per transform, because after it
+  // an image is touched by nobody but the wave that owns the sequence.
+  // (seqo / seqi: the image of the sequence the thread belongs to in the outer / inner layout.)
+  template <int SIGN>
+  static __device__ __forceinline__ void dif_split(C (&v)[PTS], C* __restrict__ seqo, int jo, C* __restrict__ seqi,
+                                                   int ji, const C* __restrict__ tw) {
+    static_assert(L >= 2 && kWaveLocal, "needs an exchange and wave-sized sequences");
+    stage<0, SIGN, false>(v, tw, jo);
+    put<0>(v, seqo, jo);
+    __syncthreads();
+    get<1>(v, seqi, ji);
+    reg_fft_sync<true>();
+    dif<SIGN, true, 1>(v, seqi, tw, ji);
+  }
+  template <int SIGN, int ST = L - 1>
+  static __device__ __forceinline__ void dit_inner(C (&v)[PTS], C* __restrict__ seq, const C* __restrict__ tw, int j) {
+    stage<ST, SIGN, true>(v, tw, j);
+    if constexpr (ST > 1) {
+      exchange<ST, ST - 1, true>(v, seq, j);
+      dit_inner<SIGN, ST - 1>(v, seq, tw, j);
+    }
+  }
+  template <int SIGN>
+  static __device__ __forceinline__ void dit_split(C (&v)[PTS], C* __restrict__ seqi, int ji, C* __restrict__ seqo,
+                                                   int jo, const C* __restrict__ tw) {
+    static_assert(L >= 2 && kWaveLocal, "needs an exchange and wave-sized sequences");
+    dit_inner<SIGN>(v, seqi, tw, ji);
+    put<1>(v, seqi, ji);
+    __syncthreads();
+    get<0>(v, seqo, jo);
+    stage<0, SIGN, true>(v, tw, jo);
   }
 };
 

@@ -28,7 +28,7 @@ namespace pdeopt {
 struct StrangFused {
   void* tw_x = nullptr;  // twiddle tables exp(-2 pi i n / N) in the problem dtype
   void* tw_y = nullptr;
-  void* mult = nullptr;  // E / (nx ny), complex [nx][ny]
+  void* mult = nullptr;  // E / (nx ny), complex, laid out by col_mult_index()
   void* dens = nullptr;  // |psi0|^2, real [batch][nx][ny]
   double* partial = nullptr;
   double key_dt = NAN, key_tr = NAN, key_ti = NAN;
@@ -137,8 +137,20 @@ __global__ __launch_bounds__(256) void strang_row_reg_kernel(Cx<T>* __restrict__
 }
 
 // The column pass with the transforms in registers: C adjacent columns x N/8 threads per workgroup,
-// the column index fastest across lanes (C x 8 bytes contiguous per row: 128-byte segments at C = 16),
-// so the threads of one column sit in different waves and the exchanges use workgroup barriers.
+// the column index fastest across lanes on the global side (C x 8 bytes contiguous per row: 128-byte
+// segments at C = 16), so there the threads of one column sit in different waves.
+//
+// Up to N = 512 only stage 0 of a transform runs in that layout; the exchange after it hands every
+// column to ONE wave (RegFft::dif_split / dit_split) and the remaining stages need no barrier: 2 per
+// pass instead of 8.  Same-box: the 512^2 pass drops from 77 to ~40 us, which is what the same kernel
+// takes with the transforms removed (pure traffic, 6.7 TB/s out of the Infinity Cache); split step
+// x 128 environments 2498 -> 2913 env-steps/s.  At N = 1024 (16 points per thread, one workgroup per CU)
+// the wave-per-column layout measured 14 % SLOWER (50 vs 44 us: its last-stage LDS reads are 4-way
+// instead of 2-way bank-conflicted and nothing overlaps them), so that size keeps the barrier form.
+#ifndef PDEOPT_COL_WL
+#define PDEOPT_COL_WL 1
+#endif
+constexpr bool col_wave_local(int n) { return PDEOPT_COL_WL && n <= 512; }
 template <typename T, int N, int C, int PTS, bool SCALED>
 __global__ __launch_bounds__(C* N / PTS) void strang_col_reg_kernel(Cx<T>* __restrict__ psi,
                                                                   const Cx<T>* __restrict__ mult,
@@ -155,14 +167,12 @@ __global__ __launch_bounds__(C* N / PTS) void strang_col_reg_kernel(Cx<T>* __res
   // uniform base pointers + 32-bit per-thread offsets: one VGPR per address instead of a 64-bit pair
   // (the 16-point threads of the N = 1024 pass run at the 128-VGPR limit of a 1024-thread workgroup)
   Cx<T>* const gb = psi + (int64_t)env * N * ny + blockIdx.x * C;
-  const Cx<T>* const mb = mult + blockIdx.x * C;
   Cx<T> v[PTS];
 #pragma unroll
   for (int m = 0; m < PTS; ++m) v[m] = gb[E::natural(j, m) * ny + c];
-  E::template dif<-1, false>(v, seq, tw, j);
-  T scale = T(1);
+  // 1 / sqrt(sum |psi|^2 dx^2) from the row pass's partial sums; published by the barriers of the transform
+  __shared__ double scale_sh;
   if constexpr (SCALED) {
-    __shared__ double scale_sh;
     if (tid < 64) {
       double sum = 0.0;
       for (int q = tid; q < blocks_per_env; q += 64) sum += partial[(int64_t)env * blocks_per_env + q];
@@ -170,12 +180,22 @@ __global__ __launch_bounds__(C* N / PTS) void strang_col_reg_kernel(Cx<T>* __res
       for (int o = 32; o > 0; o >>= 1) sum += __shfl_down(sum, o, 64);
       if (tid == 0) scale_sh = 1.0 / sqrt(sum * dx2);
     }
-    __syncthreads();
-    scale = (T)scale_sh;
   }
+  constexpr bool WL = col_wave_local(N);
+  // WL: stage 0 in the load layout, everything after it with a column per wave
+  const int ji = tid % E::TT;
+  Cx<T>* const seqi = reinterpret_cast<Cx<T>*>(smem_raw) + (tid / E::TT) * NP;
+  const Cx<T>* const mb = WL ? mult + (int64_t)(blockIdx.x * C + tid / E::TT) * N  // transposed: [ny][nx]
+                             : mult + blockIdx.x * C;
+  if constexpr (WL)
+    E::template dif_split<-1>(v, seq, j, seqi, ji, tw);
+  else
+    E::template dif<-1, false>(v, seq, tw, j);
+  T scale = T(1);
+  if constexpr (SCALED) scale = (T)scale_sh;
 #pragma unroll
   for (int sl = 0; sl < PTS; ++sl) {
-    Cx<T> m = mb[E::freq(j, sl) * ny + c];
+    Cx<T> m = WL ? mb[E::freq(ji, sl)] : mb[E::freq(j, sl) * ny + c];
     m.re *= scale;
     m.im *= scale;
     v[sl] = cmul(v[sl], m);
@@ -183,7 +203,10 @@ __global__ __launch_bounds__(C* N / PTS) void strang_col_reg_kernel(Cx<T>* __res
       if (sl % 4 == 3) __builtin_amdgcn_sched_barrier(0);
     }
   }
-  E::template dit<+1, false>(v, seq, tw, j);
+  if constexpr (WL)
+    E::template dit_split<+1>(v, seqi, ji, seq, j, tw);
+  else
+    E::template dit<+1, false>(v, seq, tw, j);
 #pragma unroll
   for (int m = 0; m < PTS; ++m) gb[E::natural(j, m) * ny + c] = v[m];
 }
@@ -204,6 +227,11 @@ constexpr int cols_per_block() { return sizeof(T) == 4 ? PDEOPT_FFT_COLS : PDEOP
 #endif
 template <typename T, int N>
 constexpr int col_pts() { return PDEOPT_FFT_COL_PTS ? PDEOPT_FFT_COL_PTS : reg_default_pts<N>(); }
+
+// where the column pass expects the multiplier of frequency (kx, ky): it reads along kx
+inline size_t col_mult_index(int64_t kx, int64_t ky, int nx, int ny) {
+  return col_wave_local(nx) ? (size_t)(ky * nx + kx) : (size_t)(kx * ny + ky);
+}
 
 template <typename K>
 int allow_lds(pdeopt_ctx* ctx, K kernel, size_t bytes) {
@@ -324,7 +352,7 @@ int strang_fused_t(pdeopt_ctx* ctx, double dt, int64_t n) {
     const double inv_n = 1.0 / (double)cells;
     for (int64_t i = 0; i < cells; ++i) {
       const std::complex<double> e = std::exp(at[i] * 0.5 * tau) * inv_n;
-      m[i] = Cx<T>{(T)e.real(), (T)e.imag()};
+      m[col_mult_index(i / p.ny, i % p.ny, p.nx, p.ny)] = Cx<T>{(T)e.real(), (T)e.imag()};
     }
     if ((rc = ensure_buffer(ctx, &sf.mult, (size_t)cells * sizeof(Cx<T>)))) return rc;
     PDEOPT_HIP_CHECK(ctx, hipMemcpyAsync(sf.mult, m.data(), (size_t)cells * sizeof(Cx<T>), hipMemcpyHostToDevice, ctx->stream));
@@ -522,7 +550,7 @@ int imex_fused_t(pdeopt_ctx* ctx, double dt, int64_t n) {
         const int my = (p.ny - ky) % p.ny;
         const std::complex<double> v =
             0.5 * (mfull[(size_t)kx * p.ny + ky] + std::conj(mfull[(size_t)mx * p.ny + my]));
-        m[(size_t)kx * p.ny + ky] = Cx<T>{(T)v.real(), (T)v.imag()};
+        m[col_mult_index(kx, ky, p.nx, p.ny)] = Cx<T>{(T)v.real(), (T)v.imag()};
       }
     }
     if ((rc = ensure_buffer(ctx, &sf.imex_mult, (size_t)cells * sizeof(Cx<T>)))) return rc;
