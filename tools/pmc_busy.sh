@@ -16,15 +16,15 @@ for d in ("pmc_busy", "pmc_busy2"):
         print(d, "no counter file"); print(open("$OUT/%s.log" % d).read()[-1500:]); continue
     acc = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.Counter()
     for row in csv.DictReader(open(files[0])):
-        k = row["Kernel_Name"][:60]
+        k = row["Kernel_Name"][:72]
         acc[k][row["Counter_Name"]] += float(row["Counter_Value"])
     for row in csv.DictReader(open(files[0])):
         pass
     disp = collections.Counter()
     for row in csv.DictReader(open(files[0])):
-        disp[(row["Kernel_Name"][:60], row["Dispatch_Id"])] += 1
+        disp[(row["Kernel_Name"][:72], row["Dispatch_Id"])] += 1
     for k in acc:
         nd = len([1 for (kk, _) in disp if kk == k])
-        if "pair" in k or "stage" in k:
+        if any(t in k for t in ("pair", "stage", "quad", "col_reg", "row_")):
             print(k, "launches", nd, {c: "%.4g" % (v / nd) for c, v in acc[k].items()})
 PY
