@@ -52,7 +52,9 @@ __device__ __forceinline__ double t_logit<double>(double c) {
 //   CL_LOGIT1  : CL_LOGIT whose polynomial part is linear (the regular-solution model 3 (1 - 2c) of the
 //                headline workload): two FMAs less per evaluation in the VALU-bound fused CH kernel; bitwise
 //                equal to CL_LOGIT there, because coefficients past n are stored as zeros
-enum { CL_GENERIC = 0, CL_POLY = 1, CL_LOGIT = 2, CL_LOGIT1 = 3 };
+//   CL_POLY_M0 : CL_POLY with a constant mobility (Allen-Cahn's R = 1, BASELINE config 2): two FMAs less
+//                per evaluation in the VALU-bound single-pass RK4 kernel, bitwise equal on finite states
+enum { CL_GENERIC = 0, CL_POLY = 1, CL_LOGIT = 2, CL_LOGIT1 = 3, CL_POLY_M0 = 4 };
 
 template <typename T>
 __device__ __forceinline__ T series_generic(const ClosureSpec& s, const T* __restrict__ coef, T c) {
@@ -104,6 +106,8 @@ template <typename T, int CL>
 __device__ __forceinline__ T eval_mob(const ClosureSpec& s, const T* __restrict__ coef, T c) {
   if constexpr (CL == CL_GENERIC) {
     return closure_generic<T>(s, coef, c);
+  } else if constexpr (CL == CL_POLY_M0) {
+    return coef[0];
   } else {
     return (coef[2] * c + coef[1]) * c + coef[0];
   }

@@ -207,12 +207,20 @@ inline int launch_ac_quad(pdeopt_ctx* ctx, const void* y, void* out, double dt) 
   const bool ragged = p.nx % G::TX != 0 || p.ny % G::TY != 0;
   ctx->n_stage_launches++;
   ctx->last_kernel = G::TX == 32 ? "rk4_quad<f32,AC,poly,rows32>" : "rk4_quad<f32,AC,poly,rows16>";
-  if (ragged)
-    hipLaunchKernelGGL((ac_rk4_quad_kernel<CL_POLY, true>), dim3(nblk), dim3(G::NT), G::lds_bytes(), ctx->stream, s, tiles_i,
-                       tiles_j, nblk, (nblk % 8 == 0) ? 1 : 0);
-  else
-    hipLaunchKernelGGL((ac_rk4_quad_kernel<CL_POLY, false>), dim3(nblk), dim3(G::NT), G::lds_bytes(), ctx->stream, s, tiles_i,
-                       tiles_j, nblk, (nblk % 8 == 0) ? 1 : 0);
+  const int remap = (nblk % 8 == 0) ? 1 : 0;
+#ifndef PDEOPT_AC4_M0
+#define PDEOPT_AC4_M0 1
+#endif
+  const bool m0 = PDEOPT_AC4_M0 && p.mob.n <= 1;  // constant mobility (coefficients past n are stored as zeros)
+#define PDEOPT_QUAD_LAUNCH(CLV, RG) \
+  hipLaunchKernelGGL((ac_rk4_quad_kernel<CLV, RG>), dim3(nblk), dim3(G::NT), G::lds_bytes(), ctx->stream, s, tiles_i, \
+                     tiles_j, nblk, remap)
+  if (m0) {
+    if (ragged) PDEOPT_QUAD_LAUNCH(CL_POLY_M0, true); else PDEOPT_QUAD_LAUNCH(CL_POLY_M0, false);
+  } else {
+    if (ragged) PDEOPT_QUAD_LAUNCH(CL_POLY, true); else PDEOPT_QUAD_LAUNCH(CL_POLY, false);
+  }
+#undef PDEOPT_QUAD_LAUNCH
   PDEOPT_HIP_CHECK(ctx, hipGetLastError());
   return PDEOPT_OK;
 }

@@ -662,14 +662,15 @@ def test_linear_logit_class_is_bitwise_the_cubic_one():
     np.testing.assert_array_equal(outs[0], ref)
 
 
+@pytest.mark.parametrize("mob", ["one_plus_sq", "const015"])  # general / constant-mobility instantiation
 @pytest.mark.parametrize("shape,batch", [((512, 512), 2), ((100, 100), 3), ((64, 128), 5), ((48, 40), 1)])
-def test_allen_cahn_single_pass_rk4_equals_stage_pairs(shape, batch):
+def test_allen_cahn_single_pass_rk4_equals_stage_pairs(shape, batch, mob):
     """csrc/stencil_fused_ac4.hpp (all four RK4 stages in one pass, fp32) against the stage-pair kernels and
     the per-stage kernels: the same arithmetic per stage, results equal to rounding; ragged grids included."""
     rng = np.random.default_rng(29)
     nx, ny = shape
     dom = std_domain(P, nx, ny)
-    eq = P.AllenCahn2DPeriodic(dom, 0.002, MU["cubic"], MOB["one_plus_sq"])
+    eq = P.AllenCahn2DPeriodic(dom, 0.002, MU["cubic"], MOB[mob])
     u = white_noise_state(rng, (batch, nx, ny), np.float32, "sym")
     outs = {}
     for fuse in (0, 1, -1):  # auto (single pass), stage pairs, one launch per stage
@@ -686,7 +687,7 @@ def test_allen_cahn_single_pass_rk4_equals_stage_pairs(shape, batch):
     for other in (1, -1):
         assert rel_l2(outs[0].astype(np.float64) - u, outs[other].astype(np.float64) - u) < 2e-5
     hx, hy = dom.dx
-    f = lambda t, v: O.ac_rhs_fd(v, hx, hy, 0.002, MU["cubic"], MOB["one_plus_sq"])
+    f = lambda t, v: O.ac_rhs_fd(v, hx, hy, 0.002, MU["cubic"], MOB[mob])
     ref = u[0].astype(np.float64)
     for i in range(40):
         ref = O.rk4_step(f, 0.0, ref, 5e-5)
