@@ -72,21 +72,55 @@ __device__ __forceinline__ void dft8(Cx<T>* v) {
   v[2] = cadd(e2, o2); v[6] = csub(e2, o2);
   v[3] = cadd(e3, o3); v[7] = csub(e3, o3);
 }
+template <typename T, int SIGN>
+__device__ __forceinline__ void dft16(Cx<T>* v) {
+  // even / odd DFT8, then the radix-2 combine with w16^q = (cos(q pi/8), SIGN sin(q pi/8))
+  Cx<T> e[8], o[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    e[q] = v[2 * q];
+    o[q] = v[2 * q + 1];
+  }
+  dft8<T, SIGN>(e);
+  dft8<T, SIGN>(o);
+  const T h = T(0.70710678118654752440), c1 = T(0.92387953251128673848), s1 = T(SIGN) * T(0.38268343236508978178);
+  const T sc1 = T(SIGN) * c1, ss1 = T(SIGN) * s1;  // ss1 = sin(pi/8): s1 already carries SIGN
+  o[1] = cmul(o[1], Cx<T>{c1, s1});
+  o[3] = cmul(o[3], Cx<T>{ss1, sc1});
+  o[5] = cmul(o[5], Cx<T>{-ss1, sc1});
+  o[7] = cmul(o[7], Cx<T>{-c1, s1});
+  const Cx<T> si2 = mul_si<T, SIGN>(o[2]), si6 = mul_si<T, SIGN>(o[6]);
+  o[2] = {(o[2].re + si2.re) * h, (o[2].im + si2.im) * h};
+  o[4] = mul_si<T, SIGN>(o[4]);
+  o[6] = {(si6.re - o[6].re) * h, (si6.im - o[6].im) * h};
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    v[q] = cadd(e[q], o[q]);
+    v[q + 8] = csub(e[q], o[q]);
+  }
+}
 template <typename T, int R, int SIGN>
 __device__ __forceinline__ void dft_small(Cx<T>* v) {
+  if constexpr (R == 16) dft16<T, SIGN>(v);
   if constexpr (R == 8) dft8<T, SIGN>(v);
   if constexpr (R == 4) dft4<T, SIGN>(v[0], v[1], v[2], v[3]);
   if constexpr (R == 2) dft2<T, SIGN>(v);
 }
 
-// ---- radix plan of a power of two: as many 8s as fit, then a tail of 4 or 2
+// ---- radix plan of a power of two: as many 8s as fit, then a tail of 4 or 2.  N = 1024 (threads own
+// 16 points there, fft_reg.hpp) runs 16 x 8 x 8 instead of 8 x 8 x 8 x 2: one exchange through LDS
+// less per transform.
+#ifndef PDEOPT_FFT_RADIX16
+#define PDEOPT_FFT_RADIX16 1
+#endif
 template <int N>
 struct FftPlan {
   static constexpr int log2n() { int l = 0, n = N; while (n > 1) { n >>= 1; ++l; } return l; }
-  static constexpr int n8 = log2n() / 3;
-  static constexpr int tail = 1 << (log2n() % 3);          // 1, 2 or 4
-  static constexpr int stages = n8 + (tail > 1 ? 1 : 0);
-  static constexpr int radix(int i) { return i < n8 ? 8 : tail; }
+  static constexpr bool lead16 = PDEOPT_FFT_RADIX16 && N == 1024;
+  static constexpr int n8 = lead16 ? (log2n() - 4) / 3 : log2n() / 3;
+  static constexpr int tail = lead16 ? 1 : 1 << (log2n() % 3);  // 1, 2 or 4
+  static constexpr int stages = lead16 ? n8 + 1 : n8 + (tail > 1 ? 1 : 0);
+  static constexpr int radix(int i) { return lead16 ? (i == 0 ? 16 : 8) : (i < n8 ? 8 : tail); }
   // sub-length entering stage i (stage 0 sees N)
   static constexpr int sublen(int i) { int ns = N; for (int k = 0; k < i; ++k) ns /= radix(k); return ns; }
 };

@@ -46,6 +46,7 @@ struct RegFft {
   static constexpr int L = P::stages;
   static constexpr bool kWaveLocal = TT <= 64;
   static_assert(PTS == 8 || PTS == 16, "8 or 16 points per thread");
+  static_assert(PTS % P::radix(0) == 0, "a thread owns whole butterflies");
 
   // position (in the in-place DIF geometry) of register slot `slot` of thread j at stage STAGE
   template <int STAGE>
@@ -89,7 +90,7 @@ struct RegFft {
 #pragma unroll
     for (int u = 0; u < PER; ++u) {
       C* b = v + u * R;
-      C w[R];
+      C w[R > 8 ? 9 : R];
       if constexpr (S > 1) {
         const int jj = (j + u * TT) % S;
         // powers of the base twiddle by multiplication: one table read instead of R - 1
@@ -104,15 +105,23 @@ struct RegFft {
           w[6] = cmul(w[3], w[3]);
           w[7] = cmul(w[4], w[3]);
         }
-        if constexpr (DIT) {
+        if constexpr (R > 8) w[8] = cmul(w[4], w[4]);
+      }
+      // radix 16: w^9 .. w^15 = w^8 w^(q-8) are formed where they are used, never held together
+      auto wq = [&](const int q) -> C {
+        if constexpr (R > 8)
+          return q <= 8 ? w[q] : cmul(w[8], w[q > 8 ? q - 8 : 0]);
+        else
+          return w[q];
+      };
+      if constexpr (S > 1 && DIT) {
 #pragma unroll
-          for (int q = 1; q < R; ++q) b[q] = cmul(b[q], w[q]);
-        }
+        for (int q = 1; q < R; ++q) b[q] = cmul(b[q], wq(q));
       }
       dft_small<T, R, SIGN>(b);
       if constexpr (S > 1 && !DIT) {
 #pragma unroll
-        for (int q = 1; q < R; ++q) b[q] = cmul(b[q], w[q]);
+        for (int q = 1; q < R; ++q) b[q] = cmul(b[q], wq(q));
       }
       // one butterfly at a time: interleaving the independent butterflies of a 16-point thread only
       // raises the register pressure (spills at 1024-thread workgroups otherwise)

@@ -150,7 +150,10 @@ __global__ __launch_bounds__(256) void strang_row_reg_kernel(Cx<T>* __restrict__
 #ifndef PDEOPT_COL_WL
 #define PDEOPT_COL_WL 1
 #endif
-constexpr bool col_wave_local(int n) { return PDEOPT_COL_WL && n <= 512; }
+#ifndef PDEOPT_COL_WL_MAX
+#define PDEOPT_COL_WL_MAX 512
+#endif
+constexpr bool col_wave_local(int n) { return PDEOPT_COL_WL && n <= PDEOPT_COL_WL_MAX; }
 template <typename T, int N, int C, int PTS, bool SCALED>
 __global__ __launch_bounds__(C* N / PTS) void strang_col_reg_kernel(Cx<T>* __restrict__ psi,
                                                                   const Cx<T>* __restrict__ mult,
