@@ -32,6 +32,9 @@ struct QuadArgs {
   ClosureSpec mu, mob;
 };
 
+#ifndef PDEOPT_AC4_FOLD
+#define PDEOPT_AC4_FOLD 1
+#endif
 #ifndef PDEOPT_AC4_THREADS
 #define PDEOPT_AC4_THREADS 512
 #endif
@@ -101,6 +104,22 @@ __global__ __launch_bounds__(Ac4Geom::NT) void ac_rk4_quad_kernel(const QuadArgs
   }
   __syncthreads();
 
+  // Constant mobility (CL_POLY_M0): k = -R (mu_h(u) - kappa lap u) is ONE cubic in u plus two weighted
+  // neighbour sums,  k = q(u) + A (u_x+ + u_x-) + B (u_y+ + u_y-),  A = R kappa / hx^2, B = R kappa / hy^2,
+  // q = -R mu_h - 2 (A + B) u  with the coefficients folded per environment: 7 instructions per cell
+  // instead of 11 in this VALU-bound kernel.  Algebraically the same expression, re-associated: the
+  // rounding differs from the literal form at the ulp level of the state per substep.
+  constexpr bool FOLD = PDEOPT_AC4_FOLD && CL == CL_POLY_M0;
+  T fA = T(0), fB = T(0), q0 = T(0), q1 = T(0), q2 = T(0), q3 = T(0);
+  if constexpr (FOLD) {
+    const T R = p.mob[0];
+    fA = R * kap * a.rhx2;
+    fB = R * kap * a.rhy2;
+    q0 = -R * p.mu[0];
+    q1 = -R * p.mu[1] - T(2) * (fA + fB);
+    q2 = -R * p.mu[2];
+    q3 = -R * p.mu[3];
+  }
   // k at one vector (tile row r, LDS vector column cv) of the field held in `src`
   auto k_at = [&](const T* src, const int r, const int cv) -> Vec {
     const T* up = src + (r + 4) * P + cv * V;
@@ -113,6 +132,11 @@ __global__ __launch_bounds__(Ac4Geom::NT) void ac_rk4_quad_kernel(const QuadArgs
     for (int e = 0; e < V; ++e) {
       const T ym = (e == 0) ? left : c[e - 1];
       const T yp = (e == V - 1) ? right : c[e + 1];
+      if constexpr (FOLD) {
+        const T q = ((q3 * c[e] + q2) * c[e] + q1) * c[e] + q0;
+        k[e] = fA * (xp[e] + xm[e]) + (fB * (yp + ym) + q);
+        continue;
+      }
       const T mu = eval_mu<T, CL>(a.mu, p.mu, c[e]) - kap * lap_at<T>(c[e], xp[e], xm[e], yp, ym, a.rhx2, a.rhy2);
       k[e] = -eval_mob<T, CL>(a.mob, p.mob, c[e]) * mu;
     }
