@@ -50,8 +50,9 @@ __device__ __forceinline__ double t_logit<double>(double c) {
 //   CL_POLY    : mu = cubic polynomial, mobility = quadratic polynomial, fully unrolled
 //   CL_LOGIT   : as CL_POLY with the log(c/(1-c)) prior added to mu (regular-solution model)
 //   CL_LOGIT1  : CL_LOGIT whose polynomial part is linear (the regular-solution model 3 (1 - 2c) of the
-//                headline workload): two FMAs less per evaluation in the VALU-bound fused CH kernel; bitwise
-//                equal to CL_LOGIT there, because coefficients past n are stored as zeros
+//                headline workload): two FMAs less per evaluation in the VALU-bound fused CH kernel
+//                (coefficients past n are stored as zeros), and the fused fp32/fp64 pair kernel folds
+//                -kappa lap into the same expression (stencil_fused.hpp, FOLD_MU)
 //   CL_POLY_M0 : CL_POLY with a constant mobility (Allen-Cahn's R = 1, BASELINE config 2): two FMAs less
 //                per evaluation in the VALU-bound single-pass RK4 kernel, bitwise equal on finite states
 enum { CL_GENERIC = 0, CL_POLY = 1, CL_LOGIT = 2, CL_LOGIT1 = 3, CL_POLY_M0 = 4 };

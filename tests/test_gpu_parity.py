@@ -643,9 +643,11 @@ def test_pipelined_pair_equals_classic(dtype, shape, batch, closures):
         assert np.mean(outs[mode] != outs[1]) < 0.5
 
 
-def test_linear_logit_class_is_bitwise_the_cubic_one():
+def test_linear_logit_class_matches_the_cubic_one():
     """CL_LOGIT1 (csrc/closures.hpp): the regular-solution closure written with 2 coefficients runs the
-    shorter in-kernel form, with 4 coefficients (two of them zero) the cubic one -- same bits."""
+    shorter in-kernel form (linear polynomial part, kappa and 1/h^2 folded into the Laplacian weights: the
+    same expression re-associated), with 4 coefficients (two of them zero) the literal cubic one.  Equal to a
+    few ulp of the fp32 state after 8 substeps."""
     from pde_opt_amd.numerics.closures import LOGIT_PRIOR, POLY, ClosureDesc
 
     rng = np.random.default_rng(23)
@@ -657,7 +659,9 @@ def test_linear_logit_class_is_bitwise_the_cubic_one():
         sol = P.diffeqsolve(eq, P.RK4(), 0.0, 8 * 2e-7, 2e-7, y0)
         assert "pair" in sol.stats["kernel"]
         outs.append(sol.ys[-1])
-    np.testing.assert_array_equal(outs[0], outs[1])
+    eps = np.finfo(np.float32).eps
+    np.testing.assert_allclose(outs[0], outs[1], rtol=0, atol=8 * eps)
+    # the traced callable closure is recognised as the same 2-coefficient description: same kernel, same bits
     ref = P.diffeqsolve(P.CahnHilliard2DPeriodic(dom, 0.002, MU["regsol"], MOB["c1mc"]), P.RK4(), 0.0, 8 * 2e-7, 2e-7, y0).ys[-1]
     np.testing.assert_array_equal(outs[0], ref)
 
