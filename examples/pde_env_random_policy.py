@@ -1,7 +1,10 @@
 """notebooks/test_pde_env.ipynb: one episode of a Cahn-Hilliard control environment under a random
 policy (kappa is the control), first as a single PDEEnv, then 16 of them as one VectorPDEEnv whose
 rewards are reduced on the GPU."""
+import os
 import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))  # run from a checkout
 import time
 
 import numpy as np

@@ -1,5 +1,8 @@
 """notebooks/run_cahn_hilliard.ipynb on the MI355X: spinodal decomposition with the IMEX solver."""
+import os
 import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))  # run from a checkout
 import time
 
 import numpy as np

@@ -2,7 +2,10 @@
 adaptive Tsit5 + PID, then a time-dependent contact angle theta(t).  psi is built directly as a tanh
 profile (upstream relaxes a binary mask with `Shape`; any object with a `.smooth` array serves as
 `domain.geometry`)."""
+import os
 import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))  # run from a checkout
 import types
 
 import numpy as np

@@ -1,6 +1,9 @@
 """notebooks/test_thomas_fermi.ipynb: imaginary-time Strang splitting relaxes a Gaussian to the
 Thomas-Fermi profile of the trapped condensate."""
+import os
 import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))  # run from a checkout
 
 import numpy as np
 
