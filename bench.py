@@ -287,7 +287,7 @@ def main():
                 "note": "achieved = SURVEY 8(d) algorithmic bytes / HIP-event time; stage-pair fusion and "
                         "Infinity-Cache-resident environment groups remove HBM traffic, so frac may exceed 1. "
                         "After fusion the RK4 pair kernel is VALU-issue-bound (SQ_ACTIVE_INST_VALU: 72-80 % of the "
-                        "launch per SIMD, profiles/r01_v10_pmc_busy.txt), not HBM-bound; `traffic` is what it really moves",
+                        "launch per SIMD, profiles/r01_v11_pmc_busy.txt), not HBM-bound; `traffic` is what it really moves",
             },
         }
         if args.gpus == 1 and not args.no_cpu_baseline:
