@@ -11,7 +11,7 @@ Every rank owns an (nx/px) x (ny/py) tile stored with a 4-cell halo.  Per RK4 su
         backend.phase(phase, dt)                               # fused stencil + RK update kernel
 
 The exchange is ONE all-gather of packed strips per phase (edges and corners together), the pattern
-BASELINE.json names; strips are 2*h*(nx+ny)+4*h^2 elements (64 KiB at 2048^2 fp32), far below the
+BASELINE.json names; strips are 2*h*(nx+ny)+4*h^2 elements (128 KiB at 2048^2 fp32), far below the
 per-link xGMI bandwidth, so the collective is latency-bound: fewer, fatter exchanges (halo 4 for a
 fused stage pair) is the lever, not bandwidth.  IMEX / Strang would need a distributed FFT
 (all-to-all transposes): replicas only for the spectral integrators.
