@@ -173,7 +173,19 @@ def main():
         import torch.distributed as dist
 
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # RCCL printf()s its version banner to stdout when the communicator is created (NCCL_DEBUG=VERSION
+        # on the GPU boxes): create it with fd 1 pointed at stderr so stdout carries the one JSON line only
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.barrier()
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_stdout, 1)
+            os.close(saved_stdout)
 
     import pde_opt_amd as P
     from pde_opt_amd import _lib as L
