@@ -108,7 +108,9 @@ __global__ __launch_bounds__(256) void strang_row_reg_kernel(Cx<T>* __restrict__
     if constexpr (MODE == ROW_MID) {
       const T kk = ep[env].gpe_k;
       const T* vrow = pot ? pot + (int64_t)env * pot_env_stride + (row - (int64_t)env * nx) * N : nullptr;
-      double acc = 0.0;
+      // |psi|^2 of the thread's points in the working precision (the reference sums in it too,
+      // solvers.py:111), the sums across threads / workgroups / the column pass in fp64
+      T accp = T(0);
 #pragma unroll
       for (int m = 0; m < PTS; ++m) {
         const int n = E::natural(j, m);
@@ -118,8 +120,9 @@ __global__ __launch_bounds__(256) void strang_row_reg_kernel(Cx<T>* __restrict__
         sincos_t<T>(w * tr, &sn, &cs);
         const T mag = (ti == T(0)) ? T(1) : exp_t<T>(w * ti);
         v[m] = cmul(v[m], Cx<T>{mag * cs, -mag * sn});
-        acc += (double)v[m].re * (double)v[m].re + (double)v[m].im * (double)v[m].im;
+        accp += v[m].re * v[m].re + v[m].im * v[m].im;
       }
+      double acc = (double)accp;
       __shared__ double red[4];
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
