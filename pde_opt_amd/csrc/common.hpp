@@ -164,6 +164,9 @@ int ensure_buffer(pdeopt_ctx* ctx, void** p, size_t bytes);
 
 // stencil.hip
 int launch_rhs(pdeopt_ctx* ctx, const void* in, void* out, double t);
+// the same slope for the IMEX step: the stage-B half of the fused pair kernel where it applies (CH, periodic
+// layout, polynomial / logit closures), launch_rhs otherwise; equal to launch_rhs up to rounding
+int launch_rhs_slope(pdeopt_ctx* ctx, const void* in, void* out, double t);
 int advance_explicit(pdeopt_ctx* ctx, int integrator, double t0, double dt, int64_t n);
 int tsit5_trial(pdeopt_ctx* ctx, double t, double dt, double rtol, double atol, double* err);
 int tsit5_commit(pdeopt_ctx* ctx, int accept);

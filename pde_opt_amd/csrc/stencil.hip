@@ -214,6 +214,20 @@ int launch_rhs(pdeopt_ctx* ctx, const void* in, void* out, double t) {
   return launch_stage(ctx, in, in, out, nullptr, 0.0, 0.0, OUT_K, ACC_NONE);
 }
 
+#ifndef PDEOPT_IMEX_SLOPE_PAIR
+#define PDEOPT_IMEX_SLOPE_PAIR 1
+#endif
+int launch_rhs_slope(pdeopt_ctx* ctx, const void* in, void* out, double t) {
+  ctx->cur_t = t;
+#if PDEOPT_IMEX_SLOPE_PAIR
+  if (ctx->prob.derivs == PDEOPT_DERIVS_FD && ctx->prob.nz <= 1 && !ctx->time_fn) {
+    if (ctx->prob.dtype == PDEOPT_F32 && slope_pair_supported<float>(ctx)) return launch_slope_pair<float>(ctx, in, out);
+    if (ctx->prob.dtype == PDEOPT_F64 && slope_pair_supported<double>(ctx)) return launch_slope_pair<double>(ctx, in, out);
+  }
+#endif
+  return launch_rhs(ctx, in, out, t);
+}
+
 namespace {
 constexpr int kGraphUnit = 16;  // substeps per captured graph (even: ping-pong buffers return)
 

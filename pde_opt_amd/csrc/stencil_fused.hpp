@@ -44,7 +44,7 @@ __device__ __forceinline__ double uniform_f(double x) {
   return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
 
-enum { PAIR_12 = 0, PAIR_34 = 1 };
+enum { PAIR_12 = 0, PAIR_34 = 1, PAIR_K = 2 };  // PAIR_K: one stage, out = f(in) (the IMEX slope)
 
 // Phase-ablation hooks (TIMING ONLY, tools/ablate_pair.sh) are compiled in with -DPDEOPT_PAIR_ABLATE
 // (tools/mkvariant.sh): even as never-taken uniform branches they change hipcc's schedule of the
@@ -230,14 +230,15 @@ __global__ __launch_bounds__(NT) PDEOPT_PAIR_WAVES_ATTR void stage_pair_kernel(c
     }
   }
 
-  // ---- P1: stage-A input, tile + 4
-  constexpr int kLoadVecs = (TX + 8) * PV;
+  // ---- P1: stage-A input, tile + 4  (PAIR_K: the only stage's input, tile + 2 = LDS rows 2 .. TX+5)
+  constexpr int kRow0 = PAIR == PAIR_K ? 2 : 0;
+  constexpr int kLoadVecs = (TX + 8 - 2 * kRow0) * PV;
 #pragma unroll
   for (int it = 0; it < (kLoadVecs + NT - 1) / NT; ++it) {
     const int idx = tid + it * NT;
     if (idx < kLoadVecs) {
-      const int row = idx / PV;
-      const int cv = idx - row * PV;
+      const int row = idx / PV + kRow0;
+      const int cv = idx - (row - kRow0) * PV;
       const int gi = wrap_row(i0 - 4 + row);
       const int gj = wrap_col(j0 - HV * V + cv * V);
       if (PDEOPT_ABL(a, 8)) {
@@ -393,6 +394,8 @@ __global__ __launch_bounds__(NT) PDEOPT_PAIR_WAVES_ATTR void stage_pair_kernel(c
     }
   };
 
+  Vec yown[RPT];  // PAIR_12: y on the own cells (stage A's centre values), used again by the stores
+  if constexpr (PAIR != PAIR_K) {
   // ---- P2: mu_A on tile + 3 (mu rows 0 .. TX+5)
   mu_pass(0, TX + 6);
   __syncthreads();
@@ -400,7 +403,7 @@ __global__ __launch_bounds__(NT) PDEOPT_PAIR_WAVES_ATTR void stage_pair_kernel(c
   // ---- P3: k_A on one ring vector, then on the own micro-tile.  The ring goes FIRST: its non-marching
   // flux_divergence needs ~60 transient registers, and after the march w_own / yown / accp are live --
   // in the other order this phase is the VGPR peak of the kernel (v95 / v115).
-  Vec w_own[RPT], yown[RPT], w_ring;
+  Vec w_own[RPT], w_ring;
   if (has_ring) {
     Vec uc;
     Vec kA;
@@ -441,6 +444,8 @@ __global__ __launch_bounds__(NT) PDEOPT_PAIR_WAVES_ATTR void stage_pair_kernel(c
   if (has_ring) *reinterpret_cast<Vec*>(sU + (ring_r + 4) * P + ring_cv * V) = w_ring;
   __syncthreads();
 
+  }  // PAIR != PAIR_K
+
   // ---- P5: mu_B on tile + 1 (mu rows 2 .. TX+3)
   mu_pass(2, TX + 2);
   __syncthreads();
@@ -458,7 +463,9 @@ __global__ __launch_bounds__(NT) PDEOPT_PAIR_WAVES_ATTR void stage_pair_kernel(c
     if (!cell_ok(r)) continue;
     if (PDEOPT_ABL(a, 16) && kB[r][0] != T(12345.678)) continue;
     const int64_t idx = pidx0 + r * ld;
-    if constexpr (PAIR == PAIR_12) {
+    if constexpr (PAIR == PAIR_K) {
+      *reinterpret_cast<Vec*>(a.out + idx) = kB[r];
+    } else if constexpr (PAIR == PAIR_12) {
       *reinterpret_cast<Vec*>(a.out + idx) = yown[r] + a.aB * kB[r];
       *reinterpret_cast<Vec*>(a.acc_out + idx) = accp[r] + a.bB * kB[r];
     } else {

@@ -71,4 +71,37 @@ int launch_pair(pdeopt_ctx* ctx, int pair, const void* in, const void* y, const 
 #undef PDEOPT_PAIR_DISPATCH
 }
 
+// out = f(in) for every environment of the window through the stage-B half of the fused kernel
+// (PAIR_K): the slope launch of the IMEX step.  Same arithmetic as launch_pair's stages (including the
+// folded mu form of the linear-logit class), so it may differ from the per-stage kernels' k by rounding;
+// pdeopt_rhs and the explicit integrators do not come here.
+template <typename T>
+bool slope_pair_supported(const pdeopt_ctx* ctx) {
+  return ctx->prob.equation == PDEOPT_EQ_CAHN_HILLIARD && !ctx->halo && ctx->opt_fuse_stages >= 0 &&
+         ctx->opt_kernel_path != 1 && fused_supported<T>(ctx);
+}
+template <typename T>
+int launch_slope_pair(pdeopt_ctx* ctx, const void* in, void* out) {
+  const pdeopt_problem& p = ctx->prob;
+  PairArgs<T> s{};
+  s.g = make_geo(ctx);
+  const int64_t woff = (int64_t)ctx->win_lo * s.g.bstride;
+  s.in = static_cast<const T*>(in) + woff;
+  s.out = static_cast<T*>(out) + woff;
+  s.rhx = T(0.5 / (p.hx * p.hx)); s.rhy = T(0.5 / (p.hy * p.hy));
+  s.rhx2 = T(1.0 / (p.hx * p.hx)); s.rhy2 = T(1.0 / (p.hy * p.hy));
+  s.ep = static_cast<const EnvParams<T>*>(ctx->env_params_dev) + ctx->win_lo;
+  s.mu = ClosureSpec{p.mu.kind, p.mu.flags, p.mu.n};
+  s.mob = ClosureSpec{p.mob.kind, p.mob.flags, p.mob.n};
+  ctx->n_stage_launches++;
+  const int cl = classify_closures(p.mu, p.mob);
+  const bool rows32 = ctx->opt_tile_rows == 32 || (ctx->opt_tile_rows == 0 && p.nx % 32 == 0);
+  ctx->last_kernel = rows32 ? "slope_pair<CH,rows32>" : "slope_pair<CH,rows16>";
+#define PDEOPT_SLOPE(CLV) \
+  (rows32 ? launch_pair_ch_inst<T, CLV, PAIR_K, 4>(ctx, s) : launch_pair_ch_inst<T, CLV, PAIR_K, 2>(ctx, s))
+  if (cl == CL_LOGIT) return p.mu.n <= 2 ? PDEOPT_SLOPE(CL_LOGIT1) : PDEOPT_SLOPE(CL_LOGIT);
+  return PDEOPT_SLOPE(CL_POLY);
+#undef PDEOPT_SLOPE
+}
+
 }  // namespace pdeopt

@@ -582,7 +582,7 @@ int imex_fused_t(pdeopt_ctx* ctx, double dt, int64_t n) {
     ctx->win_lo = lo;
     ctx->win_n = std::min(group, p.batch - lo);
     for (int64_t s = 0; s < n && !rc; ++s) {
-      if ((rc = launch_rhs(ctx, ctx->Y, ctx->TA, 0.0))) break;
+      if ((rc = launch_rhs_slope(ctx, ctx->Y, ctx->TA, 0.0))) break;
       switch (p.ny) {
 #define X(NN) case NN: rc = imex_rows<T, NN>(ctx, sf, true, dt); break;
         PDEOPT_FFT_SIZES(X)
