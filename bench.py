@@ -68,9 +68,12 @@ def make_problem(P, name, batch, rank):
         dom = P.Domain((n, n), ((-12.0, 12.0), (-12.0, 12.0)), "dimensionless")
         eq = P.GPE2DTSControl(dom, 1000.0, 0.0, lambda t, x, y: 0.0, trap_factor=1.0, kinetic=True)
         X, Y = dom.mesh()
-        psi = np.exp(-(X**2 + Y**2) / (2 * 4.0**2)).astype(complex)
-        psi /= np.sqrt(np.sum(np.abs(psi) ** 2) * dom.dx[0] ** 2)
-        y0 = np.repeat(np.stack([psi.real, psi.imag], axis=-1)[None].astype(dtype), batch, axis=0)
+        y0 = np.empty((batch, n, n, 2), dtype=dtype)
+        for b in range(batch):  # normalised Gaussians, width L/6, a little different per environment
+            wdt = 4.0 * (1.0 + 0.002 * (rank * batch + b))
+            psi = np.exp(-(X**2 + Y**2) / (2 * wdt**2))
+            psi /= np.sqrt(np.sum(psi**2) * dom.dx[0] ** 2)
+            y0[b, ..., 0], y0[b, ..., 1] = psi, 0.0
         solver = P.StrangSplitting(eq.A_term, eq.dx, eq.fft, eq.ifft, 1.0)
         return eq, y0, solver
     L_ = 0.01 * n
@@ -92,11 +95,83 @@ def make_problem(P, name, batch, rank):
     return eq, y0, solver
 
 
+def usable_cores():
+    """host cores this process may use: the affinity mask, clipped by the cgroup CPU quota (a GPU box hands
+    one GPU's job a share of the host, not all of os.cpu_count())"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
+def _oracle_closures(w):
+    from oracle import c_oracle as CO
+
+    if w["eq"] == "ch" and w.get("closures") == "cubic":
+        return 0, CO.closure(0, 0, (0.0, -1.0, 0.0, 1.0)), CO.closure(0, 0, (1.0, 0.0, 1.0))
+    if w["eq"] == "ch":
+        return 0, CO.closure(0, 1, (3.0, -6.0)), CO.closure(0, 0, (0.0, 1.0, -1.0))
+    return 1, CO.closure(0, 0, (0.0, -1.0, 0.0, 1.0)), CO.closure(0, 0, (1.0,))
+
+
+def parity_spot(name, eng, eq, solver, y0, threads):
+    """Post-timing parity spot check (the bench line proves its own result): the SAME library call the timed
+    region makes -- pdeopt_advance on the whole batch, environment groups and all -- on the fresh inputs,
+    first / last environment of the batch and the two environments either side of the middle (group edges)
+    against the CPU oracle: oracle/c_oracle.c for RK4 (one full environment step), oracle/np_oracle.py for
+    the spectral integrators (8 substeps; it is a numpy port).  Returns the worst relative L2 error of the
+    state increment (of the state for the GPE, whose norm is fixed) and the worst absolute state error."""
+    from oracle import c_oracle as CO
+    from oracle import np_oracle as O
+
+    w = WORKLOADS[name]
+    dt, batch = w["dt"], y0.shape[0]
+    nsub = w["substeps"] if w["integ"] == "rk4" else 8
+    eng.set_state(y0)
+    eng.advance(solver.integrator, dt, nsub, 0.0)
+    envs = sorted({0, batch // 2 - 1, batch // 2, batch - 1} & set(range(batch)))
+    hx, hy = eq.domain.dx
+    worst_rel = worst_abs = 0.0
+    for b in envs:
+        got = eng.get_state(b, 1)[0].astype(np.float64)
+        if w["integ"] == "rk4":
+            code, cmu, cmob = _oracle_closures(w)
+            ref = CO.rk4(code, y0[b], hx, hy, 0.002, cmu, cmob, dt, nsub, threads=threads).astype(np.float64)
+        elif w["integ"] == "imex":
+            sym = O.ch_fourier_symbol(w["n"], w["n"], hx, hy, 0.002)
+            rhs = lambda t, u: O.ch_rhs_fd(u, hx, hy, 0.002, REGSOL, C1MC)
+            ref = y0[b].astype(np.float64)
+            for i in range(nsub):
+                ref = O.imex_step(rhs, i * dt, ref, dt, 0.5, sym)
+        else:
+            X, Y = eq.domain.mesh()
+            bt = lambda t, yy: O.gpe_b_terms(yy, X, Y, 1000.0, 0.0, 1.0, 0.0)
+            ref = y0[b].astype(np.float64)
+            for i in range(nsub):
+                ref = O.strang_step(bt, i * dt, ref, dt, eq.A_term, eq.dx, 1.0)
+        base = 0.0 if w["eq"] == "gpe" else y0[b].astype(np.float64)
+        den = np.linalg.norm(ref - base)
+        worst_rel = max(worst_rel, float(np.linalg.norm((got - base) - (ref - base)) / (den if den > 0 else 1.0)))
+        worst_abs = max(worst_abs, float(np.max(np.abs(got - ref))))
+    f64 = y0.dtype == np.float64
+    tol = {"rk4": 1e-9 if f64 else 2e-3, "imex": 1e-8 if f64 else 2e-3, "strang": 1e-10 if f64 else 1e-4}[w["integ"]]
+    return {"parity_spot_rel_err": worst_rel, "parity_spot_max_abs_err": worst_abs, "parity_spot_tol": tol,
+            "parity_spot_ok": bool(worst_rel < tol),
+            "parity_spot": f"{nsub} substeps of the timed call on fresh inputs, environments {envs} of {batch} "
+                           f"(groups: {eng.last_groups()}) vs "
+                           + ("oracle/c_oracle.c" if w["integ"] == "rk4" else "oracle/np_oracle.py")}
+
+
 def cpu_baseline(name, budget_s=15.0):
     """The oracle timed on the host cores, on a bounded sample of the same workload (one
     environment, as many RK4 substeps as fit the budget):
-      * value: the C restatement (oracle/c_oracle.c, fused loops, OpenMP) on min(16, cores) threads
-        -- the stronger CPU baseline, so the GPU ratio is not inflated by a slow one;
+      * value: the C restatement (oracle/c_oracle.c, fused loops, OpenMP) on every core this job may use
+        (usable_cores(): affinity mask clipped by the cgroup quota -- a 1-GPU box grants a 16-core share of a
+        256-thread host) -- the stronger CPU baseline, so the GPU ratio is not inflated by a slow one;
       * the numpy roll-form port (oracle/np_oracle.py, what the reference's arithmetic costs when
         executed op for op, single thread) is quoted in `sample`.
     Neither is JAX-on-CPU: JAX is not installable here (no network); see BASELINE.md section 3."""
@@ -125,7 +200,7 @@ def cpu_baseline(name, budget_s=15.0):
         yy = O.rk4_step(f, 0.0, yy, dtc)
         n_np += 1
     el_np = time.perf_counter() - t0
-    threads = max(1, min(16, os.cpu_count() or 1))
+    threads = usable_cores()
     CO.rk4(eq, y, hx, hy, 0.002, cmu, cmob, dt, 2, threads=threads)  # warm-up
     chunk, n_c, yy = 8, 0, y
     t0 = time.perf_counter()
@@ -141,7 +216,8 @@ def cpu_baseline(name, budget_s=15.0):
         "sample": f"1 env of {name}: C/OpenMP oracle (oracle/c_oracle.c) {n_c} RK4 substeps in {el_c:.1f} s on "
                   f"{threads} threads = {n_c / el_c:.1f} substeps/s; numpy roll-form oracle "
                   f"(oracle/np_oracle.py) {n_np} substeps in {el_np:.1f} s on 1 thread = "
-                  f"{n_np / el_np:.1f} substeps/s; host reports {os.cpu_count()} cores",
+                  f"{n_np / el_np:.1f} substeps/s; host reports {os.cpu_count()} logical CPUs, {threads} usable by this job "
+                  f"(affinity + cgroup quota)",
     }
 
 
@@ -158,6 +234,7 @@ def main():
     ap.add_argument("--fuse", type=int, default=0, help="RK4 stage-pair fusion: 0 auto, -1 off")
     ap.add_argument("--ablate", type=int, default=0, help="TIMING ONLY (wrong results): kernel phase ablation bits")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity-spot", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
 
@@ -240,6 +317,9 @@ def main():
 
     # sanity: the timed state is finite (a diverged run would be measuring NaN arithmetic)
     bad = float(eng.reduce(L.RED_NONFINITE).sum())
+    spot = None
+    if rank == 0 and not args.no_parity_spot and not args.ablate:
+        spot = parity_spot(args.workload, eng, eq, solver, y0, usable_cores())
 
     if rank == 0:
         nx, ny = eq.domain.points
@@ -284,6 +364,7 @@ def main():
             "substeps_per_s": args.gpus * batch * args.steps * substeps / elapsed,
             "achieved_gbs_whole_job": args.gpus * total_bytes / elapsed / 1e9,
             "nonfinite_cells": bad,
+            **(spot or {}),
             "roofline": {
                 "bound": "hbm",
                 "kernel": kernel_name + " (average over the launches of a substep)",
@@ -307,10 +388,13 @@ def main():
             if cb is not None:
                 line["cpu_baseline"] = cb
         print(json.dumps(line))
+        sys.stdout.flush()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
     eng.close()
+    if spot is not None and not spot["parity_spot_ok"]:
+        raise SystemExit(f"parity spot check FAILED: {spot}")
 
 
 if __name__ == "__main__":

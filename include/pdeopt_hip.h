@@ -159,8 +159,9 @@ typedef enum {
   PDEOPT_OPT_HALO_LAYOUT = 5, /* layout of the NEXT pdeopt_configure: 0 = periodic field (wrap by index),
                                  4 = rank-local tile padded by a 4-cell halo on every side, no wrap
                                  (domain decomposition; halos filled by pdeopt_halo_unpack) */
-  PDEOPT_OPT_FUSE_STAGES = 4, /* RK4: temporally fused stage pairs (1+2, 3+4): 0 = auto (on where a
-                                 fused kernel exists), -1 = off (one launch per stage) */
+  PDEOPT_OPT_FUSE_STAGES = 4, /* RK4: temporally fused stages: 0 = auto (stage pairs 1+2 / 3+4 where a fused
+                                 kernel exists; fp32 Allen-Cahn: the whole substep in one pass), 1 = stage
+                                 pairs only, -1 = off (one launch per stage) */
   PDEOPT_OPT_DEBUG_ABLATE = 3 /* TIMING ONLY, results are wrong: bit0 skip the mu phase, bit1 skip
                                  the flux phase of the tiled kernel (where does the time go?) */
 } pdeopt_option;
@@ -180,9 +181,24 @@ int pdeopt_configure(pdeopt_ctx* ctx, const pdeopt_problem* problem);
  * [env_count][PDEOPT_CLOSURE_MAX_COEF]. */
 int pdeopt_set_env_params(pdeopt_ctx* ctx, int env_first, int env_count, const double* kappa,
                           const double* mu_coef, const double* mob_coef);
+/* per-environment GPE interaction strength k (gross_pitaevskii.py:38-39): with a batch every
+ * environment carries its own control value (BASELINE config 4 is an RL environment whose agent may act on k) */
+int pdeopt_set_env_gpe_k(pdeopt_ctx* ctx, int env_first, int env_count, const double* k);
 /* shared (per_env = 0: [nx][ny]) or per-environment (per_env = 1: [batch][nx][ny]) auxiliary
- * field, host pointer, element type = problem dtype (complex = 2 elements). */
+ * field, host pointer, element type = problem dtype (complex = 2 elements).  Replaces a time-dependent
+ * source registered with pdeopt_set_aux_time_fn for the same field. */
 int pdeopt_set_aux(pdeopt_ctx* ctx, int which, const void* host, int per_env);
+/* Time-dependent auxiliary field.  The reference evaluates its callables at the time of every right-hand
+ * side:  Strang  b = terms.vf(t0, y0, args) with control(t) = lights(t, X, Y) at each substep's t0
+ * (numerics/solvers.py:109, gross_pitaevskii.py:61,67-75); explicit integrators at every stage time.
+ * fn(t, which, host_out, user) fills host_out ([nx][ny], or [batch][nx][ny] with per_env = 1, problem
+ * dtype) with the field at local time t and returns 0 (non-zero aborts the call with PDEOPT_EINVAL).
+ * It is called on the calling thread from inside pdeopt_advance / pdeopt_rhs / pdeopt_tsit5_trial, once
+ * per distinct evaluation time, for GPE_POTENTIAL (once per Strang substep) and VX_FACE / VY_FACE (once
+ * per stage); the substep loop then runs the whole batch in one group and without hipGraph replay.
+ * fn = NULL removes the source (the field keeps its last contents). */
+typedef int (*pdeopt_aux_fn)(double t, int which, void* host_out, void* user);
+int pdeopt_set_aux_time_fn(pdeopt_ctx* ctx, int which, pdeopt_aux_fn fn, void* user, int per_env);
 
 /* ---- state  == PDEEnv._state (pde_env.py:232,305) ---------------------------------------- */
 int pdeopt_set_state(pdeopt_ctx* ctx, int env_first, int env_count, const void* host);
@@ -259,7 +275,10 @@ int pdeopt_tsit5_commit(pdeopt_ctx* ctx, int accept);
 int pdeopt_sync(pdeopt_ctx* ctx);
 int pdeopt_timer_start(pdeopt_ctx* ctx);           /* hipEventRecord on the ctx stream */
 int pdeopt_timer_stop(pdeopt_ctx* ctx, double* ms); /* record + synchronise + elapsed */
-typedef enum { PDEOPT_CNT_STAGE_LAUNCHES = 0 /* fused stencil+update kernel launches so far */ } pdeopt_counter;
+typedef enum {
+  PDEOPT_CNT_STAGE_LAUNCHES = 0, /* fused stencil+update kernel launches so far */
+  PDEOPT_CNT_LAST_GROUPS = 1     /* environment groups the last pdeopt_advance ran the batch in (1 = one sweep) */
+} pdeopt_counter;
 int pdeopt_get_counter(pdeopt_ctx* ctx, int which, int64_t* value);
 /* name of the kernel variant the last advance/rhs dispatched (for tests and profiles) */
 const char* pdeopt_last_kernel(const pdeopt_ctx* ctx);

@@ -385,9 +385,59 @@ def main():
                 c3[f"{tag}/symbol"] = np.asarray(eq.fourier_symbol)
     np.savez_compressed(os.path.join(OUT, "ch3d_cases.npz"), **c3)
 
+    round2(ref)
     print("wrote goldens to", os.path.abspath(OUT))
     for f in sorted(os.listdir(OUT)):
         print("  ", f, os.path.getsize(os.path.join(OUT, f)))
+
+
+# lights(t, x, y) of the round-2 goldens: a Gaussian spot that moves and brightens during the solve (the
+# shape of an RL stirring control); tests/util.py carries the same expression
+MOVING_SPOT = lambda t, x, y: 30.0 * (1.0 + 100.0 * t) * np.exp(-((x + 2.0 - 800.0 * t) ** 2 + (y - 1.0) ** 2) / 4.5)  # noqa: E731
+
+
+def round2(ref):
+    """Fixtures added in round 2.  Own files and an own generator state, so every round-1 file above
+    keeps reproducing bit for bit."""
+    Domain = ref.domains.Domain
+    rng = np.random.default_rng(20251004)
+
+    # ---- Strang with a TIME-DEPENDENT control: the reference evaluates lights(t0, X, Y) in every step
+    # (solvers.py:109 -> gross_pitaevskii.py:61,67-75).  48^2 takes the rocFFT pipeline, 64^2 the fused one.
+    traj = {}
+    for n in (48, 64):
+        dom = Domain((n, n), ((-12.0, 12.0), (-12.0, 12.0)), "dimensionless")
+        geq = ref.gpe.GPE2DTSControl(dom, 800.0, -0.15, MOVING_SPOT, trap_factor=0.9)
+        Xm, Ym = dom.mesh()
+        psi0 = np.exp(-(Xm**2 + Ym**2) / (2 * 3.5**2)) * np.exp(-0.2j * Ym)
+        psi0 = psi0 / np.sqrt(np.sum(np.abs(psi0) ** 2) * dom.dx[0] ** 2)
+        y0 = np.stack([psi0.real, psi0.imag], axis=-1)
+        traj[f"strang_tdep/{n}/y0"] = y0
+        a_real = 0.5j * geq.two_pi_i_k_2
+        for name, tscale in (("real", 1.0), ("imag", -1j)):
+            solver = _make(ref.solvers.StrangSplitting, A_term=a_real, dx=geq.dx, fft=geq.fft, ifft=geq.ifft,
+                           time_scale=tscale)
+            terms = _Terms(lambda t, yy: geq.B_terms(yy, t))
+            y, seq, dt = y0, [], 1e-3
+            for i in range(6):
+                y = solver.step(terms, i * dt, (i + 1) * dt, y, None, None, False)[0]
+                seq.append(np.asarray(y))
+            traj[f"strang_tdep/{n}/{name}/ys"] = np.stack(seq)
+        traj[f"strang_tdep/{n}/b_terms_t0"] = np.asarray(geq.B_terms(y0, 0.0))
+        traj[f"strang_tdep/{n}/b_terms_t3"] = np.asarray(geq.B_terms(y0, 3e-3))
+    np.savez_compressed(os.path.join(OUT, "trajectories_r2.npz"), **traj)
+
+    # ---- CahnHilliard3DPeriodic.rhs_fourier (cahn_hilliard.py:167-175; 9 transforms), fp64 only (the
+    # spectral constants are f64 in numpy but f32 in JAX-without-x64, SURVEY section 8c)
+    c3 = {}
+    for (nx, ny, nz) in ((16, 12, 20), (32, 32, 32), (8, 24, 36)):
+        dom3 = Domain((nx, ny, nz), ((-0.005 * nx, 0.005 * nx), (-0.005 * ny, 0.005 * ny), (0.0, 0.012 * nz)), "dimensionless")
+        u = np.clip(0.5 + 0.2 * rng.standard_normal((nx, ny, nz)), 0.05, 0.95)
+        eq = ref.ch.CahnHilliard3DPeriodic(dom3, 0.002, MU["regsol"], MOB["c1mc"], derivs="fourier")
+        tag = f"{nx}x{ny}x{nz}_float64"
+        c3[f"{tag}/u"] = u
+        c3[f"{tag}/rhs"] = np.asarray(eq.rhs(u, 0.0))
+    np.savez_compressed(os.path.join(OUT, "ch3d_fourier.npz"), **c3)
 
 
 if __name__ == "__main__":

@@ -107,6 +107,21 @@ def ch3d_rhs_fd(u, hx, hy, hz, kappa, mu_h, D):
     return out
 
 
+def ch3d_rhs_fourier(u, hx, hy, hz, kappa, mu_h, D):
+    """Pseudo-spectral 3-D CH RHS (9 FFTs), cahn_hilliard.py:167-175; wave numbers as
+    domains.py:44-47,58-60 with ``indexing='ij'``."""
+    nx, ny, nz = u.shape
+    kx, ky, kz = np.meshgrid(np.fft.fftfreq(nx, hx), np.fft.fftfreq(ny, hy), np.fft.fftfreq(nz, hz), indexing="ij")
+    ik = [2j * np.pi * k for k in (kx, ky, kz)]
+    k2 = ik[0] ** 2 + ik[1] ** 2 + ik[2] ** 2
+    t_hat = np.fft.fftn(mu_h(u)) - kappa * k2 * np.fft.fftn(u)
+    Du = D(u)
+    acc = 0
+    for a in ik:
+        acc = acc + a * np.fft.fftn(Du * np.fft.ifftn(a * t_hat))
+    return np.fft.ifftn(acc).real
+
+
 def ac_rhs_fd(u, hx, hy, kappa, mu_h, R):
     """Allen-Cahn ``-R(u) mu``, allen_cahn.py:81-84."""
     return -R(u) * chem_potential(u, hx, hy, kappa, mu_h)

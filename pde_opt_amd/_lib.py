@@ -39,6 +39,7 @@ OPT_HALO_LAYOUT = 5
 OPT_GRAPH = 6
 OPT_IMEX_LDS_FFT = 7
 CNT_STAGE_LAUNCHES = 0
+CNT_LAST_GROUPS = 1
 COPY_H2D, COPY_D2H, COPY_D2D = 0, 1, 2
 FIELD_Y, FIELD_TA, FIELD_TB, FIELD_ACC = 0, 1, 2, 3
 PATH_AUTO, PATH_GENERIC, PATH_TILED = 0, 1, 2
@@ -89,6 +90,8 @@ class Problem(C.Structure):
 _VP = C.c_void_p
 # pdeopt_time_fn: void (*)(double t, double out[3], void* user)
 TIME_FN = C.CFUNCTYPE(None, C.c_double, C.POINTER(C.c_double), C.c_void_p)
+# pdeopt_aux_fn: int (*)(double t, int which, void* host_out, void* user)
+AUX_FN = C.CFUNCTYPE(C.c_int, C.c_double, C.c_int, C.c_void_p, C.c_void_p)
 _SIGNATURES = {
     "pdeopt_abi_version": (C.c_int, []),
     "pdeopt_device_count": (C.c_int, [C.POINTER(C.c_int)]),
@@ -99,6 +102,8 @@ _SIGNATURES = {
     "pdeopt_configure": (C.c_int, [_VP, C.POINTER(Problem)]),
     "pdeopt_set_env_params": (C.c_int, [_VP, C.c_int, C.c_int, _VP, _VP, _VP]),
     "pdeopt_set_aux": (C.c_int, [_VP, C.c_int, _VP, C.c_int]),
+    "pdeopt_set_aux_time_fn": (C.c_int, [_VP, C.c_int, AUX_FN, _VP, C.c_int]),
+    "pdeopt_set_env_gpe_k": (C.c_int, [_VP, C.c_int, C.c_int, _VP]),
     "pdeopt_set_state": (C.c_int, [_VP, C.c_int, C.c_int, _VP]),
     "pdeopt_get_state": (C.c_int, [_VP, C.c_int, C.c_int, _VP]),
     "pdeopt_state_device_ptr": (C.c_int, [_VP, C.POINTER(_VP), C.POINTER(C.c_int64)]),

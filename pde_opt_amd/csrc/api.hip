@@ -48,6 +48,7 @@ void free_fields(pdeopt_ctx* ctx) {
   }
   for (auto& a : ctx->aux) {
     if (a.dev) (void)hipFree(a.dev);
+    if (a.stage) (void)hipHostFree(a.stage);
     a = AuxField{};
   }
   spectral_destroy(ctx);
@@ -98,6 +99,12 @@ void patch_env_params(pdeopt_ctx* ctx, int first, int count, const double* kappa
   }
 }
 
+template <typename T>
+void patch_env_gpe_k(pdeopt_ctx* ctx, int first, int count, const double* k) {
+  auto* e = reinterpret_cast<EnvParams<T>*>(ctx->env_params_host.data());
+  for (int i = 0; i < count; ++i) e[first + i].gpe_k = T(k[i]);
+}
+
 int upload_env_params(pdeopt_ctx* ctx) {
   PDEOPT_HIP_CHECK(ctx, hipMemcpyAsync(ctx->env_params_dev, ctx->env_params_host.data(),
                                        ctx->env_params_host.size(), hipMemcpyHostToDevice,
@@ -115,7 +122,45 @@ int check_envs(pdeopt_ctx* ctx, int first, int count) {
   return PDEOPT_OK;
 }
 
+size_t aux_bytes(const pdeopt_ctx* ctx, int which, int per_env) {
+  const bool cplx = which == PDEOPT_AUX_IMEX_SYMBOL || which == PDEOPT_AUX_GPE_A_TERM;
+  return (size_t)ctx->prob.nx * ctx->prob.ny * (ctx->prob.nz > 1 ? ctx->prob.nz : 1) * (cplx ? 2 : 1) * ctx->esize *
+         (per_env ? (size_t)ctx->prob.batch : 1);
+}
+
+// (re)allocate the device buffer of an auxiliary field for the given sharing mode
+int aux_alloc(pdeopt_ctx* ctx, int which, int per_env) {
+  const size_t bytes = aux_bytes(ctx, which, per_env);
+  AuxField& a = ctx->aux[which];
+  if (a.dev && a.bytes != bytes) {
+    PDEOPT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    (void)hipFree(a.dev);
+    a.dev = nullptr;
+    if (a.stage) (void)hipHostFree(a.stage);
+    a.stage = nullptr;
+  }
+  int rc = ensure_buffer(ctx, &a.dev, bytes);
+  if (rc) return rc;
+  a.bytes = bytes;
+  a.per_env = per_env ? 1 : 0;
+  return PDEOPT_OK;
+}
+
 }  // namespace
+
+int refresh_time_aux(pdeopt_ctx* ctx, int which, double t) {
+  AuxField& a = ctx->aux[which];
+  if (!a.fn || (a.loaded && a.t_loaded == t)) return PDEOPT_OK;
+  // the staging buffer is reused: the previous upload must have left it
+  PDEOPT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  if (a.fn(t, which, a.stage, a.user) != 0)
+    return fail(ctx, PDEOPT_EINVAL, "time-dependent source of aux field %d failed at t = %g", which, t);
+  PDEOPT_HIP_CHECK(ctx, hipMemcpyAsync(a.dev, a.stage, a.bytes, hipMemcpyHostToDevice, ctx->stream));
+  a.t_loaded = t;
+  a.loaded = true;
+  return PDEOPT_OK;
+}
+
 }  // namespace pdeopt
 
 using namespace pdeopt;
@@ -310,23 +355,57 @@ int pdeopt_set_aux(pdeopt_ctx* ctx, int which, const void* host, int per_env) {
   if (!ctx->configured) return fail(ctx, PDEOPT_ESTATE, "pdeopt_configure has not been called");
   if (which < 0 || which >= kNumAux) return fail(ctx, PDEOPT_EINVAL, "unknown aux field %d", which);
   PDEOPT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-  const bool cplx = which == PDEOPT_AUX_IMEX_SYMBOL || which == PDEOPT_AUX_GPE_A_TERM;
-  const size_t bytes = (size_t)ctx->prob.nx * ctx->prob.ny * (ctx->prob.nz > 1 ? ctx->prob.nz : 1) *
-                       (cplx ? 2 : 1) * ctx->esize * (per_env ? (size_t)ctx->prob.batch : 1);
-  AuxField& a = ctx->aux[which];
-  if (a.dev && a.bytes != bytes) {
-    PDEOPT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-    (void)hipFree(a.dev);
-    a.dev = nullptr;
-  }
-  int rc = ensure_buffer(ctx, &a.dev, bytes);
+  int rc = aux_alloc(ctx, which, per_env);
   if (rc) return rc;
-  a.bytes = bytes;
-  a.per_env = per_env ? 1 : 0;
+  AuxField& a = ctx->aux[which];
+  const size_t bytes = a.bytes;
+  a.fn = nullptr;  // a static upload replaces a time-dependent source
+  a.loaded = false;
   spectral_invalidate(ctx);  // multipliers derived from the old aux field are stale
   PDEOPT_HIP_CHECK(ctx, hipMemcpyAsync(a.dev, host, bytes, hipMemcpyHostToDevice, ctx->stream));
   PDEOPT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   return PDEOPT_OK;
+}
+
+int pdeopt_set_aux_time_fn(pdeopt_ctx* ctx, int which, pdeopt_aux_fn fn, void* user, int per_env) {
+  if (!ctx) return PDEOPT_EINVAL;
+  if (!ctx->configured) return fail(ctx, PDEOPT_ESTATE, "pdeopt_configure has not been called");
+  if (which != PDEOPT_AUX_GPE_POTENTIAL && which != PDEOPT_AUX_VX_FACE && which != PDEOPT_AUX_VY_FACE)
+    return fail(ctx, PDEOPT_EINVAL, "aux field %d cannot be time-dependent (GPE_POTENTIAL, VX_FACE, VY_FACE can)", which);
+  PDEOPT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  AuxField& a = ctx->aux[which];
+  if (!fn) {
+    a.fn = nullptr;
+    a.user = nullptr;
+    return PDEOPT_OK;
+  }
+  int rc = aux_alloc(ctx, which, per_env);
+  if (rc) return rc;
+  if (!a.stage) {
+    hipError_t e = hipHostMalloc(&a.stage, a.bytes, hipHostMallocDefault);
+    if (e != hipSuccess) {
+      a.stage = nullptr;
+      return fail(ctx, PDEOPT_ENOMEM, "hipHostMalloc(%zu bytes) failed: %s", a.bytes, hipGetErrorString(e));
+    }
+  }
+  a.fn = fn;
+  a.user = user;
+  a.loaded = false;
+  ctx->tsit5_fsal_valid = false;
+  graph_destroy(ctx);
+  return PDEOPT_OK;
+}
+
+int pdeopt_set_env_gpe_k(pdeopt_ctx* ctx, int env_first, int env_count, const double* k) {
+  if (!ctx || !k) return PDEOPT_EINVAL;
+  int rc = check_envs(ctx, env_first, env_count);
+  if (rc) return rc;
+  PDEOPT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  if (ctx->prob.dtype == PDEOPT_F32)
+    patch_env_gpe_k<float>(ctx, env_first, env_count, k);
+  else
+    patch_env_gpe_k<double>(ctx, env_first, env_count, k);
+  return upload_env_params(ctx);
 }
 
 int pdeopt_set_state(pdeopt_ctx* ctx, int env_first, int env_count, const void* host) {
@@ -425,6 +504,7 @@ int pdeopt_advance(pdeopt_ctx* ctx, int integrator, double t0, double dt, int64_
   PDEOPT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   ctx->tsit5_fsal_valid = false;
   ctx->tsit5_pending = false;
+  ctx->last_groups = 1;
   if (ctx->halo)
     return fail(ctx, PDEOPT_EINVAL, "padded layout: drive the substep with pdeopt_rk4_phase + halo exchange");
   const int eq = ctx->prob.equation;
@@ -534,6 +614,9 @@ int pdeopt_get_counter(pdeopt_ctx* ctx, int which, int64_t* value) {
   switch (which) {
     case PDEOPT_CNT_STAGE_LAUNCHES:
       *value = ctx->n_stage_launches;
+      return PDEOPT_OK;
+    case PDEOPT_CNT_LAST_GROUPS:
+      *value = ctx->last_groups;
       return PDEOPT_OK;
     default:
       return fail(ctx, PDEOPT_EINVAL, "unknown counter %d", which);

@@ -8,6 +8,8 @@ objects are cached by source mtime, so a rebuild after touching one file takes s
 
 from __future__ import annotations
 
+import glob
+import hashlib
 import os
 import shutil
 import subprocess
@@ -21,20 +23,14 @@ LIB = os.path.join(PKG, "libpdeopt_hip.so")
 OBJ_DIR = os.path.join(HERE, "build")
 
 SOURCES = ["api.hip", "stencil.hip", "reduce.hip", "spectral.hip", "halo.hip", "strang_fused.hip"]
-HEADERS = [
-    "common.hpp",
-    "closures.hpp",
-    "stencil_generic.hpp",
-    "stencil_tiled.hpp",
-    "stencil_fused.hpp",
-    "stencil_fused_ac.hpp",
-    "stencil_fused_ac4.hpp",
-    "stencil_fused_pipe.hpp",
-    "stencil_fused_wave.hpp",
-    "stencil_fused_launch.hpp",
-    "fft_lds.hpp",
-    os.path.join(ROOT, "include", "pdeopt_hip.h"),
-]
+
+
+def _headers() -> list[str]:
+    """every header a translation unit may include: all of csrc/*.hpp + the public C header"""
+    hs = sorted(glob.glob(os.path.join(HERE, "*.hpp")))
+    return hs + [os.path.join(ROOT, "include", "pdeopt_hip.h")]
+
+
 ARCH = "gfx950"
 CXXFLAGS = [
     "-O3",
@@ -61,15 +57,16 @@ def _hipcc() -> str:
 
 
 def _newest_header() -> float:
-    t = 0.0
-    for h in HEADERS + [os.path.abspath(__file__)]:
-        p = h if os.path.isabs(h) else os.path.join(HERE, h)
-        t = max(t, os.path.getmtime(p))
-    return t
+    return max(os.path.getmtime(p) for p in _headers() + [os.path.abspath(__file__)])
+
+
+def _flags_tag(extra: list[str]) -> str:
+    """objects built with different flags never share a cache entry"""
+    return hashlib.sha1(" ".join(CXXFLAGS + extra).encode()).hexdigest()[:10]
 
 
 def _compile(src: str, force: bool, extra: list[str]) -> str:
-    obj = os.path.join(OBJ_DIR, src.replace(".hip", ".o"))
+    obj = os.path.join(OBJ_DIR, src.replace(".hip", f".{_flags_tag(extra)}.o"))
     sp = os.path.join(HERE, src)
     stamp = max(os.path.getmtime(sp), _newest_header())
     if not force and os.path.exists(obj) and os.path.getmtime(obj) >= stamp:
@@ -88,7 +85,11 @@ def build(force: bool = False, verbose: bool = True, extra_flags: list[str] | No
     extra = list(extra_flags or [])
     with ThreadPoolExecutor(max_workers=min(6, len(SOURCES))) as ex:
         objs = list(ex.map(lambda s: _compile(s, force, extra), SOURCES))
-    need_link = force or not os.path.exists(LIB) or any(
+    # the link stamp records which objects (flag sets included) the library was made of
+    stamp = os.path.join(OBJ_DIR, "link.stamp")
+    want = "\n".join(objs)
+    have = open(stamp).read() if os.path.exists(stamp) else ""
+    need_link = force or not os.path.exists(LIB) or have != want or any(
         os.path.getmtime(o) > os.path.getmtime(LIB) for o in objs
     )
     if need_link:
@@ -97,6 +98,8 @@ def build(force: bool = False, verbose: bool = True, extra_flags: list[str] | No
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{' '.join(cmd)}\n{r.stdout}\n{r.stderr}")
+        with open(stamp, "w") as f:
+            f.write(want)
     if verbose:
         print(f"[pde_opt_amd] {LIB} ({os.path.getsize(LIB) / 1e6:.1f} MB)")
     return LIB

@@ -51,6 +51,12 @@ struct AuxField {
   void* dev = nullptr;
   int per_env = 0;
   size_t bytes = 0;
+  // time-dependent source (pdeopt_set_aux_time_fn): host callback, pinned staging buffer, time last uploaded
+  pdeopt_aux_fn fn = nullptr;
+  void* user = nullptr;
+  void* stage = nullptr;
+  double t_loaded = 0.0;
+  bool loaded = false;
 };
 
 struct Spectral;     // rocFFT plans + work buffers (spectral.hip)
@@ -122,9 +128,10 @@ struct pdeopt_ctx {
   pdeopt::GraphKey graph_key{};
   int64_t graph_launches_per_replay = 0;
   std::string graph_name;
-  int64_t opt_fuse_stages = 0;   // RK4 stage-pair fusion: 0 auto, -1 off, 1 one tile per workgroup, 2 persistent + LDS-DMA pipeline, 3 wave-local tiles
+  int64_t opt_fuse_stages = 0;   // RK4 stage-pair fusion: 0 auto, -1 off (one launch per stage), 1 stage pairs (AC: no single-pass kernel)
   int64_t opt_debug_ablate = 0;  // timing-only ablations, results are wrong when set
   int win_lo = 0, win_n = 0;  // environment window the stage launchers operate on
+  int64_t last_groups = 1;    // environment groups of the last advance (PDEOPT_CNT_LAST_GROUPS)
   double imex_A = 0.5, ts_re = 1.0, ts_im = 0.0, strang_dx = 1.0;
   double* red_dev = nullptr;  // reduction scratch
   size_t red_cap = 0;
@@ -161,6 +168,9 @@ int fail(pdeopt_ctx* ctx, int code, const char* fmt, ...);
   } while (0)
 
 int ensure_buffer(pdeopt_ctx* ctx, void** p, size_t bytes);
+// api.hip: bring a time-dependent auxiliary field to local time t (no-op for static fields)
+int refresh_time_aux(pdeopt_ctx* ctx, int which, double t);
+inline bool has_time_aux(const pdeopt_ctx* ctx, int which) { return ctx->aux[which].fn != nullptr; }
 
 // stencil.hip
 int launch_rhs(pdeopt_ctx* ctx, const void* in, void* out, double t);
@@ -193,7 +203,7 @@ void spectral_destroy(pdeopt_ctx* ctx);
 void spectral_invalidate(pdeopt_ctx* ctx);
 // strang_fused.hip
 bool strang_fused_supported(const pdeopt_ctx* ctx);
-int advance_strang_fused(pdeopt_ctx* ctx, double dt, int64_t n);
+int advance_strang_fused(pdeopt_ctx* ctx, double t0, double dt, int64_t n);
 bool imex_fused_supported(const pdeopt_ctx* ctx);
 int advance_imex_fused(pdeopt_ctx* ctx, double dt, int64_t n);
 void strang_fused_invalidate(pdeopt_ctx* ctx);

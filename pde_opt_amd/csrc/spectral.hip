@@ -367,7 +367,7 @@ int imex_t(pdeopt_ctx* ctx, double dt, int64_t n) {
 }
 
 template <typename T>
-int strang_t(pdeopt_ctx* ctx, double dt, int64_t n) {
+int strang_t(pdeopt_ctx* ctx, double t0, double dt, int64_t n) {
   Spectral& sp = *ctx->spectral;
   const pdeopt_problem& p = ctx->prob;
   const int64_t cells = (int64_t)p.nx * p.ny;
@@ -399,6 +399,8 @@ int strang_t(pdeopt_ctx* ctx, double dt, int64_t n) {
     hipLaunchKernelGGL((spectral_mul_kernel<T, false>), mgrid, dim3(256), 0, ctx->stream,
                        (C2<T>*)ctx->Y, (const C2<T>*)sp.mult, nullptr, cells);
     if ((rc = fft_exec(ctx, false, ctx->Y))) return rc;
+    // b = terms.vf(t0, y0): a time-dependent potential is evaluated at this substep's start time (solvers.py:109)
+    if ((rc = refresh_time_aux(ctx, PDEOPT_AUX_GPE_POTENTIAL, t0 + (double)s * dt))) return rc;
     hipLaunchKernelGGL(strang_b_kernel<T>, dim3(kNormBlocks, p.batch), dim3(256), 0, ctx->stream,
                        (C2<T>*)ctx->Y, (const T*)sp.dens, (const T*)pot.dev, pot_stride,
                        (const EnvParams<T>*)ctx->env_params_dev, (T)tau.real(), (T)tau.imag(), cells,
@@ -566,13 +568,13 @@ int advance_imex(pdeopt_ctx* ctx, double, double dt, int64_t n) {
   return ctx->prob.dtype == PDEOPT_F32 ? imex_t<float>(ctx, dt, n) : imex_t<double>(ctx, dt, n);
 }
 
-int advance_strang(pdeopt_ctx* ctx, double, double dt, int64_t n) {
+int advance_strang(pdeopt_ctx* ctx, double t0, double dt, int64_t n) {
   if (!ctx->aux[PDEOPT_AUX_GPE_A_TERM].dev)
     return fail(ctx, PDEOPT_ESTATE, "Strang splitting needs the GPE_A_TERM aux field");
-  if (strang_fused_supported(ctx)) return advance_strang_fused(ctx, dt, n);  // LDS FFTs, fused passes
+  if (strang_fused_supported(ctx)) return advance_strang_fused(ctx, t0, dt, n);  // LDS FFTs, fused passes
   int rc = ensure_plans(ctx);
   if (rc) return rc;
-  return ctx->prob.dtype == PDEOPT_F32 ? strang_t<float>(ctx, dt, n) : strang_t<double>(ctx, dt, n);
+  return ctx->prob.dtype == PDEOPT_F32 ? strang_t<float>(ctx, t0, dt, n) : strang_t<double>(ctx, t0, dt, n);
 }
 
 void spectral_invalidate(pdeopt_ctx* ctx) {

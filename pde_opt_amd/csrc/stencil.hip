@@ -13,7 +13,6 @@
 #include "stencil_fused.hpp"
 #include "stencil_fused_ac.hpp"
 #include "stencil_fused_ac4.hpp"
-#include "stencil_fused_pipe.hpp"
 #include "stencil_fused_launch.hpp"
 
 namespace pdeopt {
@@ -154,6 +153,12 @@ int launch_stage_fourier(pdeopt_ctx* ctx, const StageArgs<T>& s, const void* in,
 template <typename T>
 int launch_stage_t(pdeopt_ctx* ctx, const void* in, const void* y, void* out, void* acc, double a,
                    double b, int out_mode, int acc_mode) {
+  if (ctx->prob.equation == PDEOPT_EQ_ADVECTION_DIFFUSION) {
+    // velocity_fn(t, x, y): face velocities at the time of THIS right-hand side (ctx->cur_t = stage time)
+    int rc;
+    if ((rc = refresh_time_aux(ctx, PDEOPT_AUX_VX_FACE, ctx->cur_t))) return rc;
+    if ((rc = refresh_time_aux(ctx, PDEOPT_AUX_VY_FACE, ctx->cur_t))) return rc;
+  }
   StageArgs<T> s = make_args<T>(ctx, in, y, out, acc, a, b, out_mode, acc_mode);
   ctx->n_stage_launches++;
   if (ctx->prob.derivs == PDEOPT_DERIVS_FOURIER) return launch_stage_fourier<T>(ctx, s, in, out);
@@ -177,6 +182,11 @@ int launch_stage(pdeopt_ctx* ctx, const void* in, const void* y, void* out, void
 template <typename T>
 int launch_stage_lc(pdeopt_ctx* ctx, const void* in, const void* y, void* kout, void* const* ks, const double* c,
                     int n, void* next) {
+  if (ctx->prob.equation == PDEOPT_EQ_ADVECTION_DIFFUSION) {
+    int rc;
+    if ((rc = refresh_time_aux(ctx, PDEOPT_AUX_VX_FACE, ctx->cur_t))) return rc;
+    if ((rc = refresh_time_aux(ctx, PDEOPT_AUX_VY_FACE, ctx->cur_t))) return rc;
+  }
   StageArgs<T> s = make_args<T>(ctx, in, y, kout, nullptr, 0.0, 0.0, OUT_K_LC, ACC_NONE);
   const int64_t woff = (int64_t)ctx->win_lo * s.g.bstride;
   for (int j = 0; j < n; ++j) {
@@ -264,9 +274,12 @@ int advance_explicit(pdeopt_ctx* ctx, int integrator, double t0, double dt, int6
   // reads and writes on-die for all n substeps instead of streaming the whole batch through HBM
   // once per stage.
   const int batch = ctx->prob.batch;
+  // time-dependent terms evaluated by the host per stage (smoothed-boundary scalars, advection velocities)
+  const bool timed = ctx->prob.equation == PDEOPT_EQ_ALLEN_CAHN_SBM || ctx->prob.equation == PDEOPT_EQ_CAHN_HILLIARD_SBM ||
+                     has_time_aux(ctx, PDEOPT_AUX_VX_FACE) || has_time_aux(ctx, PDEOPT_AUX_VY_FACE);
   int group = batch;
-  if (ctx->prob.derivs == PDEOPT_DERIVS_FOURIER) {
-    group = batch;  // batched rocFFT plans cover the whole batch
+  if (ctx->prob.derivs == PDEOPT_DERIVS_FOURIER || timed) {
+    group = batch;  // batched rocFFT plans cover the whole batch; host callbacks run once per stage time
   } else if (ctx->opt_group_envs > 0) {
     group = (int)std::min<int64_t>(ctx->opt_group_envs, batch);
   } else if (ctx->opt_group_envs == 0) {
@@ -335,7 +348,6 @@ int advance_explicit(pdeopt_ctx* ctx, int integrator, double t0, double dt, int6
   // per-environment parameter VALUES live in device memory and may change between replays.
   int64_t done = 0;
   const int64_t cells_per_launch = (int64_t)ctx->prob.nx * ctx->prob.ny * group;
-  const bool timed = ctx->prob.equation == PDEOPT_EQ_ALLEN_CAHN_SBM || ctx->prob.equation == PDEOPT_EQ_CAHN_HILLIARD_SBM;
   const bool want_graph = !timed && ctx->opt_graph >= 0 && group >= batch && ctx->prob.derivs == PDEOPT_DERIVS_FD &&
                           n >= 2 * kGraphUnit && (ctx->opt_graph > 0 || cells_per_launch <= (1 << 20));
   if (want_graph) {
@@ -390,6 +402,7 @@ int advance_explicit(pdeopt_ctx* ctx, int integrator, double t0, double dt, int6
 
   void* y_final = ctx->Y;
   void* ta_final = ctx->TA;
+  ctx->last_groups = (batch + group - 1) / group;
   for (int lo = 0; lo < batch; lo += group) {
     ctx->win_lo = lo;
     ctx->win_n = std::min(group, batch - lo);

@@ -487,8 +487,6 @@ bool fused_supported(const pdeopt_ctx* ctx) {
 
 template <typename T, int CL, int PAIR, int RPT>
 int launch_pair_ac_inst(pdeopt_ctx* ctx, const PairArgs<T>& s);  // stencil_fused_ac.hpp
-template <typename T, int CL, int PAIR>
-int launch_pair_pipe_inst(pdeopt_ctx* ctx, const PairArgs<T>& s);  // stencil_fused_pipe.hpp
 
 template <typename T, int CL, int PAIR, int RPT>
 int launch_pair_ch_inst(pdeopt_ctx* ctx, const PairArgs<T>& s);

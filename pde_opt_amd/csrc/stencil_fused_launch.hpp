@@ -4,8 +4,6 @@
 
 #include "stencil_fused.hpp"
 #include "stencil_fused_ac.hpp"
-#include "stencil_fused_pipe.hpp"
-#include "stencil_fused_wave.hpp"
 
 namespace pdeopt {
 
@@ -39,22 +37,6 @@ int launch_pair(pdeopt_ctx* ctx, int pair, const void* in, const void* y, const 
   snprintf(name, sizeof(name), "stage_pair<%s,%s,%s,rows%d>", sizeof(T) == 4 ? "f32" : "f64",
            p.equation == PDEOPT_EQ_ALLEN_CAHN ? "AC" : "CH", cl == CL_LOGIT ? "logit" : "poly", 8 * rpt);
   ctx->last_kernel = name;
-  if (p.equation == PDEOPT_EQ_CAHN_HILLIARD && ctx->opt_fuse_stages == 3 && !ctx->halo) {
-    ctx->last_kernel += "+wave";
-    if (cl == CL_LOGIT)
-      return pair == PAIR_12 ? launch_pair_wave_inst<T, CL_LOGIT, PAIR_12>(ctx, s)
-                             : launch_pair_wave_inst<T, CL_LOGIT, PAIR_34>(ctx, s);
-    return pair == PAIR_12 ? launch_pair_wave_inst<T, CL_POLY, PAIR_12>(ctx, s)
-                           : launch_pair_wave_inst<T, CL_POLY, PAIR_34>(ctx, s);
-  }
-  if (p.equation == PDEOPT_EQ_CAHN_HILLIARD && rpt == 2 && ctx->opt_fuse_stages == 2) {
-    ctx->last_kernel += "+pipe";
-    if (cl == CL_LOGIT)
-      return pair == PAIR_12 ? launch_pair_pipe_inst<T, CL_LOGIT, PAIR_12>(ctx, s)
-                             : launch_pair_pipe_inst<T, CL_LOGIT, PAIR_34>(ctx, s);
-    return pair == PAIR_12 ? launch_pair_pipe_inst<T, CL_POLY, PAIR_12>(ctx, s)
-                           : launch_pair_pipe_inst<T, CL_POLY, PAIR_34>(ctx, s);
-  }
   if (cl == CL_LOGIT && p.mu.n <= 2 && p.equation == PDEOPT_EQ_CAHN_HILLIARD) {
     // linear polynomial part: the shorter closure (same bits, see closures.hpp)
     if (rpt == 2)

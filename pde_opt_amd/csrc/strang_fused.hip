@@ -330,7 +330,7 @@ int upload_table(pdeopt_ctx* ctx, void** dev, int n) {
 }
 
 template <typename T>
-int strang_fused_t(pdeopt_ctx* ctx, double dt, int64_t n) {
+int strang_fused_t(pdeopt_ctx* ctx, double t0, double dt, int64_t n) {
   if (!ctx->strang_fused) ctx->strang_fused = new StrangFused();
   StrangFused& sf = *ctx->strang_fused;
   const pdeopt_problem& p = ctx->prob;
@@ -371,8 +371,13 @@ int strang_fused_t(pdeopt_ctx* ctx, double dt, int64_t n) {
   const double tr = tau.real(), ti = tau.imag();
   // Environments are independent: run the whole n-step pipeline group by group, a group's wavefunction +
   // density (12 B/cell at fp32) sized to stay in the 256 MiB Infinity Cache between its passes.
+  // A time-dependent potential (lights(t, x, y), gross_pitaevskii.py:61) is brought to each substep's t0
+  // before the pass that applies exp(b tau) (b = terms.vf(t0, y0), solvers.py:109): one sweep over the batch.
+  const bool timed = has_time_aux(ctx, PDEOPT_AUX_GPE_POTENTIAL);
   int group = p.batch;
-  if (ctx->opt_group_envs > 0) {
+  if (timed) {
+    group = p.batch;
+  } else if (ctx->opt_group_envs > 0) {
     group = (int)std::min<int64_t>(ctx->opt_group_envs, p.batch);
   } else if (ctx->opt_group_envs == 0) {
     const size_t per_env = (size_t)cells * (sizeof(Cx<T>) + sizeof(T));
@@ -382,12 +387,14 @@ int strang_fused_t(pdeopt_ctx* ctx, double dt, int64_t n) {
       group = (p.batch + ngroups - 1) / ngroups;
     }
   }
+  ctx->last_groups = (p.batch + group - 1) / group;
   for (int lo = 0; lo < p.batch && !rc; lo += group) {
     ctx->win_lo = lo;
     ctx->win_n = std::min(group, p.batch - lo);
     if ((rc = row_dispatch<T, ROW_FIRST>(ctx, sf, tr, ti))) break;
     for (int64_t s = 0; s < n; ++s) {
       if ((rc = col_dispatch<T, false>(ctx, sf))) break;
+      if (timed && (rc = refresh_time_aux(ctx, PDEOPT_AUX_GPE_POTENTIAL, t0 + (double)s * dt))) break;
       if ((rc = row_dispatch<T, ROW_MID>(ctx, sf, tr, ti))) break;
       if ((rc = col_dispatch<T, true>(ctx, sf))) break;
       if (s + 1 < n)
@@ -578,6 +585,7 @@ int imex_fused_t(pdeopt_ctx* ctx, double dt, int64_t n) {
       group = ((p.batch + ngroups - 1) / ngroups + 1) & ~1;
     }
   }
+  ctx->last_groups = (p.batch + group - 1) / group;
   for (int lo = 0; lo < p.batch && !rc; lo += group) {
     ctx->win_lo = lo;
     ctx->win_n = std::min(group, p.batch - lo);
@@ -635,8 +643,8 @@ bool strang_fused_supported(const pdeopt_ctx* ctx) {
   return true;
 }
 
-int advance_strang_fused(pdeopt_ctx* ctx, double dt, int64_t n) {
-  return ctx->prob.dtype == PDEOPT_F32 ? strang_fused_t<float>(ctx, dt, n) : strang_fused_t<double>(ctx, dt, n);
+int advance_strang_fused(pdeopt_ctx* ctx, double t0, double dt, int64_t n) {
+  return ctx->prob.dtype == PDEOPT_F32 ? strang_fused_t<float>(ctx, t0, dt, n) : strang_fused_t<double>(ctx, t0, dt, n);
 }
 
 void strang_fused_invalidate(pdeopt_ctx* ctx) {

@@ -56,9 +56,14 @@ class HipEngine:
         self.dtype = np.float32
         self.batch = 0
         self.state_shape: tuple = ()
+        self._aux_thunks: dict = {}
+        self._callback_error = None
 
     # -- plumbing ---------------------------------------------------------------------------
     def _check(self, rc: int):
+        err, self._callback_error = getattr(self, "_callback_error", None), None
+        if err is not None:  # a Python callback raised inside the library call: re-raise it here
+            raise err
         if rc != L.OK:
             msg = self._lib.pdeopt_last_error(self._h).decode()
             if rc == L.EINVAL:
@@ -156,7 +161,7 @@ class HipEngine:
         ptrs = [b.ctypes.data_as(C.c_void_p) if b is not None else None for b in bufs]
         self._check(self._lib.pdeopt_set_env_params(self._h, int(env_first), int(count), *ptrs))
 
-    def set_aux(self, which: int, field, per_env: bool = False):
+    def _aux_array(self, which: int, field, per_env: bool) -> np.ndarray:
         cplx = which in (L.AUX_IMEX_SYMBOL, L.AUX_GPE_A_TERM)
         p = self.problem
         if cplx:
@@ -166,8 +171,41 @@ class HipEngine:
         want = ((p.batch,) if per_env else ()) + (p.nx, p.ny) + ((p.nz,) if p.nz > 1 else ())
         if a.shape != want:
             a = np.broadcast_to(a, want)
-        a = np.ascontiguousarray(a)
+        return np.ascontiguousarray(a)
+
+    def set_aux(self, which: int, field, per_env: bool = False):
+        a = self._aux_array(which, field, per_env)
         self._check(self._lib.pdeopt_set_aux(self._h, int(which), a.ctypes.data_as(C.c_void_p), int(per_env)))
+        self._aux_thunks.pop(int(which), None)  # the static upload replaced a time-dependent source
+
+    def set_aux_time_fn(self, which: int, fn, per_env: bool = False):
+        """Time-dependent auxiliary field: ``fn(t)`` returns the field ((nx, ny), or (batch, nx, ny) with
+        ``per_env``) at local time ``t``; the library calls it once per distinct evaluation time from inside
+        ``advance`` / ``rhs`` (every Strang substep's t0, every Runge-Kutta stage time), as the reference's
+        ``terms.vf(t, y, args)`` does (numerics/solvers.py:109).  ``fn=None`` removes it."""
+        which = int(which)
+        if fn is None:
+            self._check(self._lib.pdeopt_set_aux_time_fn(self._h, which, L.AUX_FN(0), None, 0))
+            self._aux_thunks.pop(which, None)
+            return
+
+        def thunk(t, w, out_ptr, _user):
+            try:
+                a = self._aux_array(w, fn(t), per_env)
+                C.memmove(out_ptr, a.ctypes.data, a.nbytes)
+                return 0
+            except BaseException as e:  # noqa: BLE001 -- must not propagate through the C frame
+                self._callback_error = e
+                return 1
+
+        cb = L.AUX_FN(thunk)
+        self._check(self._lib.pdeopt_set_aux_time_fn(self._h, which, cb, None, int(per_env)))
+        self._aux_thunks[which] = cb  # keep the ctypes thunk alive while the library may call it
+
+    def set_env_gpe_k(self, env_first: int, k):
+        """per-environment GPE interaction strength (the control value travels with the environment)"""
+        a = np.ascontiguousarray(np.atleast_1d(np.asarray(k, dtype=np.float64)))
+        self._check(self._lib.pdeopt_set_env_gpe_k(self._h, int(env_first), a.shape[0], a.ctypes.data_as(C.c_void_p)))
 
     def set_integrator_params(self, imex_A=0.5, time_scale=1.0, strang_dx=1.0):
         ts = complex(time_scale)
@@ -310,6 +348,12 @@ class HipEngine:
     def stage_launches(self) -> int:
         v = C.c_int64()
         self._check(self._lib.pdeopt_get_counter(self._h, L.CNT_STAGE_LAUNCHES, C.byref(v)))
+        return v.value
+
+    def last_groups(self) -> int:
+        """environment groups the last ``advance`` ran the batch in (1 = the whole batch per sweep)"""
+        v = C.c_int64()
+        self._check(self._lib.pdeopt_get_counter(self._h, L.CNT_LAST_GROUPS, C.byref(v)))
         return v.value
 
     def sync(self):

@@ -47,7 +47,7 @@ def constant_step_plan(t0, t1, dt, rel_tol=1e-9):
     return n_full, rem
 
 
-def _prepare(equation, solver, y0, engine: Optional[HipEngine], t_aux: float):
+def _prepare(equation, solver, y0, engine: Optional[HipEngine], t_aux: float, t_end: Optional[float] = None):
     y0 = np.asarray(y0)
     if np.iscomplexobj(y0):
         raise ValueError("complex states are stored as (..., 2) real/imag pairs (gross_pitaevskii.py:75)")
@@ -64,7 +64,7 @@ def _prepare(equation, solver, y0, engine: Optional[HipEngine], t_aux: float):
 
         engine = default_engine()
     engine.configure(dtype=yb.dtype, batch=yb.shape[0], **equation._engine_problem())
-    equation._engine_upload(engine, t_aux)
+    equation._engine_upload(engine, t_aux, t_end)  # time-dependent terms register a per-substep source
     solver.configure_engine(engine, equation)
     engine.set_state(yb)
     return engine, single
@@ -89,7 +89,7 @@ def diffeqsolve(
     saveat = saveat or SaveAt(t1=True)
     controller = stepsize_controller or ConstantStepSize()
     t0, t1 = float(t0), float(t1)
-    eng, single = _prepare(equation, solver, y0, engine, t0)
+    eng, single = _prepare(equation, solver, y0, engine, t0, t1)
     take = (lambda a: a[0]) if single else (lambda a: a)
 
     if isinstance(controller, PIDController):

@@ -20,8 +20,19 @@ class BaseEquation(ABC):
         """kwargs for HipEngine.configure (minus dtype / batch)."""
         raise NotImplementedError(f"{type(self).__name__} has no HIP kernel")
 
-    def _engine_upload(self, engine, t: float = 0.0) -> None:
-        """auxiliary fields; ``t`` is the local time they are frozen at for this advance call."""
+    def _engine_upload(self, engine, t: float = 0.0, t_end=None) -> None:
+        """Auxiliary fields for integration over local times ``[t, t_end]`` (``t_end=None``: one
+        right-hand-side evaluation at ``t``).  Fields that depend on time register a source the library
+        calls at every substep / stage time (``HipEngine.set_aux_time_fn``); constant ones are uploaded once."""
+
+    # names of constructor parameters whose VALUE may differ between the environments of one batch
+    # (VectorPDEEnv): they travel with the environment (per-environment scalars / auxiliary fields)
+    _per_env_controls: frozenset = frozenset()
+
+    @classmethod
+    def _engine_upload_batch(cls, engine, eqs, t: float = 0.0, t_end=None) -> None:
+        """``_engine_upload`` for a batch whose environment b is described by ``eqs[b]``"""
+        eqs[0]._engine_upload(engine, t, t_end)
 
     _state_trailing = ()  # trailing state axes after (nx, ny); the GPE has (2,)
 
@@ -47,6 +58,19 @@ class BaseEquation(ABC):
         eng.set_state(a)
         out = eng.rhs(float(t))
         return out[0] if single else out
+
+
+def depends_on_time(fn, t: float, t_end) -> bool:
+    """Does ``fn(t)`` (an array-valued function of local time) change over ``[t, t_end]``?  Probed at
+    the two ends and two interior points; equations expose ``time_dependent=True/False`` to override
+    (a callable that only changes inside a narrow window between the probes needs the override)."""
+    if t_end is None or not t_end > t:
+        return False
+    ref = np.asarray(fn(t))
+    for frac in (0.381966, 0.723607, 1.0):
+        if not np.array_equal(np.asarray(fn(t + frac * (t_end - t))), ref):
+            return True
+    return False
 
 
 class TimeSplittingEquation(BaseEquation):

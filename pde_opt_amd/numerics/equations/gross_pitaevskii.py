@@ -6,6 +6,12 @@ ymesh, control, two_pi_i_k_2 ...``; state layout ``(N, N, 2)`` = (re, im).
 
     B(state, t) = -i/2 trap_factor ((1+e) X^2 + (1-e) Y^2) - i lights(t, X, Y) - i k |psi|^2
 
+``lights(t, X, Y)`` is evaluated at the start time of EVERY Strang substep, as upstream's
+``b_term = terms.vf(t0, y0, args)`` does (numerics/solvers.py:109 -> gross_pitaevskii.py:61,67-75):
+a control that depends on time registers a source the library calls per substep
+(``pdeopt_set_aux_time_fn``); one that does not is uploaded once.  ``time_dependent`` (new, default
+``None`` = probe ``lights`` over the integration interval) forces either behaviour.
+
 Quirk kept: upstream multiplies ``A_term`` by 0.0 (:62), so the committed
 kinetic half-step is the identity.  Here ``A_term`` is caller data: by default it reproduces the
 committed value (zeros); ``kinetic=True`` publishes the physical ``0.5j (2 pi i k)^2``.
@@ -14,13 +20,13 @@ committed value (zeros); ``kinetic=True`` publishes the physical ``0.5j (2 pi i 
 from __future__ import annotations
 
 import dataclasses
-from typing import Callable
+from typing import Callable, Optional
 
 import numpy as np
 
 from ... import _lib as L
 from ..domains import Domain
-from .base_eq import TimeSplittingEquation
+from .base_eq import TimeSplittingEquation, depends_on_time
 from .phase_field import spectral_table
 
 # constants published by the reference module (gross_pitaevskii.py:12-15)
@@ -37,6 +43,7 @@ class GPE2DTSControl(TimeSplittingEquation):
     lights: Callable
     trap_factor: float = 1.0
     kinetic: bool = False
+    time_dependent: Optional[bool] = None
     fft = None
     ifft = None
     A_term = None
@@ -72,8 +79,34 @@ class GPE2DTSControl(TimeSplittingEquation):
         hx, hy = self.domain.dx
         return dict(equation=L.EQ_GPE, nx=nx, ny=ny, hx=hx, hy=hy, gpe_k=float(self.k))
 
-    def _engine_upload(self, engine, t: float = 0.0):
-        engine.set_aux(L.AUX_GPE_POTENTIAL, self.potential(t))
+    _per_env_controls = frozenset({"k", "e", "lights", "trap_factor"})
+
+    def _lights_vary(self, t, t_end) -> bool:
+        if self.time_dependent is not None:
+            return bool(self.time_dependent) and t_end is not None
+        return depends_on_time(self.control, t, t_end)
+
+    def _engine_upload(self, engine, t: float = 0.0, t_end=None):
+        if self._lights_vary(t, t_end):
+            engine.set_aux_time_fn(L.AUX_GPE_POTENTIAL, self.potential)
+        else:
+            engine.set_aux(L.AUX_GPE_POTENTIAL, self.potential(t))
+
+    @classmethod
+    def _engine_upload_batch(cls, engine, eqs, t: float = 0.0, t_end=None):
+        """Per-environment interaction strengths and potentials (``VectorPDEEnv``: the control of
+        environment b is one of k, e, lights, trap_factor)."""
+        eq0 = eqs[0]
+        if any(e.kinetic != eq0.kinetic for e in eqs):
+            raise ValueError("all environments of a batch must share A_term (the `kinetic` switch)")
+        engine.set_env_gpe_k(0, [float(e.k) for e in eqs])
+        shared = all(e.lights is eq0.lights and e.e == eq0.e and e.trap_factor == eq0.trap_factor for e in eqs)
+        if shared:
+            eq0._engine_upload(engine, t, t_end)
+        elif any(e._lights_vary(t, t_end) for e in eqs):
+            engine.set_aux_time_fn(L.AUX_GPE_POTENTIAL, lambda tt: np.stack([e.potential(tt) for e in eqs]), per_env=True)
+        else:
+            engine.set_aux(L.AUX_GPE_POTENTIAL, np.stack([e.potential(t) for e in eqs]), per_env=True)
 
     def A_terms(self, state, t):
         return self.A_term * 0.0

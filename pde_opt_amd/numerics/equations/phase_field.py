@@ -93,6 +93,8 @@ class CahnHilliard2DPeriodic(BaseEquation):
         """kappa (2 pi i k)^4, the stiff linear symbol of the IMEX solver (cahn_hilliard.py:74)"""
         return self.kappa * self.two_pi_i_k_4
 
+    _per_env_controls = frozenset({"kappa", "mu", "D"})
+
     def rhs(self, state, t):  # replaced in __post_init__, as upstream
         raise NotImplementedError("rhs method not implemented")
 
@@ -127,6 +129,8 @@ class AllenCahn2DPeriodic(BaseEquation):
     mu: Any
     R: Any
     derivs: str = "fd"
+
+    _per_env_controls = frozenset({"kappa", "mu", "R"})
 
     def rhs(self, state, t):
         raise NotImplementedError("rhs method not implemented")
@@ -169,6 +173,7 @@ class CahnHilliard3DPeriodic(BaseEquation):
     fft = None
     ifft = None
     fourier_symbol = None
+    _per_env_controls = frozenset({"kappa", "mu", "D"})
 
     def rhs(self, state, t):  # replaced in __post_init__, as upstream
         raise NotImplementedError("rhs method not implemented")

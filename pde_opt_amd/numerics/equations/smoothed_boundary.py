@@ -72,7 +72,7 @@ class _SmoothedBoundary(BaseEquation):
                     kappa=float(self.kappa), mu=self._mu_desc, mob=self._mob_desc, fe=self._f_desc,
                     derivs=L.DERIVS_FD)
 
-    def _engine_upload(self, engine, t: float = 0.0):
+    def _engine_upload(self, engine, t: float = 0.0, t_end=None):
         engine.set_aux(L.AUX_SBM_PSI, self.psi)
         engine.set_aux(L.AUX_SBM_NORM_GRAD, self.norm_grad_psi)
         engine.set_aux(L.AUX_SBM_MASK, self.left_half)

@@ -59,6 +59,7 @@ class PDEEnv(EnvBase):
         control_equation_parameter_name: str,
         solver_parameters: Dict[str, Any],
         device: int = 0,
+        engine=None,
     ):
         if HAVE_GYMNASIUM:  # pragma: no cover
             super().__init__()
@@ -84,7 +85,9 @@ class PDEEnv(EnvBase):
         self.control_equation_parameter_name = control_equation_parameter_name
         self.solver_parameters = solver_parameters
 
-        self._engine = HipEngine(device)  # raises HipUnavailableError without a GPU / library
+        # raises HipUnavailableError without a GPU / library (`engine`: a caller-owned HipEngine, e.g. one
+        # bound to a stream; the CPU test-suite injects its oracle-backed double here)
+        self._engine = engine if engine is not None else HipEngine(device)
         self._state = None
         self._time = 0.0
         self._control_value = reset_control_value
@@ -149,7 +152,7 @@ class PDEEnv(EnvBase):
             y = y.astype(np.float64)
         eng = self._engine
         eng.configure(dtype=y.dtype, batch=1, **eq._engine_problem())
-        eq._engine_upload(eng, 0.0)
+        eq._engine_upload(eng, 0.0, self.step_dt)  # time-dependent controls see the local time of every substep
         solver.configure_engine(eng, eq)
         eng.set_state(y)
         n_full, rem = constant_step_plan(0.0, self.step_dt, self.numeric_dt)
@@ -169,9 +172,13 @@ class VectorPDEEnv:
     """B independent PDEEnv episodes advanced in lock step on one GPU (new capability).
 
     Semantics per environment are exactly ``PDEEnv``'s.  ``step(actions)`` takes one action per
-    environment; the control parameter of environment b must be a number or map onto closure
-    *coefficients* (same closure structure across the batch), so the whole batch runs in one
-    launch per stage with per-environment coefficient tables.
+    environment and every environment integrates with ITS control parameter: numbers and closure
+    *coefficients* (same closure structure across the batch) travel in per-environment tables, fields
+    that depend on the control (the GPE potential for ``e`` / ``lights`` / ``trap_factor``, face velocities
+    of advection-diffusion) are uploaded per environment, so the whole batch still runs in one launch per
+    stage.  A control the kernels cannot vary inside one batch (see ``_per_env_controls`` of the equation
+    class; the IMEX solver's ``fourier_symbol`` when ``kappa`` is the control) raises ``ValueError`` as
+    soon as two environments disagree on it -- never a silently shared value.
 
     ``reward`` / observations: ``reward_function`` and ``state_to_observation_func`` are applied
     per environment on host copies unless ``device_reward`` names an on-device reduction
@@ -203,6 +210,7 @@ class VectorPDEEnv:
         device_reward: Optional[str] = None,
         fetch_observations: bool = True,
         device_observation: Optional[tuple] = None,
+        engine=None,
     ):
         self.num_envs = int(num_envs)
         self.equation_type, self.domain, self.solver_type = equation_type, domain, solver_type
@@ -228,7 +236,7 @@ class VectorPDEEnv:
         else:
             self.single_action_space = Box(low=cfg.get("low", -1.0), high=cfg.get("high", 1.0), shape=cfg.get("shape", (2,)))
             self._action_to_direction = None
-        self._engine = HipEngine(device)
+        self._engine = engine if engine is not None else HipEngine(device)
         self._configured_key = None
         self._time = np.zeros(self.num_envs)
         self._control_value = [reset_control_value] * self.num_envs
@@ -278,17 +286,49 @@ class VectorPDEEnv:
         self._engine.set_env_params(0, kappa=kappa, mu_coef=mu, mob_coef=mob)
         return eq0
 
+    @staticmethod
+    def _same(a, b) -> bool:
+        if a is b:
+            return True
+        if callable(a) or callable(b):
+            return False
+        try:
+            return bool(np.all(np.asarray(a) == np.asarray(b)))
+        except Exception:
+            return False
+
+    def _check_controls(self, eq0, controls):
+        """environments may only disagree on parameters the batched kernels carry per environment"""
+        if all(self._same(c, controls[0]) for c in controls[1:]):
+            return
+        name = self.control_equation_parameter_name
+        if name not in type(eq0)._per_env_controls:
+            raise ValueError(
+                f"{type(eq0).__name__}: the control parameter {name!r} cannot differ between the environments "
+                f"of one VectorPDEEnv (per-environment controls: {sorted(type(eq0)._per_env_controls)})")
+        from .numerics.solvers import SemiImplicitFourierSpectral
+
+        if self.solver_type is SemiImplicitFourierSpectral and name == "kappa":
+            raise ValueError(
+                "SemiImplicitFourierSpectral with a per-environment kappa: fourier_symbol = kappa (2 pi i k)^4 "
+                "would differ between environments, and the batched IMEX transforms share one implicit "
+                "operator; use one PDEEnv per kappa or an explicit integrator")
+
     def step(self, actions: Sequence):
         from .integrate import constant_step_plan
 
-        eqs = []
+        if len(actions) != self.num_envs:
+            raise ValueError(f"{len(actions)} actions for {self.num_envs} environments")
+        eqs, controls = [], []
         for b, action in enumerate(actions):
             offset = action if not self._action_to_direction else self._action_to_direction[action]
             old = self._control_value[b]
             self._control_value[b] = self.update_control_value(offset, old)
-            eqs.append(self._equation_for(self.update_control_parameter(old, self._control_value[b])))
+            controls.append(self.update_control_parameter(old, self._control_value[b]))
+            eqs.append(self._equation_for(controls[-1]))
+        self._check_controls(eqs[0], controls)
         eq0 = self._configure(eqs)
-        eq0._engine_upload(self._engine, 0.0)
+        type(eq0)._engine_upload_batch(self._engine, eqs, 0.0, self.step_dt)
         solver = self.solver_type(**prepare_solver_params(self.solver_type, self.solver_parameters, eq0))
         solver.configure_engine(self._engine, eq0)
         n_full, rem = constant_step_plan(0.0, self.step_dt, self.numeric_dt)

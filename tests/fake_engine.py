@@ -16,30 +16,67 @@ class OracleEngine:
         self.calls = []
 
     # -- configuration ------------------------------------------------------------------------
-    def configure(self, equation, dtype, nx, ny, batch, hx, hy, kappa=0.0, mu=None, mob=None, gpe_k=0.0, derivs=0, fe=None):
+    def configure(self, equation, dtype, nx, ny, batch, hx, hy, kappa=0.0, mu=None, mob=None, gpe_k=0.0, derivs=0, fe=None,
+                  nz=0, hz=0.0):
+        same = self.problem is not None and (self.eq, self.dtype, self.batch, self.state_shape[:2]) == (
+            equation, np.dtype(dtype), batch, (nx, ny))
         self.eq, self.dtype, self.batch = equation, np.dtype(dtype), batch
         self.hx, self.hy, self.kappa, self.mu, self.mob = hx, hy, kappa, mu, mob
         self.problem = object()
-        self.state_shape = (nx, ny)
-        self.y = np.zeros((batch, nx, ny), self.dtype)
-        self.imex_A, self.symbol = 0.5, None
-        self.fe, self.sbm, self.time_fn = fe, {}, None
+        self.state_shape = (nx, ny) + ((2,) if equation == L.EQ_GPE else ())
+        if not same:  # a same-shape configure keeps the resident state and the aux fields, like the library
+            self.y = np.zeros((batch,) + self.state_shape, self.dtype)
+            self.aux, self.aux_fn = {}, {}
+            self.imex_A, self.symbol = 0.5, None
+            self.sbm, self.time_fn = {}, None
+        self.fe = fe
+        self.kappa_env = np.full(batch, float(kappa))
+        self.gpe_k_env = np.full(batch, float(gpe_k))
+        self.time_scale, self.strang_dx = 1.0, 1.0
 
     def set_aux(self, which, field, per_env=False):
+        self.aux[which] = (np.asarray(field), bool(per_env))
+        self.aux_fn.pop(which, None)  # a static upload replaces a time-dependent source
         if which == L.AUX_IMEX_SYMBOL:
             self.symbol = np.asarray(field)
         if which in (L.AUX_SBM_PSI, L.AUX_SBM_NORM_GRAD, L.AUX_SBM_MASK):
             self.sbm[which] = np.asarray(field)
 
+    def set_aux_time_fn(self, which, fn, per_env=False):
+        if fn is None:
+            self.aux_fn.pop(which, None)
+        else:
+            self.aux_fn[which] = (fn, bool(per_env))
+            self.calls.append(("aux_time_fn", which, bool(per_env)))
+
+    def _aux_at(self, which, t, b):
+        """aux field `which` of environment b at local time t (the library refreshes per substep / stage)"""
+        if which in self.aux_fn:
+            fn, per_env = self.aux_fn[which]
+            self.calls.append(("aux_eval", which, t))
+            a = np.asarray(fn(t))
+        else:
+            a, per_env = self.aux[which]
+        return a[b] if per_env else a
+
+    def set_env_gpe_k(self, env_first, k):
+        k = np.atleast_1d(np.asarray(k, dtype=float))
+        self.gpe_k_env[env_first:env_first + len(k)] = k
+
+    def set_env_params(self, env_first, kappa=None, mu_coef=None, mob_coef=None):
+        if kappa is not None:
+            kappa = np.atleast_1d(np.asarray(kappa, dtype=float))
+            self.kappa_env[env_first:env_first + len(kappa)] = kappa
+
     def set_time_terms(self, fn=None, constant=(0.0, 0.0, 0.0)):
         self.time_fn = fn if fn is not None else (lambda t: constant)
 
     def set_integrator_params(self, imex_A=0.5, time_scale=1.0, strang_dx=1.0):
-        self.imex_A = imex_A
+        self.imex_A, self.time_scale, self.strang_dx = imex_A, time_scale, strang_dx
 
     def set_state(self, state, env_first=0):
         a = np.asarray(state, dtype=self.dtype)
-        a = a[None] if a.ndim == 2 else a
+        a = a[None] if a.ndim == len(self.state_shape) else a
         self.y[env_first:env_first + a.shape[0]] = a
 
     def get_state(self, env_first=0, env_count=None):
@@ -47,7 +84,10 @@ class OracleEngine:
         return self.y[env_first:env_first + n].copy()
 
     # -- compute --------------------------------------------------------------------------------
-    def _f(self, t, u):
+    def _f(self, t, u, b=0):
+        if self.eq == L.EQ_ADVECTION_DIFFUSION:
+            return O.ad_rhs_fd(u, self.hx, self.hy, self._aux_at(L.AUX_VX_FACE, t, b), self._aux_at(L.AUX_VY_FACE, t, b),
+                               self.kappa_env[b])
         if self.eq in (L.EQ_ALLEN_CAHN_SBM, L.EQ_CAHN_HILLIARD_SBM):
             # the ABI's decomposition (include/pdeopt_hip.h, pdeopt_time_fn): scalars from the
             # callback, spatial fields from the aux uploads
@@ -61,23 +101,34 @@ class OracleEngine:
             Fy = O.avg_face(psi, 1) * O.avg_face(Du, 1) * O.grad_face(inner, self.hy, 1)
             return (O.div_face(Fx, self.hx, 0) + O.div_face(Fy, self.hy, 1)) / psi + ngp * fl
         fn = O.ch_rhs_fd if self.eq == L.EQ_CAHN_HILLIARD else O.ac_rhs_fd
-        return fn(u, self.hx, self.hy, self.kappa, self.mu, self.mob)
+        return fn(u, self.hx, self.hy, self.kappa_env[b], self.mu, self.mob)
 
     def advance(self, integrator, dt, n, t0=0.0):
         self.calls.append(("advance", integrator, dt, n, t0))
         for b in range(self.batch):
             u = self.y[b]
+            f = lambda t, v, b=b: self._f(t, v, b)
             for i in range(int(n)):
                 t = t0 + i * dt
                 if integrator == L.INT_EULER:
-                    u = O.euler_step(self._f, t, u, dt)
+                    u = O.euler_step(f, t, u, dt)
                 elif integrator == L.INT_RK4:
-                    u = O.rk4_step(self._f, t, u, dt)
+                    u = O.rk4_step(f, t, u, dt)
                 elif integrator == L.INT_IMEX:
-                    u = O.imex_step(self._f, t, u, dt, self.imex_A, self.symbol)
+                    u = O.imex_step(f, t, u, dt, self.imex_A, self.symbol)
+                elif integrator == L.INT_STRANG:
+                    # b = -i (V(t0) + k |psi0|^2): the ABI's decomposition of gross_pitaevskii.py:67-75
+                    def bterm(tt, yy, b=b):
+                        w = self._aux_at(L.AUX_GPE_POTENTIAL, tt, b) + self.gpe_k_env[b] * (yy[..., 0] ** 2 + yy[..., 1] ** 2)
+                        return np.stack([np.zeros_like(w), -w], axis=-1)
+
+                    u = O.strang_step(bterm, t, u, dt, self.aux[L.AUX_GPE_A_TERM][0], self.strang_dx, self.time_scale)
                 else:
                     raise ValueError(integrator)
             self.y[b] = u
+
+    def close(self):
+        pass
 
     def snapshot(self):
         self.snap = self.y.copy()
@@ -90,7 +141,7 @@ class OracleEngine:
     def tsit5_trial(self, t, dt, rtol, atol):
         self.pending, errs = [], []
         for b in range(self.batch):
-            y1, err, _ = O.tsit5_step(self._f, t, self.y[b], dt)
+            y1, err, _ = O.tsit5_step(lambda tt, v, b=b: self._f(tt, v, b), t, self.y[b], dt)
             sc = atol + rtol * np.maximum(np.abs(self.y[b]), np.abs(y1))
             errs.append(np.sqrt(np.mean((err / sc) ** 2)))
             self.pending.append(y1)

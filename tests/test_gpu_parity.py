@@ -605,44 +605,6 @@ def test_ragged_tiles_match_generic_and_oracle(engine, dtype, shape):
             assert rel_l2(inc, inc_ref) < 2e-2, (shape, cls.__name__)
 
 
-@pytest.mark.parametrize("dtype", [np.float32, np.float64])
-@pytest.mark.parametrize("shape,batch", [((256, 256), 3), ((100, 100), 2), ((48, 40), 5), ((512, 384), 2), ((16, 128), 9)])
-@pytest.mark.parametrize("closures", ["regsol", "cubic"])
-def test_pipelined_pair_equals_classic(dtype, shape, batch, closures):
-    """The persistent, LDS-DMA pipelined stage-pair kernel (csrc/stencil_fused_pipe.hpp) and the wave-local
-    one (csrc/stencil_fused_wave.hpp) against the
-    one-tile-per-workgroup kernel: same arithmetic up to the compiler's FMA contraction choices (a few
-    cells differ by 1 ulp) -- divisible and ragged grids, runs that cross environment boundaries,
-    per-environment parameters."""
-    rng = np.random.default_rng(17)
-    nx, ny = shape
-    dom = std_domain(P, nx, ny)
-    if closures == "regsol":
-        eq = P.CahnHilliard2DPeriodic(dom, 0.002, MU["regsol"], MOB["c1mc"])
-        u = white_noise_state(rng, (batch, nx, ny), dtype, "c")
-    else:
-        eq = P.CahnHilliard2DPeriodic(dom, 0.002, MU["cubic"], MOB["one_plus_sq"])
-        u = white_noise_state(rng, (batch, nx, ny), dtype, "sym")
-    outs = {}
-    for mode in (1, 2, 3):
-        eng = P.HipEngine()
-        eng.set_fuse_stages(mode)
-        eng.set_tile_rows(16)  # the persistent / wave-local variants are 16-row kernels
-        eng.configure(dtype=dtype, batch=batch, **eq._engine_problem())
-        eng.set_env_params(0, kappa=0.002 * (1.0 + 0.1 * np.arange(batch)))
-        eng.set_state(u)
-        eng.advance(L.INT_RK4, 2e-7 if closures == "regsol" else 4e-8, 6)
-        outs[mode] = eng.get_state()
-        assert ("+pipe" in eng.last_kernel) == (mode == 2), eng.last_kernel
-        assert ("+wave" in eng.last_kernel) == (mode == 3), eng.last_kernel
-        eng.close()
-    assert np.isfinite(outs[1]).all()
-    eps = np.finfo(dtype).eps
-    for mode in (2, 3):
-        np.testing.assert_allclose(outs[mode], outs[1], rtol=0, atol=8 * eps)
-        assert np.mean(outs[mode] != outs[1]) < 0.5
-
-
 def test_linear_logit_class_matches_the_cubic_one():
     """CL_LOGIT1 (csrc/closures.hpp): the regular-solution closure written with 2 coefficients runs the
     shorter in-kernel form (linear polynomial part, kappa and 1/h^2 folded into the Laplacian weights: the

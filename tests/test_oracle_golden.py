@@ -233,3 +233,31 @@ def test_ch3d_rhs_matches_reference_goldens(golden):
         hx, hy, hz = _dx3(tag)
         got = O.ch3d_rhs_fd(z[tag + "/u"], hx, hy, hz, 0.002, MU["regsol"], MOB["c1mc"])
         np.testing.assert_array_equal(got, z[tag + "/rhs"], err_msg=tag)
+
+
+def test_advection_diffusion_manufactured_solution_slope():
+    """advection-diffusion is absent from the reference package, so its pin is a
+    sympy manufactured solution in the style of tests/test_rhs_convergence.py:14-77: second-order slope
+    (2.0 +- 10 %) of the oracle's conservative flux form against the exact -div(v u) + D lap u."""
+    import sympy as sp
+    from sympy.utilities.lambdify import lambdify
+
+    x, y, t = sp.symbols("x y t", real=True)
+    u = sp.sin(2 * x) * sp.cos(3 * y) * sp.exp(-0.7 * t)
+    vx = sp.Rational(3, 5) + sp.Rational(3, 10) * sp.sin(x) * sp.cos(2 * y) * (1 + t)
+    vy = -sp.Rational(2, 5) + sp.Rational(1, 5) * sp.cos(3 * x) * sp.sin(y)
+    Dc = 0.05
+    exact = -(sp.diff(vx * u, x) + sp.diff(vy * u, y)) + Dc * (sp.diff(u, x, 2) + sp.diff(u, y, 2))
+    u_fn, ex_fn = lambdify((x, y, t), u, "numpy"), lambdify((x, y, t), exact, "numpy")
+    vx_fn, vy_fn = lambdify((x, y, t), vx, "numpy"), lambdify((x, y, t), vy, "numpy")
+    hs, errs = [], []
+    for n in (32, 64, 128, 256):
+        h = 2 * np.pi / n
+        ax = np.linspace(-np.pi + h / 2, np.pi - h / 2, n)
+        X, Y = np.meshgrid(ax, ax, indexing="ij")
+        got = O.ad_rhs_fd(u_fn(X, Y, 0.3), h, h, vx_fn(X + h / 2, Y, 0.3), vy_fn(X, Y + h / 2, 0.3) + 0 * X, Dc)
+        ex = ex_fn(X, Y, 0.3)
+        errs.append(np.sqrt(np.sum((got - ex) ** 2)) / np.sqrt(np.sum(ex**2)))
+        hs.append(h)
+    slope = np.polyfit(np.log(hs), np.log(errs), 1)[0]
+    np.testing.assert_allclose(slope, 2.0, rtol=0.1)

@@ -60,3 +60,8 @@ def sbm_domain(P, psi):
     nx, ny = psi.shape
     return P.Domain((nx, ny), ((0.0, float(nx)), (0.0, float(ny))), "dimensionless",
                     geometry=types.SimpleNamespace(smooth=psi))
+
+
+# lights(t, x, y) of the round-2 goldens (oracle/gen_golden.py MOVING_SPOT): a Gaussian spot that moves and
+# brightens during the solve
+MOVING_SPOT = lambda t, x, y: 30.0 * (1.0 + 100.0 * t) * np.exp(-((x + 2.0 - 800.0 * t) ** 2 + (y - 1.0) ** 2) / 4.5)  # noqa: E731

@@ -9,9 +9,10 @@ ROOT=$(cd $(dirname $0)/.. && pwd)
 mkdir -p $ROOT/variants
 C=$ROOT/pde_opt_amd/csrc
 hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-gpu-rdc -fno-slp-vectorize -Wno-unused-function -I/opt/rocm/include "$@" -c $C/$SRC.hip -o $ROOT/variants/${SRC}_$NAME.o
+TAG=$(cd $ROOT && python -c "from pde_opt_amd.csrc.build import _flags_tag; print(_flags_tag([]))")
 OBJS=""
 for o in api stencil reduce spectral halo strang_fused; do
-  if [ $o = $SRC ]; then OBJS="$OBJS $ROOT/variants/${SRC}_$NAME.o"; else OBJS="$OBJS $C/build/$o.o"; fi
+  if [ $o = $SRC ]; then OBJS="$OBJS $ROOT/variants/${SRC}_$NAME.o"; else OBJS="$OBJS $C/build/$o.$TAG.o"; fi
 done
 hipcc -shared -fPIC --offload-arch=gfx950 -fno-gpu-rdc -o $ROOT/variants/lib_$NAME.so $OBJS -L/opt/rocm/lib -lrocfft -Wl,-rpath,/opt/rocm/lib
 rm $ROOT/variants/${SRC}_$NAME.o
