@@ -17,11 +17,18 @@ Timing: barrier + device sync on both sides, max over ranks.  The roofline figur
 with HIP events recorded on the engine's own stream (pdeopt_timer_start/stop) and the number of
 kernel launches counted by the library (pdeopt_get_counter).
 
-roofline.achieved uses the ALGORITHMIC bytes of SURVEY 8(d) (RK4, one fused kernel per stage:
-16 words/cell/substep = 64 B fp32).  The shipped kernels fuse stage PAIRS (7 words/cell/substep of
-real traffic, profiles/) and keep environment groups resident in the 256 MiB Infinity Cache, so
-achieved/peak can exceed 1: that is removed traffic, not a measurement error -- `traffic` is the
-measured HBM bytes per launch (rocprofv3 PMC, profiles/traffic.json).
+The `roofline` object says what binds the dominant kernel (roofline_block below).  SURVEY 8(d)'s ALGORITHMIC
+byte count (RK4 with one fused kernel per stage: 16 words/cell/substep = 64 B fp32) over the HIP-event launch time
+is always reported (`algorithmic_gbs`); the shipped kernels fuse stage PAIRS (7 words/cell/substep of real
+traffic) and keep environment groups resident in the 256 MiB Infinity Cache, so that figure exceeds the HBM peak
+-- removed traffic, not a measurement error -- and the headline kernel is bound by VALU issue instead:
+`bound = "valu"`, achieved / peak in wave64 VALU instructions per second (SQ_INSTS_VALU per launch from the
+committed PMC profile of this command, profiles/pmc_r02.json, over the live launch time; peak = the scalar-fp32
+issue rate measured by tools/valubench.hip, profiles/r02_valubench.txt), `traffic` = measured L2 fabric-side bytes.
+
+After the timed region the line proves its own result (`parity_spot_*`: the same library call on fresh inputs,
+first / last environment of every group against the CPU oracle) and adds `api_value`: env-steps/s through
+VectorPDEEnv.step with the reward and uint8 observations formed on the GPU.
 
 Other workloads (--workload) are secondary rows for DESIGN.md, not the bench line.
 """
@@ -55,6 +62,10 @@ WORKLOADS = {
     "ac_rk4_512_f32": dict(eq="ac", n=512, dtype=np.float32, integ="rk4", dt=5e-5, substeps=100, batch=64),
     "ch_imex_1024_f32": dict(eq="ch", n=1024, dtype=np.float32, integ="imex", dt=1e-6, substeps=100, batch=32),
     "gpe_strang_512_c64": dict(eq="gpe", n=512, dtype=np.float32, integ="strang", dt=1e-3, substeps=100, batch=128),
+    # the same with a time-dependent control: every environment's lights(t, x, y) is a moving Gaussian spot
+    # evaluated in-kernel at each substep's t0 (pdeopt_set_gpe_spots)
+    "gpe_strang_512_c64_spots": dict(eq="gpe", n=512, dtype=np.float32, integ="strang", dt=1e-3, substeps=100, batch=128,
+                                     spots=True),
 }
 
 REGSOL = lambda c: np.log(c / (1 - c)) + 3 * (1 - 2 * c)  # noqa: E731
@@ -66,7 +77,8 @@ def make_problem(P, name, batch, rank):
     n, dtype = w["n"], w["dtype"]
     if w["eq"] == "gpe":
         dom = P.Domain((n, n), ((-12.0, 12.0), (-12.0, 12.0)), "dimensionless")
-        eq = P.GPE2DTSControl(dom, 1000.0, 0.0, lambda t, x, y: 0.0, trap_factor=1.0, kinetic=True)
+        lights = P.GaussianSpots.moving(20.0, (-3.0, 0.0), (3.0, 1.0), 0.1, 1.5) if w.get("spots") else (lambda t, x, y: 0.0)
+        eq = P.GPE2DTSControl(dom, 1000.0, 0.0, lights, trap_factor=1.0, kinetic=True)
         X, Y = dom.mesh()
         y0 = np.empty((batch, n, n, 2), dtype=dtype)
         for b in range(batch):  # normalised Gaussians, width L/6, a little different per environment
@@ -93,6 +105,116 @@ def make_problem(P, name, batch, rank):
         eq = P.AllenCahn2DPeriodic(dom, 0.002, lambda c: c**3 - c, lambda c: np.ones_like(c))
     solver = P.SemiImplicitFourierSpectral(0.5, eq.fourier_symbol, eq.fft, eq.ifft) if w["integ"] == "imex" else P.RK4()
     return eq, y0, solver
+
+
+PMC_FILE = os.path.join(ROOT, "profiles", "pmc_r02.json")  # per-launch PMC averages (tools/pmc_to_json.py)
+N_SIMD, SHADER_HZ = 1024, 2.4e9  # 256 CUs x 4 SIMDs; MI355X_MICROARCH.md chip table
+# issue cost of one scalar-fp32 wave64 VALU instruction per SIMD, measured with >= 4 waves resident
+# (tools/valubench.hip -> profiles/r02_valubench.txt: v_fma_f32 3.5 clk, v_add_f32 4.1, v_pk_fma_f32 5.7 for two
+# FMAs, v_log_f32 / v_rcp_f32 8.5; costs of a mix add up).  The 157.3 TF vector peak (= 2 clk) is the PACKED rate.
+VALU_CLK_MEASURED = 3.5
+
+
+def roofline_block(workload, kernel_name, bytes_per_launch, words, avg_launch_s, launches):
+    """HBM roofline by SURVEY 8(d)'s algorithmic bytes and, where a PMC profile of this workload is committed, the
+    VALU-issue roofline of the same kernel; `bound` names the larger fraction (what binds the kernel)."""
+    alg_gbs = bytes_per_launch / avg_launch_s / 1e9
+    r = {
+        "bound": "hbm",
+        "kernel": kernel_name + " (average over the launches of a substep)",
+        "achieved": alg_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg_gbs / HBM_PEAK_GBS,
+        "traffic": None,
+        "algorithmic_gbs": alg_gbs,
+        "algorithmic_frac_of_hbm_peak": alg_gbs / HBM_PEAK_GBS,
+        "algorithmic_bytes_per_launch": bytes_per_launch,
+        "algorithmic_words_per_cell_substep": words,
+        "avg_launch_us": avg_launch_s * 1e6,
+        "launches_timed": launches,
+    }
+    try:
+        pmc = json.load(open(PMC_FILE)).get(workload)
+    except Exception:
+        pmc = None
+    if not pmc:
+        r["note"] = "achieved = SURVEY 8(d) algorithmic bytes / HIP-event time of the average launch; no PMC profile of this workload is committed"
+        return r
+    c = pmc["counters_per_launch"]
+    if pmc.get("hbm_bytes_per_launch"):
+        r["traffic"] = pmc["hbm_bytes_per_launch"]
+        r["traffic_gbs"] = r["traffic"] / avg_launch_s / 1e9
+        r["traffic_frac"] = r["traffic_gbs"] / HBM_PEAK_GBS
+    if c.get("SQ_INSTS_VALU"):
+        per_simd = c["SQ_INSTS_VALU"] / N_SIMD
+        cycles = avg_launch_s * SHADER_HZ
+        r["valu_insts_per_launch"] = c["SQ_INSTS_VALU"]
+        r["frac_valu_measured_issue"] = per_simd * VALU_CLK_MEASURED / cycles
+        r["frac_valu_4clk"] = per_simd * 4.0 / cycles
+        r["frac_valu_spec"] = per_simd * 2.0 / cycles  # 157.3 TF denominator: the packed-fp32 rate
+        if c.get("SQ_ACTIVE_INST_VALU") and c.get("GRBM_GUI_ACTIVE"):
+            # quad-cycles summed over SIMDs vs the launch's cycles under the profiler (sum over 8 XCDs)
+            r["valu_busy_frac_pmc"] = 4.0 * c["SQ_ACTIVE_INST_VALU"] / N_SIMD / (c["GRBM_GUI_ACTIVE"] / 8.0)
+        if r["frac_valu_measured_issue"] > (r.get("traffic_frac") or 0.0):
+            r["bound"] = "valu"
+            r["unit"] = "Ginst/s"
+            r["achieved"] = c["SQ_INSTS_VALU"] / avg_launch_s / 1e9
+            r["peak"] = N_SIMD * SHADER_HZ / VALU_CLK_MEASURED / 1e9
+            r["frac"] = r["achieved"] / r["peak"]
+    r["pmc_source"] = os.path.relpath(PMC_FILE, ROOT) + ": " + pmc.get("source", "")
+    r["note"] = ("bound = what binds the kernel.  valu: achieved = wave64 VALU instructions issued per second (SQ_INSTS_VALU per "
+                 "launch, PMC profile of this command / live HIP-event launch time), peak = 1024 SIMDs x 2.4 GHz / 3.5 clk, the "
+                 "measured scalar-fp32 issue rate (profiles/r02_valubench.txt; transcendentals cost 8.5 clk, so the true issue "
+                 "share is higher: valu_busy_frac_pmc).  algorithmic_gbs is SURVEY 8(d)'s byte count over the same time: it may "
+                 "exceed the HBM peak because stage-pair fusion and cache-resident environment groups remove traffic; "
+                 "traffic = measured L2 fabric-side bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, Infinity-Cache hits included).")
+    return r
+
+
+def api_throughput(P, name, rank, steps, warmup):
+    """env-steps/s through the Python API the RL loop calls: VectorPDEEnv.step (per-environment control update,
+    equation rebuild, one pdeopt_advance) with the reward reduced and the uint8 observation frames quantised on
+    the GPU -- the same workload, timed on the wall clock after the raw measurement."""
+    w = WORKLOADS[name]
+    if w["eq"] not in ("ch", "ac") or w["integ"] not in ("rk4", "imex"):
+        return None
+    n, batch = w["n"], w["batch"]
+    L_ = 0.01 * n
+    dom = P.Domain((n, n), ((-L_ / 2, L_ / 2), (-L_ / 2, L_ / 2)), "dimensionless")
+
+    def reset(domain, seed=0):
+        rng = np.random.default_rng(seed)
+        if w["eq"] == "ch":
+            return np.clip(0.5 + 0.01 * rng.standard_normal((n, n)), 0.05, 0.95).astype(w["dtype"])
+        return (0.01 * rng.standard_normal((n, n))).astype(w["dtype"])
+
+    if w["eq"] == "ch":
+        cubic = w.get("closures") == "cubic"
+        eq_t, static = P.CahnHilliard2DPeriodic, {"mu": (lambda c: c**3 - c) if cubic else REGSOL,
+                                                   "D": (lambda c: 1 + c**2) if cubic else C1MC}
+    else:
+        eq_t, static = P.AllenCahn2DPeriodic, {"mu": lambda c: c**3 - c, "R": lambda c: np.ones_like(c)}
+    imex = w["integ"] == "imex"
+    env = P.VectorPDEEnv(
+        batch, eq_t, dom, P.SemiImplicitFourierSpectral if imex else P.RK4, end_time=1e9,
+        step_dt=w["dt"] * w["substeps"], numeric_dt=w["dt"], state_to_observation_func=lambda s_: s_,
+        reward_function=lambda s_: 0.0, reset_func=reset, reset_control_value=0.002,
+        update_control_value=lambda off, old: old + off, update_control_parameter=lambda old, new: new,
+        action_space_config={"type": "discrete", "num_actions": 3, "action_mapping": {0: -1e-5, 1: 0.0, 2: 1e-5}},
+        static_equation_parameters=static, control_equation_parameter_name="kappa",
+        solver_parameters={"A": 0.5} if imex else {}, device=int(os.environ.get("LOCAL_RANK", "0")),
+        device_reward="var", device_observation=(0.0, 1.0))
+    env.reset(seed=rank * batch)
+    actions = [1] * batch if imex else [(b % 3) for b in range(batch)]  # IMEX shares one implicit operator
+    for _ in range(warmup):
+        env.step(actions)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        obs, rew, *_ = env.step(actions)
+    el = time.perf_counter() - t0
+    ok = bool(np.isfinite(rew).all()) and obs.dtype == np.uint8 and obs.shape == (batch, 1, n, n)
+    env.close()
+    return {"api_value": batch * steps / el, "api_ms_per_step": 1e3 * el / steps, "api_ok": ok,
+            "api": "VectorPDEEnv.step, per-environment kappa control, device variance reward + uint8 frames "
+                   f"(1 byte/cell D2H), {steps} steps after {warmup} warm-up, one GPU"}
 
 
 def usable_cores():
@@ -149,7 +271,7 @@ def parity_spot(name, eng, eq, solver, y0, threads):
                 ref = O.imex_step(rhs, i * dt, ref, dt, 0.5, sym)
         else:
             X, Y = eq.domain.mesh()
-            bt = lambda t, yy: O.gpe_b_terms(yy, X, Y, 1000.0, 0.0, 1.0, 0.0)
+            bt = lambda t, yy: O.gpe_b_terms(yy, X, Y, 1000.0, 0.0, 1.0, eq.lights(t, X, Y))
             ref = y0[b].astype(np.float64)
             for i in range(nsub):
                 ref = O.strang_step(bt, i * dt, ref, dt, eq.A_term, eq.dx, 1.0)
@@ -235,6 +357,7 @@ def main():
     ap.add_argument("--ablate", type=int, default=0, help="TIMING ONLY (wrong results): kernel phase ablation bits")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity-spot", action="store_true")
+    ap.add_argument("--no-api", action="store_true", help="skip the VectorPDEEnv.step throughput leg")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
 
@@ -279,7 +402,7 @@ def main():
     if args.ablate:
         eng._check(eng._lib.pdeopt_set_option(eng._h, L.OPT_DEBUG_ABLATE, args.ablate))
     eng.configure(dtype=y0.dtype, batch=batch, **eq._engine_problem())
-    eq._engine_upload(eng, 0.0)
+    eq._engine_upload(eng, 0.0, dt * substeps)
     solver.configure_engine(eng, eq)
     eng.set_state(y0)  # inputs resident in HBM before the timed region
 
@@ -329,13 +452,6 @@ def main():
         bytes_per_launch = total_bytes / launches
         avg_launch_s = (dev_ms * 1e-3) / launches
         achieved = bytes_per_launch / avg_launch_s / 1e9
-        traffic = None
-        tfile = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tfile):
-            try:
-                traffic = json.load(open(tfile)).get(args.workload, {}).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
         line = {
             "metric": METRIC if args.workload == "ch_rk4_1024_f32" else
                       f"env-steps/sec ({args.workload}, {substeps} substeps/env-step) & achieved HBM GB/s",
@@ -365,24 +481,10 @@ def main():
             "achieved_gbs_whole_job": args.gpus * total_bytes / elapsed / 1e9,
             "nonfinite_cells": bad,
             **(spot or {}),
-            "roofline": {
-                "bound": "hbm",
-                "kernel": kernel_name + " (average over the launches of a substep)",
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic,
-                "algorithmic_bytes_per_launch": bytes_per_launch,
-                "algorithmic_words_per_cell_substep": WORDS[w["integ"]],
-                "avg_launch_us": avg_launch_s * 1e6,
-                "launches_timed": launches,
-                "note": "achieved = SURVEY 8(d) algorithmic bytes / HIP-event time; stage-pair fusion and "
-                        "Infinity-Cache-resident environment groups remove HBM traffic, so frac may exceed 1. "
-                        "After fusion the RK4 pair kernel is VALU-issue-bound (SQ_ACTIVE_INST_VALU: 72-80 % of the "
-                        "launch per SIMD, profiles/r01_v11_pmc_busy.txt), not HBM-bound; `traffic` is what it really moves",
-            },
+            "roofline": roofline_block(args.workload, kernel_name, bytes_per_launch, WORDS[w["integ"]], avg_launch_s, launches),
         }
+        if args.gpus == 1 and not args.no_api and not args.ablate:
+            line.update(api_throughput(P, args.workload, rank, args.steps, args.warmup) or {})
         if args.gpus == 1 and not args.no_cpu_baseline:
             cb = cpu_baseline(args.workload, args.cpu_seconds)
             if cb is not None:

@@ -199,6 +199,23 @@ int pdeopt_set_aux(pdeopt_ctx* ctx, int which, const void* host, int per_env);
  * fn = NULL removes the source (the field keeps its last contents). */
 typedef int (*pdeopt_aux_fn)(double t, int which, void* host_out, void* user);
 int pdeopt_set_aux_time_fn(pdeopt_ctx* ctx, int which, pdeopt_aux_fn fn, void* user, int per_env);
+/* The GPE control field lights(t, X, Y) (gross_pitaevskii.py:43,61,72) as a sum of Gaussian spots that the
+ * Strang kernels evaluate themselves at every substep's t0 -- the stirring-beam controls of the RL environments
+ * without a host round trip per substep:
+ *     lights(t, x, y) = sum_s (amp0 + amp_rate t) exp(-((x - x0 - x_rate t)^2 + (y - y0 - y_rate t)^2) inv_two_w2)
+ * added to the GPE_POTENTIAL aux field (which then holds the time-independent part: the trap).  spots is
+ * [env_count][n_spots]; every environment of a batch carries its own spots (n_spots is one number per ctx,
+ * 0 .. PDEOPT_MAX_SPOTS; 0 removes them).  x_first / y_first: coordinates of cell (0, 0) (Domain.axes()[d][0],
+ * domains.py:36-40); the spacing is the problem's hx, hy. */
+#define PDEOPT_MAX_SPOTS 4
+typedef struct {
+  double amp0, amp_rate;
+  double x0, x_rate;
+  double y0, y_rate;
+  double inv_two_w2; /* 1 / (2 width^2) */
+} pdeopt_light_spot;
+int pdeopt_set_gpe_spots(pdeopt_ctx* ctx, int env_first, int env_count, int n_spots, const pdeopt_light_spot* spots,
+                         double x_first, double y_first);
 
 /* ---- state  == PDEEnv._state (pde_env.py:232,305) ---------------------------------------- */
 int pdeopt_set_state(pdeopt_ctx* ctx, int env_first, int env_count, const void* host);

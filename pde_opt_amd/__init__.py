@@ -24,6 +24,8 @@ from .numerics.equations import (
 from .numerics.functions import (
     ChemicalPotentialLegendrePolynomials,
     DiffusionLegendrePolynomials,
+    GaussianSpot,
+    GaussianSpots,
     LegendrePolynomialExpansion,
 )
 from .numerics.solvers import (
@@ -44,6 +46,7 @@ __all__ = [
     "BaseEquation", "AllenCahn2DPeriodic", "CahnHilliard2DPeriodic", "AdvectionDiffusion2D", "GPE2DTSControl",
     "AllenCahn2DSmoothedBoundary", "CahnHilliard2DSmoothedBoundary", "CahnHilliard3DPeriodic",
     "Domain", "LegendrePolynomialExpansion", "DiffusionLegendrePolynomials", "ChemicalPotentialLegendrePolynomials",
+    "GaussianSpot", "GaussianSpots",
     "SemiImplicitFourierSpectral", "StrangSplitting", "Euler", "RK4", "Tsit5",
     "ConstantStepSize", "PIDController", "SaveAt",
     "ClosureDesc", "as_closure", "polynomial", "UnsupportedClosureError", "HipUnavailableError", "PdeoptError",

@@ -65,6 +65,13 @@ class Closure(C.Structure):
     ]
 
 
+MAX_SPOTS = 4
+
+
+class LightSpot(C.Structure):  # pdeopt_light_spot
+    _fields_ = [(n, C.c_double) for n in ("amp0", "amp_rate", "x0", "x_rate", "y0", "y_rate", "inv_two_w2")]
+
+
 class Problem(C.Structure):
     _fields_ = [
         ("equation", C.c_int32),
@@ -104,6 +111,7 @@ _SIGNATURES = {
     "pdeopt_set_aux": (C.c_int, [_VP, C.c_int, _VP, C.c_int]),
     "pdeopt_set_aux_time_fn": (C.c_int, [_VP, C.c_int, AUX_FN, _VP, C.c_int]),
     "pdeopt_set_env_gpe_k": (C.c_int, [_VP, C.c_int, C.c_int, _VP]),
+    "pdeopt_set_gpe_spots": (C.c_int, [_VP, C.c_int, C.c_int, C.c_int, _VP, C.c_double, C.c_double]),
     "pdeopt_set_state": (C.c_int, [_VP, C.c_int, C.c_int, _VP]),
     "pdeopt_get_state": (C.c_int, [_VP, C.c_int, C.c_int, _VP]),
     "pdeopt_state_device_ptr": (C.c_int, [_VP, C.POINTER(_VP), C.POINTER(C.c_int64)]),

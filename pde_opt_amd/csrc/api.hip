@@ -36,7 +36,10 @@ int ensure_buffer(pdeopt_ctx* ctx, void** p, size_t bytes) {
 namespace {
 
 void free_fields(pdeopt_ctx* ctx) {
-  void** bufs[] = {&ctx->Y, &ctx->TA, &ctx->TB, &ctx->ACC, &ctx->SNAP, &ctx->KS, &ctx->obs_dev, &ctx->vort_dev, &ctx->env_params_dev};
+  void** bufs[] = {&ctx->Y, &ctx->TA, &ctx->TB, &ctx->ACC, &ctx->SNAP, &ctx->KS, &ctx->obs_dev, &ctx->vort_dev, &ctx->env_params_dev,
+                   &ctx->spots_dev};
+  ctx->n_spots = 0;
+  ctx->spots_host.clear();
   ctx->vort_cap = 0;
   for (void** b : bufs) {
     if (*b) (void)hipFree(*b);
@@ -393,6 +396,49 @@ int pdeopt_set_aux_time_fn(pdeopt_ctx* ctx, int which, pdeopt_aux_fn fn, void* u
   a.loaded = false;
   ctx->tsit5_fsal_valid = false;
   graph_destroy(ctx);
+  return PDEOPT_OK;
+}
+
+int pdeopt_set_gpe_spots(pdeopt_ctx* ctx, int env_first, int env_count, int n_spots, const pdeopt_light_spot* spots,
+                         double x_first, double y_first) {
+  if (!ctx) return PDEOPT_EINVAL;
+  int rc = check_envs(ctx, env_first, env_count);
+  if (rc) return rc;
+  if (ctx->prob.equation != PDEOPT_EQ_GPE) return fail(ctx, PDEOPT_EINVAL, "light spots belong to the GPE");
+  if (n_spots < 0 || n_spots > PDEOPT_MAX_SPOTS)
+    return fail(ctx, PDEOPT_EINVAL, "n_spots = %d outside 0..%d", n_spots, PDEOPT_MAX_SPOTS);
+  if (n_spots > 0 && !spots) return PDEOPT_EINVAL;
+  PDEOPT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  const int batch = ctx->prob.batch;
+  if (n_spots != ctx->n_spots && !(env_first == 0 && env_count == batch))
+    return fail(ctx, PDEOPT_EINVAL, "changing the number of spots (%d -> %d) needs the whole batch in one call",
+                ctx->n_spots, n_spots);
+  ctx->n_spots = n_spots;
+  ctx->spots_x_first = x_first;
+  ctx->spots_y_first = y_first;
+  if (n_spots == 0) return PDEOPT_OK;
+  ctx->spots_host.resize((size_t)batch * PDEOPT_MAX_SPOTS, pdeopt_light_spot{});
+  for (int e = 0; e < env_count; ++e)
+    for (int s = 0; s < PDEOPT_MAX_SPOTS; ++s)
+      ctx->spots_host[(size_t)(env_first + e) * PDEOPT_MAX_SPOTS + s] =
+          s < n_spots ? spots[(size_t)e * n_spots + s] : pdeopt_light_spot{};
+  const size_t n = ctx->spots_host.size();
+  const bool f32 = ctx->prob.dtype == PDEOPT_F32;
+  const size_t bytes = n * 7 * (f32 ? sizeof(float) : sizeof(double));
+  if ((rc = ensure_buffer(ctx, &ctx->spots_dev, bytes))) return rc;
+  std::vector<char> packed(bytes);
+  for (size_t i = 0; i < n; ++i) {
+    const pdeopt_light_spot& q = ctx->spots_host[i];
+    const double v[7] = {q.amp0, q.amp_rate, q.x0, q.x_rate, q.y0, q.y_rate, q.inv_two_w2};
+    for (int c = 0; c < 7; ++c) {
+      if (f32)
+        reinterpret_cast<float*>(packed.data())[i * 7 + c] = (float)v[c];
+      else
+        reinterpret_cast<double*>(packed.data())[i * 7 + c] = v[c];
+    }
+  }
+  PDEOPT_HIP_CHECK(ctx, hipMemcpyAsync(ctx->spots_dev, packed.data(), bytes, hipMemcpyHostToDevice, ctx->stream));
+  PDEOPT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   return PDEOPT_OK;
 }
 

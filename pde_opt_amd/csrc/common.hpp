@@ -29,6 +29,36 @@ struct EnvParams {
   T fe[kMaxCoef];  // free-energy density closure (smoothed-boundary equations)
 };
 
+// Gaussian light spots of the GPE control field (pdeopt_set_gpe_spots), in the arithmetic type of the path;
+// device table [batch][PDEOPT_MAX_SPOTS]
+template <typename T>
+struct LightSpot {
+  T amp0, amp_rate, x0, x_rate, y0, y_rate, c;  // c = 1 / (2 width^2)
+};
+// what a Strang kernel needs to evaluate lights(t, x, y) of its environment at cell (ix, iy)
+template <typename T>
+struct SpotArgs {
+  const LightSpot<T>* table;  // nullptr / n == 0: no spots
+  int n;
+  T t, x_first, y_first, hx, hy;
+};
+template <typename T>
+__device__ __forceinline__ T t_exp_neg(T x);  // exp(-x)
+template <>
+__device__ __forceinline__ float t_exp_neg<float>(float x) { return __expf(-x); }
+template <>
+__device__ __forceinline__ double t_exp_neg<double>(double x) { return exp(-x); }
+template <typename T>
+__device__ __forceinline__ T spots_value(const SpotArgs<T>& a, int env, T x, T y) {
+  T w = T(0);
+  for (int s = 0; s < a.n; ++s) {
+    const LightSpot<T> q = a.table[(size_t)env * PDEOPT_MAX_SPOTS + s];
+    const T dx = x - (q.x0 + q.x_rate * a.t), dy = y - (q.y0 + q.y_rate * a.t);
+    w += (q.amp0 + q.amp_rate * a.t) * t_exp_neg<T>((dx * dx + dy * dy) * q.c);
+  }
+  return w;
+}
+
 // structure of a closure (shared by the whole batch; only coefficient VALUES vary per env)
 struct ClosureSpec {
   int kind;
@@ -130,6 +160,11 @@ struct pdeopt_ctx {
   std::string graph_name;
   int64_t opt_fuse_stages = 0;   // RK4 stage-pair fusion: 0 auto, -1 off (one launch per stage), 1 stage pairs (AC: no single-pass kernel)
   int64_t opt_debug_ablate = 0;  // timing-only ablations, results are wrong when set
+  // Gaussian light spots of the GPE (pdeopt_set_gpe_spots)
+  int n_spots = 0;
+  void* spots_dev = nullptr;
+  std::vector<pdeopt_light_spot> spots_host;  // [batch][PDEOPT_MAX_SPOTS]
+  double spots_x_first = 0.0, spots_y_first = 0.0;
   int win_lo = 0, win_n = 0;  // environment window the stage launchers operate on
   int64_t last_groups = 1;    // environment groups of the last advance (PDEOPT_CNT_LAST_GROUPS)
   double imex_A = 0.5, ts_re = 1.0, ts_im = 0.0, strang_dx = 1.0;
@@ -171,6 +206,19 @@ int ensure_buffer(pdeopt_ctx* ctx, void** p, size_t bytes);
 // api.hip: bring a time-dependent auxiliary field to local time t (no-op for static fields)
 int refresh_time_aux(pdeopt_ctx* ctx, int which, double t);
 inline bool has_time_aux(const pdeopt_ctx* ctx, int which) { return ctx->aux[which].fn != nullptr; }
+// light spots of the environments from win_lo on, at local time t
+template <typename T>
+inline SpotArgs<T> make_spot_args(const pdeopt_ctx* ctx, double t) {
+  SpotArgs<T> a{};
+  a.n = ctx->n_spots;
+  a.table = a.n ? static_cast<const LightSpot<T>*>(ctx->spots_dev) + (size_t)ctx->win_lo * PDEOPT_MAX_SPOTS : nullptr;
+  a.t = T(t);
+  a.x_first = T(ctx->spots_x_first);
+  a.y_first = T(ctx->spots_y_first);
+  a.hx = T(ctx->prob.hx);
+  a.hy = T(ctx->prob.hy);
+  return a;
+}
 
 // stencil.hip
 int launch_rhs(pdeopt_ctx* ctx, const void* in, void* out, double t);

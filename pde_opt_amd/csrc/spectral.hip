@@ -225,7 +225,7 @@ __global__ __launch_bounds__(256) void strang_b_kernel(C2<T>* __restrict__ psi,
                                                        const T* __restrict__ pot, int64_t pot_stride,
                                                        const EnvParams<T>* __restrict__ ep, T tr,
                                                        T ti, int64_t cells,
-                                                       double* __restrict__ partial) {
+                                                       double* __restrict__ partial, const SpotArgs<T> spots, int ny) {
   const int b = blockIdx.y;
   C2<T>* pb = psi + (int64_t)b * cells;
   const T* db = dens + (int64_t)b * cells;
@@ -233,7 +233,9 @@ __global__ __launch_bounds__(256) void strang_b_kernel(C2<T>* __restrict__ psi,
   const T kk = ep[b].gpe_k;
   double acc = 0.0;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < cells; i += (int64_t)gridDim.x * 256) {
-    const T w = (vb ? vb[i] : T(0)) + kk * db[i];
+    T w = (vb ? vb[i] : T(0)) + kk * db[i];
+    if (spots.n)  // lights(t0, x, y) as Gaussian spots (pdeopt_set_gpe_spots)
+      w += spots_value<T>(spots, b, spots.x_first + T(i / ny) * spots.hx, spots.y_first + T(i % ny) * spots.hy);
     // exp(-i w (tr + i ti)) = exp(w ti) (cos(w tr) - i sin(w tr))
     T sn, cs;
     t_sincos<T>(w * tr, &sn, &cs);
@@ -404,7 +406,7 @@ int strang_t(pdeopt_ctx* ctx, double t0, double dt, int64_t n) {
     hipLaunchKernelGGL(strang_b_kernel<T>, dim3(kNormBlocks, p.batch), dim3(256), 0, ctx->stream,
                        (C2<T>*)ctx->Y, (const T*)sp.dens, (const T*)pot.dev, pot_stride,
                        (const EnvParams<T>*)ctx->env_params_dev, (T)tau.real(), (T)tau.imag(), cells,
-                       sp.partial);
+                       sp.partial, make_spot_args<T>(ctx, t0 + (double)s * dt), p.ny);
     hipLaunchKernelGGL(norm_finalize_kernel, dim3((p.batch + 63) / 64), dim3(64), 0, ctx->stream,
                        (const double*)sp.partial, kNormBlocks, ctx->strang_dx * ctx->strang_dx,
                        sp.scale, p.batch);

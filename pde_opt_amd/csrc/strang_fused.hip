@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256) void strang_row_reg_kernel(Cx<T>* __restrict__
                                                              const T* __restrict__ pot, int64_t pot_env_stride,
                                                              const EnvParams<T>* __restrict__ ep,
                                                              const Cx<T>* __restrict__ tw, T tr, T ti, int nx,
-                                                             double* __restrict__ partial) {
+                                                             double* __restrict__ partial, const SpotArgs<T> spots) {
   using E = RegFft<T, N>;
   constexpr int PTS = reg_default_pts<N>(), TT = E::TT, F = 256 / TT, NP = fft_lds_pitch<N>();
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -107,14 +107,17 @@ __global__ __launch_bounds__(256) void strang_row_reg_kernel(Cx<T>* __restrict__
     const int env = (int)(row / nx);
     if constexpr (MODE == ROW_MID) {
       const T kk = ep[env].gpe_k;
-      const T* vrow = pot ? pot + (int64_t)env * pot_env_stride + (row - (int64_t)env * nx) * N : nullptr;
+      const int ix = (int)(row - (int64_t)env * nx);
+      const T* vrow = pot ? pot + (int64_t)env * pot_env_stride + (int64_t)ix * N : nullptr;
+      const T xs = spots.x_first + T(ix) * spots.hx;
       // |psi|^2 of the thread's points in the working precision (the reference sums in it too,
       // solvers.py:111), the sums across threads / workgroups / the column pass in fp64
       T accp = T(0);
 #pragma unroll
       for (int m = 0; m < PTS; ++m) {
         const int n = E::natural(j, m);
-        const T w = (vrow ? vrow[n] : T(0)) + kk * dens[row * N + n];
+        T w = (vrow ? vrow[n] : T(0)) + kk * dens[row * N + n];
+        if (spots.n) w += spots_value<T>(spots, env, xs, spots.y_first + T(n) * spots.hy);  // lights(t0, x, y)
         // exp(-i w (tr + i ti)) = exp(w ti) (cos(w tr) - i sin(w tr))
         T sn, cs;
         sincos_t<T>(w * tr, &sn, &cs);
@@ -254,7 +257,7 @@ template <typename T>
 int row_pass_rows_rt(int ny) { return ny <= 512 ? 256 / (ny / 8) : 256 / (ny / 16); }
 
 template <typename T, int N, int MODE>
-int launch_row(pdeopt_ctx* ctx, StrangFused& sf, double tr, double ti) {
+int launch_row(pdeopt_ctx* ctx, StrangFused& sf, double tr, double ti, double t = 0.0) {
   const pdeopt_problem& p = ctx->prob;
   const AuxField& pot = ctx->aux[PDEOPT_AUX_GPE_POTENTIAL];
   constexpr int F = row_pass_rows<T, N>();
@@ -268,7 +271,8 @@ int launch_row(pdeopt_ctx* ctx, StrangFused& sf, double tr, double ti) {
   hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, ctx->stream, (Cx<T>*)ctx->Y + w0 * cells,
                      (T*)sf.dens + w0 * cells, pot.dev ? (const T*)pot.dev + (pot.per_env ? w0 * cells : 0) : nullptr,
                      pot.per_env ? cells : (int64_t)0, (const EnvParams<T>*)ctx->env_params_dev + w0,
-                     (const Cx<T>*)sf.tw_y, (T)tr, (T)ti, p.nx, sf.partial + w0 * (p.nx / F));
+                     (const Cx<T>*)sf.tw_y, (T)tr, (T)ti, p.nx, sf.partial + w0 * (p.nx / F),
+                     MODE == ROW_MID ? make_spot_args<T>(ctx, t) : SpotArgs<T>{});
   PDEOPT_HIP_CHECK(ctx, hipGetLastError());
   return PDEOPT_OK;
 }
@@ -295,9 +299,9 @@ int launch_col(pdeopt_ctx* ctx, StrangFused& sf) {
 #define PDEOPT_FFT_SIZES(X) X(64) X(128) X(256) X(512) X(1024)
 
 template <typename T, int MODE>
-int row_dispatch(pdeopt_ctx* ctx, StrangFused& sf, double tr, double ti) {
+int row_dispatch(pdeopt_ctx* ctx, StrangFused& sf, double tr, double ti, double t = 0.0) {
   switch (ctx->prob.ny) {
-#define X(NN) case NN: return launch_row<T, NN, MODE>(ctx, sf, tr, ti);
+#define X(NN) case NN: return launch_row<T, NN, MODE>(ctx, sf, tr, ti, t);
     PDEOPT_FFT_SIZES(X)
 #undef X
     default: return fail(ctx, PDEOPT_EINVAL, "fused Strang: ny=%d is not covered", ctx->prob.ny);
@@ -395,7 +399,7 @@ int strang_fused_t(pdeopt_ctx* ctx, double t0, double dt, int64_t n) {
     for (int64_t s = 0; s < n; ++s) {
       if ((rc = col_dispatch<T, false>(ctx, sf))) break;
       if (timed && (rc = refresh_time_aux(ctx, PDEOPT_AUX_GPE_POTENTIAL, t0 + (double)s * dt))) break;
-      if ((rc = row_dispatch<T, ROW_MID>(ctx, sf, tr, ti))) break;
+      if ((rc = row_dispatch<T, ROW_MID>(ctx, sf, tr, ti, t0 + (double)s * dt))) break;
       if ((rc = col_dispatch<T, true>(ctx, sf))) break;
       if (s + 1 < n)
         rc = row_dispatch<T, ROW_JOIN>(ctx, sf, tr, ti);

@@ -202,6 +202,19 @@ class HipEngine:
         self._check(self._lib.pdeopt_set_aux_time_fn(self._h, which, cb, None, int(per_env)))
         self._aux_thunks[which] = cb  # keep the ctypes thunk alive while the library may call it
 
+    def set_gpe_spots(self, tables, x_first: float = 0.0, y_first: float = 0.0, env_first: int = 0):
+        """Gaussian light spots of the GPE control field, evaluated in-kernel at every substep's t0.
+        ``tables``: (envs, n_spots, 7) rows of ``pdeopt_light_spot`` (``GaussianSpots.table``); ``None`` or an
+        empty second axis removes the spots of the whole batch."""
+        if tables is None:
+            self._check(self._lib.pdeopt_set_gpe_spots(self._h, 0, self.batch, 0, None, 0.0, 0.0))
+            return
+        a = np.ascontiguousarray(np.asarray(tables, dtype=np.float64))
+        if a.ndim != 3 or a.shape[2] != 7:
+            raise ValueError(f"spot tables have shape (envs, n_spots, 7), got {a.shape}")
+        self._check(self._lib.pdeopt_set_gpe_spots(self._h, int(env_first), a.shape[0], a.shape[1],
+                                                   a.ctypes.data_as(C.c_void_p), float(x_first), float(y_first)))
+
     def set_env_gpe_k(self, env_first: int, k):
         """per-environment GPE interaction strength (the control value travels with the environment)"""
         a = np.ascontiguousarray(np.atleast_1d(np.asarray(k, dtype=np.float64)))

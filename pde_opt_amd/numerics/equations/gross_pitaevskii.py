@@ -26,6 +26,7 @@ import numpy as np
 
 from ... import _lib as L
 from ..domains import Domain
+from ..functions.lights import GaussianSpots
 from .base_eq import TimeSplittingEquation, depends_on_time
 from .phase_field import spectral_table
 
@@ -68,11 +69,23 @@ class GPE2DTSControl(TimeSplittingEquation):
         self.control = lambda t: self.lights(t, self.xmesh, self.ymesh)
         self.A_term = tab["A_kinetic"] if self.kinetic else tab["A_zero"]
 
+    def trap_potential(self) -> np.ndarray:
+        """the time-independent part of V: 1/2 trap_factor ((1 + e) X^2 + (1 - e) Y^2)"""
+        return 0.5 * self.trap_factor * ((1 + self.e) * self.xmesh**2 + (1 - self.e) * self.ymesh**2)
+
     def potential(self, t: float) -> np.ndarray:
         """V with b = -i (V + k |psi|^2): harmonic trap + control field."""
-        trap = 0.5 * self.trap_factor * ((1 + self.e) * self.xmesh**2 + (1 - self.e) * self.ymesh**2)
+        trap = self.trap_potential()
         ctrl = np.asarray(self.control(t), dtype=np.float64)
         return trap + np.broadcast_to(ctrl, trap.shape)
+
+    def _spots_in_kernel(self, t_end) -> bool:
+        """lights is a GaussianSpots family member and may vary: the kernels evaluate it (no host sampling)"""
+        return isinstance(self.lights, GaussianSpots) and self.time_dependent is not False and t_end is not None
+
+    def _cell0(self):
+        ax = self.domain.axes()
+        return float(ax[0][0]), float(ax[1][0])
 
     def _engine_problem(self):
         nx, ny = self.domain.points
@@ -87,6 +100,12 @@ class GPE2DTSControl(TimeSplittingEquation):
         return depends_on_time(self.control, t, t_end)
 
     def _engine_upload(self, engine, t: float = 0.0, t_end=None):
+        if self._spots_in_kernel(t_end):
+            engine.set_aux(L.AUX_GPE_POTENTIAL, self.trap_potential())
+            tab = self.lights.table(len(self.lights.spots))
+            engine.set_gpe_spots(np.broadcast_to(tab, (engine.batch,) + tab.shape), *self._cell0())
+            return
+        engine.set_gpe_spots(None)
         if self._lights_vary(t, t_end):
             engine.set_aux_time_fn(L.AUX_GPE_POTENTIAL, self.potential)
         else:
@@ -100,12 +119,24 @@ class GPE2DTSControl(TimeSplittingEquation):
         if any(e.kinetic != eq0.kinetic for e in eqs):
             raise ValueError("all environments of a batch must share A_term (the `kinetic` switch)")
         engine.set_env_gpe_k(0, [float(e.k) for e in eqs])
-        shared = all(e.lights is eq0.lights and e.e == eq0.e and e.trap_factor == eq0.trap_factor for e in eqs)
+        same_trap = all(e.e == eq0.e and e.trap_factor == eq0.trap_factor for e in eqs)
+        shared = same_trap and all(e.lights is eq0.lights for e in eqs)
         if shared:
             eq0._engine_upload(engine, t, t_end)
+        elif all(e._spots_in_kernel(t_end) for e in eqs):
+            # every environment steers its own spots: a few numbers per environment, evaluated in-kernel
+            n = max(len(e.lights.spots) for e in eqs)
+            engine.set_gpe_spots(np.stack([e.lights.table(n) for e in eqs]), *eq0._cell0())
+            if same_trap:
+                engine.set_aux(L.AUX_GPE_POTENTIAL, eq0.trap_potential())
+            else:
+                engine.set_aux(L.AUX_GPE_POTENTIAL, np.stack([e.trap_potential() for e in eqs]), per_env=True)
+            return
         elif any(e._lights_vary(t, t_end) for e in eqs):
+            engine.set_gpe_spots(None)
             engine.set_aux_time_fn(L.AUX_GPE_POTENTIAL, lambda tt: np.stack([e.potential(tt) for e in eqs]), per_env=True)
         else:
+            engine.set_gpe_spots(None)
             engine.set_aux(L.AUX_GPE_POTENTIAL, np.stack([e.potential(t) for e in eqs]), per_env=True)
 
     def A_terms(self, state, t):

@@ -1,5 +1,6 @@
 """Function representations used as closures (Legendre family; CNN/Mixer are out of scope)."""
 
+from .lights import GaussianSpot, GaussianSpots
 from .legendre import (
     ChemicalPotentialLegendrePolynomials,
     DiffusionLegendrePolynomials,
@@ -7,6 +8,8 @@ from .legendre import (
 )
 
 __all__ = [
+    "GaussianSpot",
+    "GaussianSpots",
     "LegendrePolynomialExpansion",
     "DiffusionLegendrePolynomials",
     "ChemicalPotentialLegendrePolynomials",

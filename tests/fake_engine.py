@@ -26,7 +26,7 @@ class OracleEngine:
         self.state_shape = (nx, ny) + ((2,) if equation == L.EQ_GPE else ())
         if not same:  # a same-shape configure keeps the resident state and the aux fields, like the library
             self.y = np.zeros((batch,) + self.state_shape, self.dtype)
-            self.aux, self.aux_fn = {}, {}
+            self.aux, self.aux_fn, self.spots = {}, {}, None
             self.imex_A, self.symbol = 0.5, None
             self.sbm, self.time_fn = {}, None
         self.fe = fe
@@ -58,6 +58,28 @@ class OracleEngine:
         else:
             a, per_env = self.aux[which]
         return a[b] if per_env else a
+
+    def set_gpe_spots(self, tables, x_first=0.0, y_first=0.0, env_first=0):
+        self.calls.append(("gpe_spots", None if tables is None else np.asarray(tables).shape))
+        if tables is None:
+            self.spots = None
+            return
+        t = np.asarray(tables, dtype=float)
+        if getattr(self, "spots", None) is None or self.spots.shape[1:] != t.shape[1:]:
+            self.spots = np.zeros((self.batch,) + t.shape[1:])
+        self.spots[env_first:env_first + t.shape[0]] = t
+        nx, ny = self.state_shape[:2]
+        self.spot_mesh = np.meshgrid(x_first + self.hx * np.arange(nx), y_first + self.hy * np.arange(ny), indexing="ij")
+
+    def _spots_at(self, t, b):
+        """the ABI's expression (include/pdeopt_hip.h, pdeopt_set_gpe_spots)"""
+        if getattr(self, "spots", None) is None:
+            return 0.0
+        X, Y = self.spot_mesh
+        w = 0.0
+        for a0, a1, x0, x1, y0, y1, c in self.spots[b]:
+            w = w + (a0 + a1 * t) * np.exp(-((X - x0 - x1 * t) ** 2 + (Y - y0 - y1 * t) ** 2) * c)
+        return w
 
     def set_env_gpe_k(self, env_first, k):
         k = np.atleast_1d(np.asarray(k, dtype=float))
@@ -119,7 +141,8 @@ class OracleEngine:
                 elif integrator == L.INT_STRANG:
                     # b = -i (V(t0) + k |psi0|^2): the ABI's decomposition of gross_pitaevskii.py:67-75
                     def bterm(tt, yy, b=b):
-                        w = self._aux_at(L.AUX_GPE_POTENTIAL, tt, b) + self.gpe_k_env[b] * (yy[..., 0] ** 2 + yy[..., 1] ** 2)
+                        w = (self._aux_at(L.AUX_GPE_POTENTIAL, tt, b) + self._spots_at(tt, b)
+                             + self.gpe_k_env[b] * (yy[..., 0] ** 2 + yy[..., 1] ** 2))
                         return np.stack([np.zeros_like(w), -w], axis=-1)
 
                     u = O.strang_step(bterm, t, u, dt, self.aux[L.AUX_GPE_A_TERM][0], self.strang_dx, self.time_scale)

@@ -137,6 +137,66 @@ def test_config4_size_per_environment_k_vs_oracle():
     assert rel_l2(out[0], out[-1]) > 1e-4
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("n,kernel", [(48, "strang_rocfft_c2c"), (128, "strang_fused_lds_fft")])
+def test_gaussian_spots_in_kernel_vs_oracle(dtype, n, kernel):
+    """GaussianSpots lights evaluated by the Strang kernels (pdeopt_set_gpe_spots) == the reference expression
+    lights(t0, X, Y) at every substep's t0 == the same control sampled on the host per substep."""
+    dt, nsub = 1e-3, 5
+    spots = P.GaussianSpots.moving(25.0, (-2.0, 0.5), (1.5, -1.0), nsub * dt, 1.3) + P.GaussianSpots.single((10.0, 2000.0), 3.0, (0.0, -300.0), 0.9)
+    dom = P.Domain((n, n), ((-12.0, 12.0), (-10.0, 10.0)), "dimensionless")
+    X, Y = dom.mesh()
+    rng = np.random.default_rng(3)
+    states = []
+    for b in range(3):
+        psi = np.exp(-(X**2 + Y**2) / (16.0 + b)) * np.exp(0.05j * rng.standard_normal((n, n)))
+        psi /= np.sqrt(np.sum(np.abs(psi) ** 2) * dom.dx[0] ** 2)
+        states.append(np.stack([psi.real, psi.imag], axis=-1))
+    y0 = np.stack(states).astype(dtype)
+    outs = {}
+    for name, lights in (("kernel", spots), ("host", lambda t, x, y: spots(t, x, y))):
+        eq = P.GPE2DTSControl(dom, 800.0, -0.15, lights, trap_factor=0.9, kinetic=True)
+        solver = P.StrangSplitting(eq.A_term, eq.dx, eq.fft, eq.ifft, 1.0)
+        eng = P.HipEngine()
+        outs[name] = P.diffeqsolve(eq, solver, 0.0, nsub * dt, dt, y0, engine=eng).ys[-1]
+        assert eng.last_kernel == kernel, eng.last_kernel
+        eng.close()
+    tol = 1e-11 if dtype is np.float64 else 3e-5
+    b_t = lambda t, yy: O.gpe_b_terms(yy, X, Y, 800.0, -0.15, 0.9, spots(t, X, Y))
+    for b in range(3):
+        want = y0[b].astype(np.float64)
+        for i in range(nsub):
+            want = O.strang_step(b_t, i * dt, want, dt, eq.A_term, eq.dx, 1.0)
+        assert rel_l2(outs["kernel"][b], want) < tol, rel_l2(outs["kernel"][b], want)
+        assert rel_l2(outs["host"][b], want) < tol
+    assert rel_l2(outs["kernel"], outs["host"]) < tol
+
+
+def test_vector_env_spot_controls_match_single_envs():
+    """every environment steers its own spot; batched == one PDEEnv per environment, bitwise"""
+    n, step_dt = 64, 3e-3
+    dom = P.Domain((n, n), ((-12.0, 12.0), (-12.0, 12.0)), "dimensionless")
+    update = lambda old, new: P.GaussianSpots.moving(25.0, (old, 0.0), (new, 0.0), step_dt, 1.2)
+    kw = _env_kwargs(dom, "lights", dict(k=800.0, e=0.1, trap_factor=1.0, kinetic=True), 0.0, update)
+    venv = P.VectorPDEEnv(3, **kw)
+    venv.reset(seed=5)
+    singles = []
+    for b in range(3):
+        e = P.PDEEnv(**kw)
+        e.reset(seed=5 + b)
+        singles.append(e)
+    for actions in ([0, 1, 2], [2, 0, 0]):
+        venv.step(actions)
+        states = venv.states
+        for b, e in enumerate(singles):
+            e.step(actions[b])
+            np.testing.assert_array_equal(states[b], e._state)
+        assert np.abs(states[0] - states[2]).max() > 1e-6
+    venv.close()
+    for e in singles:
+        e.close()
+
+
 @pytest.mark.parametrize("solver", ["euler", "rk4", "tsit5"])
 def test_advection_time_dependent_velocity_vs_oracle(solver):
     """velocity_fn(t, x, y) re-sampled at every Runge-Kutta stage time"""

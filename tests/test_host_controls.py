@@ -229,3 +229,57 @@ def test_advection_velocity_sampled_at_every_stage_time():
     eng = OracleEngine()
     P.diffeqsolve(eq_s, P.Euler(), 0.0, 3 * dt, dt, y0, engine=eng)
     assert not [c for c in eng.calls if c[0] in ("aux_time_fn", "aux_eval")]
+
+
+def test_gaussian_spots_are_handed_to_the_kernels_not_sampled():
+    """GaussianSpots lights: a table of numbers goes to the engine (pdeopt_set_gpe_spots), nothing is sampled
+    on the host per substep, and the result is the reference expression evaluated at every substep's t0."""
+    n, dt = 32, 1e-3
+    spots = P.GaussianSpots.moving(25.0, (-2.0, 0.5), (1.5, -1.0), 5 * dt, 1.3) + P.GaussianSpots.single((10.0, 2000.0), 3.0, (0.0, -300.0), 0.9)
+    assert spots.time_dependent
+    dom, eq = _gpe(n, spots)
+    X, Y = dom.mesh()
+    np.testing.assert_allclose(eq.control(2e-3), 25.0 * np.exp(-((X + 2.0 - 700.0 * 2e-3) ** 2 + (Y - 0.5 + 300.0 * 2e-3) ** 2) / (2 * 1.69))
+                               + 14.0 * np.exp(-((X - 3.0) ** 2 + (Y + 0.6) ** 2) / (2 * 0.81)), rtol=1e-13)
+    rng = np.random.default_rng(3)
+    psi = np.exp(-(X**2 + Y**2) / 18.0) * np.exp(0.1j * rng.standard_normal((n, n)))
+    psi /= np.sqrt(np.sum(np.abs(psi) ** 2) * dom.dx[0] ** 2)
+    y0 = np.stack([psi.real, psi.imag], axis=-1)
+    solver = P.StrangSplitting(eq.A_term, eq.dx, eq.fft, eq.ifft, 1.0)
+    eng = OracleEngine()
+    got = P.diffeqsolve(eq, solver, 0.0, 5 * dt, dt, y0, engine=eng).ys[-1]
+    assert ("gpe_spots", (1, 2, 7)) in eng.calls
+    assert not [c for c in eng.calls if c[0] in ("aux_time_fn", "aux_eval")]
+    b = lambda t, yy: O.gpe_b_terms(yy, X, Y, 800.0, -0.15, 0.9, spots(t, X, Y))
+    want = y0
+    for i in range(5):
+        want = O.strang_step(b, i * dt, want, dt, eq.A_term, eq.dx, 1.0)
+    np.testing.assert_allclose(got, want, rtol=0, atol=1e-13)
+    # a later equation without spots on the same engine removes them
+    dom, eq_c = _gpe(n, lambda t, x, y: 0.05 * x)
+    P.diffeqsolve(eq_c, solver, 0.0, 2 * dt, dt, y0, engine=eng)
+    assert eng.spots is None
+    with pytest.raises(ValueError, match="spots"):
+        P.GaussianSpots([])
+
+
+def test_vector_env_spot_controls_per_environment():
+    n, step_dt = 32, 3e-3
+    dom = P.Domain((n, n), ((-12.0, 12.0), (-12.0, 12.0)), "dimensionless")
+    update = lambda old, new: P.GaussianSpots.moving(25.0, (old, 0.0), (new, 0.0), step_dt, 1.2)
+    kw = _env_kwargs(dom, "lights", dict(k=800.0, e=0.1, trap_factor=1.0, kinetic=True), 0.0, update)
+    eng = OracleEngine()
+    venv = P.VectorPDEEnv(3, **kw, engine=eng)
+    venv.reset(seed=5)
+    singles = []
+    for b in range(3):
+        e = P.PDEEnv(**kw, engine=OracleEngine())
+        e.reset(seed=5 + b)
+        singles.append(e)
+    for actions in ([0, 1, 2], [2, 0, 0]):
+        venv.step(actions)
+        for b, e in enumerate(singles):
+            e.step(actions[b])
+            np.testing.assert_allclose(venv.states[b], e._state, rtol=0, atol=1e-14)
+    assert ("gpe_spots", (3, 1, 7)) in eng.calls
+    assert not [c for c in eng.calls if c[0] in ("aux_time_fn", "aux_eval")]

@@ -1,0 +1,30 @@
+"""Per-launch PMC averages of the dominant kernel -> profiles/pmc_<tag>.json (read by bench.py's roofline block).
+
+    python tools/pmc_to_json.py <workload> <tag> <kernel-substring> <dir> [<dir> ...]
+
+Every <dir> is the output directory of one `rocprofv3 --pmc ...` pass (tools/pmc_busy.sh, tools/profile_gpu.sh:
+separate passes per counter group, as MI355X_MICROARCH.md prescribes).  Counters are averaged over the launches
+whose kernel name contains the substring.  hbm_bytes_per_launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: FETCH_SIZE
+reports half the bytes of wide streaming loads on gfx950, both are KiB of L2 fabric-side requests (Infinity-Cache
+hits included)."""
+import collections, csv, glob, json, os, sys
+
+workload, tag, sub = sys.argv[1:4]
+acc, cnt, names = collections.defaultdict(float), collections.Counter(), set()
+for d in sys.argv[4:]:
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if sub in r["Kernel_Name"]:
+                acc[r["Counter_Name"]] += float(r["Counter_Value"])
+                cnt[r["Counter_Name"]] += 1
+                names.add(r["Kernel_Name"].split("(")[0])
+out = {c: acc[c] / cnt[c] for c in sorted(acc)}
+rec = {"kernels": sorted(names), "launches_averaged": max(cnt.values()) if cnt else 0, "counters_per_launch": out,
+       "source": "rocprofv3 --pmc passes of `python bench.py --steps 1 --warmup 0` (" + ", ".join(os.path.basename(d.rstrip('/')) for d in sys.argv[4:]) + ")"}
+if "FETCH_SIZE" in out and "WRITE_SIZE" in out:
+    rec["hbm_bytes_per_launch"] = (2 * out["FETCH_SIZE"] + out["WRITE_SIZE"]) * 1024
+path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles", f"pmc_{tag}.json")
+allrec = json.load(open(path)) if os.path.exists(path) else {}
+allrec[workload] = rec
+json.dump(allrec, open(path, "w"), indent=1)
+print(json.dumps(rec, indent=1))
