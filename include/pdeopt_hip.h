@@ -242,6 +242,11 @@ int pdeopt_get_interpolated(pdeopt_ctx* ctx, double theta, int env_first, int en
                             void* host_out);
 /* per-environment reductions of the state (reward helpers); out is [batch] doubles. */
 int pdeopt_reduce(pdeopt_ctx* ctx, int op, double* out_per_env);
+/* Point probes: the state at n_probes grid cells -- (i, j) index pairs, (i, j, k) triples for the 3-D
+ * equations -- of every environment of a range; host_out is [env_count][n_probes][comps] doubles (comps = 2
+ * for the GPE: re, im).  Sensor-style observations / rewards without moving the field. */
+int pdeopt_probe(pdeopt_ctx* ctx, const int32_t* cells, int n_probes, int env_first, int env_count,
+                 double* host_out);
 /* uint8 image observations formed on the device (observation space Box(0, 255, (1, *points), uint8),
  * pde_env.py:118-126): q = rint(clip((x - lo) / (hi - lo), 0, 1) * 255); host_out is
  * [env_count][nx][ny] bytes -- a quarter (fp32) / an eighth (fp64) of the D2H of the raw field. */
@@ -287,6 +292,20 @@ int pdeopt_buffer_copy(pdeopt_ctx* ctx, void* dst, const void* src, int64_t byte
 int pdeopt_tsit5_trial(pdeopt_ctx* ctx, double t, double dt, double rtol, double atol,
                        double* err_norm);
 int pdeopt_tsit5_commit(pdeopt_ctx* ctx, int accept);
+/* The same with ONE STEP SIZE PER ENVIRONMENT ("per-env error-norm reduction and per-env dt"):
+ * environment b steps by dt[b] (0 = leave it alone); the stages still run as one batched launch, every slope
+ * is stored scaled by dt[b] / dt_ref with dt_ref = max_b dt[b] (returned), so the shared coefficients
+ * dt_ref a_ij apply to all environments.  Needs an autonomous right-hand side (environments sit at different
+ * times).  pdeopt_tsit5_commit_env accepts / rejects per environment (accept[batch], 0 or 1);
+ * pdeopt_tsit5_dense takes dt = dt_ref and theta of the environment asked for. */
+int pdeopt_tsit5_trial_env(pdeopt_ctx* ctx, double t, const double* dt, double rtol, double atol, double* dt_ref,
+                           double* err_norm);
+int pdeopt_tsit5_commit_env(pdeopt_ctx* ctx, const uint8_t* accept);
+/* Dense output of the PENDING trial step (call between pdeopt_tsit5_trial and pdeopt_tsit5_commit):
+ * host_out = y(t + theta dt) = y + dt sum_i b_i(theta) k_i, theta in [0, 1], with the 4th-order continuous
+ * extension of Tsitouras' pair (Comput. Math. Appl. 62 (2011), section 4) -- the interpolant diffrax.Tsit5
+ * evaluates for SaveAt(ts=...) points that fall inside a step (tests/test_solvers.py:86-96 saves 200 of them). */
+int pdeopt_tsit5_dense(pdeopt_ctx* ctx, double theta, double dt, int env_first, int env_count, void* host_out);
 
 /* ---- timing / sync ------------------------------------------------------------------------- */
 int pdeopt_sync(pdeopt_ctx* ctx);

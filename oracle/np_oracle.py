@@ -318,8 +318,32 @@ _TS_E = (
 )
 
 
-def tsit5_step(f, t, y, dt, k1=None):
-    """One Tsit5 step.  Returns ``(y1, err, k7)`` (FSAL: ``k7 = f(t+dt, y1)``)."""
+def tsit5_dense_weights(theta):
+    """b_i(theta) of the 4th-order continuous extension of the pair (Tsitouras 2011, section 4) -- the
+    interpolant diffrax.Tsit5 (third party) evaluates at SaveAt points inside a step; b_i(1) = _TS_B."""
+    th, t2 = theta, theta * theta
+    return (
+        -1.0530884977290216 * th * (th - 1.3299890189751412) * (t2 - 1.4364028541716351 * th + 0.7139816917074209),
+        0.1017 * t2 * (t2 - 2.1966568338249754 * th + 1.2949852507374631),
+        2.490627285651252793 * t2 * (t2 - 2.38535645472061657 * th + 1.57803468208092486),
+        -16.54810288924490272 * (th - 1.21712927295533244) * (th - 0.61620406037800089) * t2,
+        47.37952196281928122 * (th - 1.203071208372362603) * (th - 0.658047292653547382) * t2,
+        -34.87065786149660974 * (th - 1.2) * (th - 0.666666666666666667) * t2,
+        2.5 * (th - 1.0) * (th - 0.6) * t2,
+    )
+
+
+def tsit5_dense(y, dt, ks, theta):
+    """``y(t + theta dt) = y + dt sum_i b_i(theta) k_i`` from the seven slopes of a step"""
+    out = y
+    for b, kk in zip(tsit5_dense_weights(theta), ks):
+        out = out + (dt * b) * kk
+    return out
+
+
+def tsit5_step(f, t, y, dt, k1=None, return_slopes=False):
+    """One Tsit5 step.  Returns ``(y1, err, k7)`` (FSAL: ``k7 = f(t+dt, y1)``); with ``return_slopes`` the
+    seven slopes are appended (dense output)."""
     ks = [f(t, y) if k1 is None else k1]
     for s in range(6):
         ys = y
@@ -331,6 +355,8 @@ def tsit5_step(f, t, y, dt, k1=None):
     err = 0
     for e, kk in zip(_TS_E, ks):
         err = err + (dt * e) * kk
+    if return_slopes:
+        return y1, err, ks[6], ks
     return y1, err, ks[6]
 
 

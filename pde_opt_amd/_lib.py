@@ -122,10 +122,14 @@ _SIGNATURES = {
     "pdeopt_snapshot": (C.c_int, [_VP]),
     "pdeopt_get_interpolated": (C.c_int, [_VP, C.c_double, C.c_int, C.c_int, _VP]),
     "pdeopt_reduce": (C.c_int, [_VP, C.c_int, _VP]),
+    "pdeopt_probe": (C.c_int, [_VP, _VP, C.c_int, C.c_int, C.c_int, _VP]),
     "pdeopt_observe_u8": (C.c_int, [_VP, C.c_double, C.c_double, C.c_int, C.c_int, _VP]),
     "pdeopt_detect_vortices": (C.c_int, [_VP, C.c_double, C.c_double, C.c_int, C.c_int, _VP, _VP]),
     "pdeopt_tsit5_trial": (C.c_int, [_VP, C.c_double, C.c_double, C.c_double, C.c_double, _VP]),
     "pdeopt_tsit5_commit": (C.c_int, [_VP, C.c_int]),
+    "pdeopt_tsit5_trial_env": (C.c_int, [_VP, C.c_double, _VP, C.c_double, C.c_double, C.POINTER(C.c_double), _VP]),
+    "pdeopt_tsit5_commit_env": (C.c_int, [_VP, _VP]),
+    "pdeopt_tsit5_dense": (C.c_int, [_VP, C.c_double, C.c_double, C.c_int, C.c_int, _VP]),
     "pdeopt_halo_strip_elems": (C.c_int, [_VP, C.POINTER(C.c_int64)]),
     "pdeopt_halo_pack": (C.c_int, [_VP, C.c_int, _VP]),
     "pdeopt_halo_unpack": (C.c_int, [_VP, C.c_int, _VP, C.POINTER(C.c_int)]),

@@ -80,6 +80,7 @@ void fill_env_params(pdeopt_ctx* ctx) {
   for (int b = 0; b < p.batch; ++b) {
     e[b].kappa = T(p.kappa);
     e[b].gpe_k = T(p.gpe_k);
+    e[b].kscale = T(1);
     for (int k = 0; k < kMaxCoef; ++k) {
       e[b].mu[k] = k < p.mu.n ? T(p.mu.coef[k]) : T(0);
       e[b].mob[k] = k < p.mob.n ? T(p.mob.coef[k]) : T(0);
@@ -106,6 +107,12 @@ template <typename T>
 void patch_env_gpe_k(pdeopt_ctx* ctx, int first, int count, const double* k) {
   auto* e = reinterpret_cast<EnvParams<T>*>(ctx->env_params_host.data());
   for (int i = 0; i < count; ++i) e[first + i].gpe_k = T(k[i]);
+}
+
+template <typename T>
+void patch_kscale(pdeopt_ctx* ctx, const std::vector<double>& sc) {
+  auto* e = reinterpret_cast<EnvParams<T>*>(ctx->env_params_host.data());
+  for (size_t b = 0; b < sc.size(); ++b) e[b].kscale = T(sc[b]);
 }
 
 int upload_env_params(pdeopt_ctx* ctx) {
@@ -291,8 +298,6 @@ int pdeopt_configure(pdeopt_ctx* ctx, const pdeopt_problem* pr) {
   const bool is3d = pr->equation == PDEOPT_EQ_CAHN_HILLIARD_3D;
   if (is3d) {
     if (pr->nz < 1 || !(pr->hz > 0)) return fail(ctx, PDEOPT_EINVAL, "3-D problem needs nz >= 1 and hz > 0");
-    if (pr->derivs != PDEOPT_DERIVS_FD)
-      return fail(ctx, PDEOPT_EINVAL, "CahnHilliard3DPeriodic: only derivs=\"fd\" has a kernel");
     if (ctx->halo) return fail(ctx, PDEOPT_EINVAL, "the padded layout is 2-D only");
   } else if (pr->nz > 1) {
     return fail(ctx, PDEOPT_EINVAL, "nz=%d with a 2-D equation", pr->nz);
@@ -308,7 +313,7 @@ int pdeopt_configure(pdeopt_ctx* ctx, const pdeopt_problem* pr) {
   if (pr->derivs != PDEOPT_DERIVS_FD && pr->derivs != PDEOPT_DERIVS_FOURIER)
     return fail(ctx, PDEOPT_EINVAL, "Invalid derivative type: %d", pr->derivs);
   if (pr->derivs == PDEOPT_DERIVS_FOURIER && pr->equation != PDEOPT_EQ_CAHN_HILLIARD &&
-      pr->equation != PDEOPT_EQ_ALLEN_CAHN)
+      pr->equation != PDEOPT_EQ_ALLEN_CAHN && pr->equation != PDEOPT_EQ_CAHN_HILLIARD_3D)
     return fail(ctx, PDEOPT_EINVAL, "the pseudo-spectral RHS exists for Cahn-Hilliard / Allen-Cahn only");
   ctx->prob = *pr;
   if (ctx->prob.mu.n < 1) ctx->prob.mu.n = 1;
@@ -617,6 +622,17 @@ int pdeopt_reduce(pdeopt_ctx* ctx, int op, double* out_per_env) {
   return reduce_state(ctx, op, out_per_env);
 }
 
+int pdeopt_probe(pdeopt_ctx* ctx, const int32_t* cells, int n_probes, int env_first, int env_count,
+                 double* host_out) {
+  if (!ctx || !cells || !host_out) return PDEOPT_EINVAL;
+  int rc = check_envs(ctx, env_first, env_count);
+  if (rc) return rc;
+  if (n_probes < 1) return fail(ctx, PDEOPT_EINVAL, "n_probes = %d", n_probes);
+  if (ctx->halo) return fail(ctx, PDEOPT_EINVAL, "probes are not available in the padded layout");
+  PDEOPT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  return env_count ? probe_state(ctx, cells, n_probes, env_first, env_count, host_out) : PDEOPT_OK;
+}
+
 int pdeopt_observe_u8(pdeopt_ctx* ctx, double lo, double hi, int env_first, int env_count,
                       uint8_t* host_out) {
   if (!ctx || !host_out) return PDEOPT_EINVAL;
@@ -645,7 +661,62 @@ int pdeopt_tsit5_trial(pdeopt_ctx* ctx, double t, double dt, double rtol, double
   if (ctx->prob.equation == PDEOPT_EQ_GPE)
     return fail(ctx, PDEOPT_EINVAL, "the GPE is integrated by Strang splitting only");
   PDEOPT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  if (!ctx->kscale_prev.empty()) {
+    // the FSAL slope may carry per-environment scales from pdeopt_tsit5_trial_env: recompute it
+    bool ones = true;
+    for (double v : ctx->kscale_prev) ones = ones && v == 1.0;
+    if (!ones) ctx->tsit5_fsal_valid = false;
+    ctx->kscale_prev.clear();
+  }
   return tsit5_trial(ctx, t, dt, rtol, atol, err_norm);
+}
+
+int pdeopt_tsit5_trial_env(pdeopt_ctx* ctx, double t, const double* dt, double rtol, double atol, double* dt_ref,
+                           double* err_norm) {
+  if (!ctx || !dt || !dt_ref) return PDEOPT_EINVAL;
+  if (!ctx->configured) return fail(ctx, PDEOPT_ESTATE, "pdeopt_configure has not been called");
+  if (ctx->prob.equation == PDEOPT_EQ_GPE)
+    return fail(ctx, PDEOPT_EINVAL, "the GPE is integrated by Strang splitting only");
+  if (ctx->time_fn || has_time_aux(ctx, PDEOPT_AUX_VX_FACE) || has_time_aux(ctx, PDEOPT_AUX_VY_FACE) ||
+      ctx->prob.equation == PDEOPT_EQ_ALLEN_CAHN_SBM || ctx->prob.equation == PDEOPT_EQ_CAHN_HILLIARD_SBM)
+    return fail(ctx, PDEOPT_EINVAL, "per-environment step sizes need an autonomous right-hand side (environments sit at different times)");
+  PDEOPT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  const int batch = ctx->prob.batch;
+  double ref = 0.0;
+  for (int b = 0; b < batch; ++b) {
+    if (!(dt[b] >= 0.0)) return fail(ctx, PDEOPT_EINVAL, "dt[%d] = %g", b, dt[b]);
+    ref = dt[b] > ref ? dt[b] : ref;
+  }
+  if (!(ref > 0.0)) return fail(ctx, PDEOPT_EINVAL, "every per-environment step size is zero");
+  std::vector<double> sc((size_t)batch), ratio((size_t)batch, 1.0);
+  if (ctx->kscale_prev.size() != (size_t)batch) ctx->kscale_prev.assign((size_t)batch, 1.0);
+  bool rescale = false;
+  for (int b = 0; b < batch; ++b) {
+    sc[b] = dt[b] / ref;
+    ratio[b] = ctx->kscale_prev[b] > 0.0 ? sc[b] / ctx->kscale_prev[b] : 0.0;
+    rescale = rescale || ratio[b] != 1.0;
+  }
+  int rc;
+  // the FSAL slope K[0] of environment b carries the scale of its previous trial
+  if (ctx->tsit5_fsal_valid && rescale && (rc = tsit5_rescale_fsal(ctx, ratio.data()))) return rc;
+  if (ctx->prob.dtype == PDEOPT_F32)
+    patch_kscale<float>(ctx, sc);
+  else
+    patch_kscale<double>(ctx, sc);
+  if ((rc = upload_env_params(ctx))) return rc;
+  ctx->slope_scaled = true;
+  rc = tsit5_trial(ctx, t, ref, rtol, atol, err_norm);
+  ctx->slope_scaled = false;
+  ctx->kscale_prev = sc;
+  *dt_ref = ref;
+  return rc;
+}
+
+int pdeopt_tsit5_commit_env(pdeopt_ctx* ctx, const uint8_t* accept) {
+  if (!ctx || !accept) return PDEOPT_EINVAL;
+  if (!ctx->configured) return fail(ctx, PDEOPT_ESTATE, "pdeopt_configure has not been called");
+  PDEOPT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  return tsit5_commit_env(ctx, accept);
 }
 
 int pdeopt_tsit5_commit(pdeopt_ctx* ctx, int accept) {
@@ -653,6 +724,21 @@ int pdeopt_tsit5_commit(pdeopt_ctx* ctx, int accept) {
   if (!ctx->configured) return fail(ctx, PDEOPT_ESTATE, "pdeopt_configure has not been called");
   PDEOPT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   return tsit5_commit(ctx, accept);
+}
+
+int pdeopt_tsit5_dense(pdeopt_ctx* ctx, double theta, double dt, int env_first, int env_count, void* host_out) {
+  if (!ctx || !host_out) return PDEOPT_EINVAL;
+  int rc = check_envs(ctx, env_first, env_count);
+  if (rc) return rc;
+  if (!(theta >= 0.0 && theta <= 1.0)) return fail(ctx, PDEOPT_EINVAL, "theta = %g outside [0, 1]", theta);
+  PDEOPT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  // TA is free between a trial and its commit (the candidate sits in TB)
+  if ((rc = tsit5_dense(ctx, theta, dt, env_first, env_count, ctx->TA))) return rc;
+  const size_t eb = ctx->env_elems * ctx->esize;
+  PDEOPT_HIP_CHECK(ctx, hipMemcpyAsync(host_out, (const char*)ctx->TA + eb * env_first, eb * env_count,
+                                       hipMemcpyDeviceToHost, ctx->stream));
+  PDEOPT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return PDEOPT_OK;
 }
 
 int pdeopt_get_counter(pdeopt_ctx* ctx, int which, int64_t* value) {

@@ -23,7 +23,8 @@ template <typename T>
 struct EnvParams {
   T kappa;
   T gpe_k;
-  T r0, r1;
+  T kscale;  // slope scale dt_b / dt_ref of per-environment step sizes (pdeopt_tsit5_trial_env); 1 otherwise
+  T r1;
   T mu[kMaxCoef];
   T mob[kMaxCoef];
   T fe[kMaxCoef];  // free-energy density closure (smoothed-boundary equations)
@@ -136,6 +137,8 @@ struct pdeopt_ctx {
   void* K[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // Tsit5 slopes
   bool tsit5_pending = false;
   bool tsit5_fsal_valid = false;
+  bool slope_scaled = false;           // stage launches multiply k by EnvParams::kscale (per-environment dt)
+  std::vector<double> kscale_prev;     // scale the FSAL slope K[0] of each environment carries
   // smoothed-boundary equations: time of the RHS evaluation being launched and its scalar terms
   double cur_t = 0.0;
   pdeopt_time_fn time_fn = nullptr;
@@ -228,6 +231,9 @@ int launch_rhs_slope(pdeopt_ctx* ctx, const void* in, void* out, double t);
 int advance_explicit(pdeopt_ctx* ctx, int integrator, double t0, double dt, int64_t n);
 int tsit5_trial(pdeopt_ctx* ctx, double t, double dt, double rtol, double atol, double* err);
 int tsit5_commit(pdeopt_ctx* ctx, int accept);
+int tsit5_dense(pdeopt_ctx* ctx, double theta, double dt, int env_first, int env_count, void* dev_out);
+int tsit5_commit_env(pdeopt_ctx* ctx, const uint8_t* accept);
+int tsit5_rescale_fsal(pdeopt_ctx* ctx, const double* ratio);  // K[0] of environment b *= ratio[b]
 void graph_destroy(pdeopt_ctx* ctx);
 int launch_lerp(pdeopt_ctx* ctx, const void* a, const void* b, void* out, double theta,
                 size_t env_first, size_t env_count);
@@ -240,6 +246,7 @@ int rk4_phase_plan(pdeopt_ctx* ctx, int* fields, int* nphases);
 void* field_ptr(pdeopt_ctx* ctx, int field);
 // reduce.hip
 int reduce_state(pdeopt_ctx* ctx, int op, double* out);
+int probe_state(pdeopt_ctx* ctx, const int32_t* cells, int n_probes, int env_first, int env_count, double* host_out);
 int observe_u8(pdeopt_ctx* ctx, double lo, double hi, int env_first, int env_count, void* host_out);
 int detect_vortices(pdeopt_ctx* ctx, double amp_thresh, double tol, int env_first, int env_count,
                     int32_t* host_winding, int64_t* host_counts);

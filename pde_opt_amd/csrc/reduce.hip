@@ -249,6 +249,55 @@ int detect_vortices(pdeopt_ctx* ctx, double amp_thresh, double tol, int env_firs
   return PDEOPT_OK;
 }
 
+// Point probes: the state at a list of grid cells, for every environment of a range (observation / reward
+// functions that read a few sensors: n_probes * comps doubles per environment cross PCIe instead of the field).
+template <typename T>
+__global__ void probe_kernel(const T* __restrict__ y, const int64_t* __restrict__ cell, int n_probes, int comps,
+                             int64_t env_elems, int env_first, double* __restrict__ out, int64_t total) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int c = (int)(i % comps);
+  const int q = (int)((i / comps) % n_probes);
+  const int64_t e = i / ((int64_t)comps * n_probes);
+  out[i] = (double)y[(env_first + e) * env_elems + cell[q] * comps + c];
+}
+
+int probe_state(pdeopt_ctx* ctx, const int32_t* cells, int n_probes, int env_first, int env_count, double* host_out) {
+  const pdeopt_problem& p = ctx->prob;
+  const int nz = p.nz > 1 ? p.nz : 1;
+  const int nd = nz > 1 ? 3 : 2;
+  std::vector<int64_t> flat((size_t)n_probes);
+  for (int q = 0; q < n_probes; ++q) {
+    const int i = cells[(size_t)q * nd], j = cells[(size_t)q * nd + 1], k = nd == 3 ? cells[(size_t)q * nd + 2] : 0;
+    if (i < 0 || i >= p.nx || j < 0 || j >= p.ny || k < 0 || k >= nz)
+      return fail(ctx, PDEOPT_EINVAL, "probe %d at (%d, %d, %d) outside the %d x %d x %d grid", q, i, j, k, p.nx, p.ny, nz);
+    flat[q] = ((int64_t)i * p.ny + j) * nz + k;
+  }
+  const int64_t total = (int64_t)env_count * n_probes * ctx->comps;
+  const size_t need = (size_t)n_probes * sizeof(int64_t) + (size_t)total * sizeof(double);
+  if (ctx->red_cap < need) {
+    if (ctx->red_dev) (void)hipFree(ctx->red_dev);
+    ctx->red_dev = nullptr;
+    ctx->red_cap = 0;
+    PDEOPT_HIP_CHECK(ctx, hipMalloc((void**)&ctx->red_dev, need));
+    ctx->red_cap = need;
+  }
+  double* out_dev = ctx->red_dev;
+  int64_t* cell_dev = reinterpret_cast<int64_t*>(ctx->red_dev + total);
+  PDEOPT_HIP_CHECK(ctx, hipMemcpyAsync(cell_dev, flat.data(), (size_t)n_probes * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
+  const int blocks = (int)((total + 255) / 256);
+  if (p.dtype == PDEOPT_F32)
+    hipLaunchKernelGGL(probe_kernel<float>, dim3(blocks), dim3(256), 0, ctx->stream, (const float*)ctx->Y, cell_dev, n_probes,
+                       ctx->comps, (int64_t)ctx->env_elems, env_first, out_dev, total);
+  else
+    hipLaunchKernelGGL(probe_kernel<double>, dim3(blocks), dim3(256), 0, ctx->stream, (const double*)ctx->Y, cell_dev, n_probes,
+                       ctx->comps, (int64_t)ctx->env_elems, env_first, out_dev, total);
+  PDEOPT_HIP_CHECK(ctx, hipGetLastError());
+  PDEOPT_HIP_CHECK(ctx, hipMemcpyAsync(host_out, out_dev, (size_t)total * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  PDEOPT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));  // flat[] and host_out are the caller's from here on
+  return PDEOPT_OK;
+}
+
 int reduce_state(pdeopt_ctx* ctx, int op, double* out) {
   const int batch = ctx->prob.batch;
   const double n = (double)ctx->env_elems;

@@ -67,8 +67,9 @@ int ensure_plans(pdeopt_ctx* ctx) {
   const pdeopt_problem& p = ctx->prob;
   // rocFFT lengths are fastest-first; a dimension of length 1 is dropped (256 x 1 "1-D" runs
   // of tests/test_solvers.py:21-61)
-  size_t lengths[2];
+  size_t lengths[3];
   size_t dims = 0;
+  if (p.nz > 1) lengths[dims++] = (size_t)p.nz;  // 3-D equations: z is the contiguous axis
   if (p.ny > 1) lengths[dims++] = (size_t)p.ny;
   if (p.nx > 1) lengths[dims++] = (size_t)p.nx;
   if (dims == 0) lengths[dims++] = 1;
@@ -552,12 +553,128 @@ int rhs_fourier_t(pdeopt_ctx* ctx, const void* in, void* out) {
   return PDEOPT_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// CahnHilliard3DPeriodic.rhs_fourier (cahn_hilliard.py:167-175), fields [b][nx][ny][nz]:
+//   t_hat = F[mu_h(u)] - kappa K2 F[u];   rhs = Re F^-1[ sum_d i k_d F[ D(u) F^-1[ i k_d t_hat ] ] ]   (9 FFTs)
+// one axis at a time through a single work field, the divergence accumulated in spectral space.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ void wave3(int64_t i, int nx, int ny, int nz, T ilx, T ily, T ilz, T* k) {
+  const int iz = (int)(i % nz), iy = (int)((i / nz) % ny), ix = (int)(i / ((int64_t)nz * ny));
+  k[0] = wavenumber_2pi<T>(ix, nx, ilx);
+  k[1] = wavenumber_2pi<T>(iy, ny, ily);
+  k[2] = wavenumber_2pi<T>(iz, nz, ilz);
+}
+
+// b <- t_hat = b - kappa K2 a
+template <typename T>
+__global__ void fourier3_that_kernel(const C2<T>* __restrict__ a, C2<T>* __restrict__ b, const EnvParams<T>* __restrict__ ep,
+                                     int nx, int ny, int nz, T ilx, T ily, T ilz) {
+  const int env = blockIdx.y;
+  const T kap = ep[env].kappa;
+  const int64_t cells = (int64_t)nx * ny * nz, o = (int64_t)env * cells;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cells; i += (int64_t)gridDim.x * blockDim.x) {
+    T k[3];
+    wave3<T>(i, nx, ny, nz, ilx, ily, ilz, k);
+    const T k2 = -(k[0] * k[0] + k[1] * k[1] + k[2] * k[2]);
+    const C2<T> ua = a[o + i], mb = b[o + i];
+    b[o + i] = C2<T>{mb.re - kap * k2 * ua.re, mb.im - kap * k2 * ua.im};
+  }
+}
+
+// w <- i k_axis t_hat
+template <typename T>
+__global__ void fourier3_grad_kernel(const C2<T>* __restrict__ that, C2<T>* __restrict__ w, int axis, int nx, int ny,
+                                     int nz, T ilx, T ily, T ilz) {
+  const int env = blockIdx.y;
+  const int64_t cells = (int64_t)nx * ny * nz, o = (int64_t)env * cells;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cells; i += (int64_t)gridDim.x * blockDim.x) {
+    T k[3];
+    wave3<T>(i, nx, ny, nz, ilx, ily, ilz, k);
+    const C2<T> t = that[o + i];
+    w[o + i] = C2<T>{-k[axis] * t.im, k[axis] * t.re};
+  }
+}
+
+// w *= D(u) / N
+template <typename T>
+__global__ void fourier3_mob_kernel(const T* __restrict__ u, C2<T>* __restrict__ w, const EnvParams<T>* __restrict__ ep,
+                                    ClosureSpec mob, int64_t cells, T inv_n) {
+  const int env = blockIdx.y;
+  const EnvParams<T>& p = ep[env];
+  const int64_t o = (int64_t)env * cells;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cells; i += (int64_t)gridDim.x * blockDim.x) {
+    const T d = closure_generic<T>(mob, p.mob, u[o + i]) * inv_n;
+    const C2<T> v = w[o + i];
+    w[o + i] = C2<T>{v.re * d, v.im * d};
+  }
+}
+
+// acc (+)= i k_axis w
+template <typename T>
+__global__ void fourier3_div_kernel(C2<T>* __restrict__ acc, const C2<T>* __restrict__ w, int axis, int first, int nx,
+                                    int ny, int nz, T ilx, T ily, T ilz) {
+  const int env = blockIdx.y;
+  const int64_t cells = (int64_t)nx * ny * nz, o = (int64_t)env * cells;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cells; i += (int64_t)gridDim.x * blockDim.x) {
+    T k[3];
+    wave3<T>(i, nx, ny, nz, ilx, ily, ilz, k);
+    const C2<T> v = w[o + i];
+    C2<T> r{-k[axis] * v.im, k[axis] * v.re};
+    if (!first) {
+      const C2<T> old = acc[o + i];
+      r.re += old.re;
+      r.im += old.im;
+    }
+    acc[o + i] = r;
+  }
+}
+
+template <typename T>
+int rhs_fourier3_t(pdeopt_ctx* ctx, const void* in, void* out) {
+  Spectral& sp = *ctx->spectral;
+  const pdeopt_problem& p = ctx->prob;
+  const int64_t cells = (int64_t)p.nx * p.ny * p.nz, total = cells * p.batch;
+  int rc;
+  if ((rc = ensure_buffer(ctx, &sp.cbuf, (size_t)total * 2 * sizeof(T)))) return rc;
+  if ((rc = ensure_buffer(ctx, &sp.cbuf2, (size_t)total * 2 * sizeof(T)))) return rc;
+  if ((rc = ensure_buffer(ctx, &sp.cbuf3, (size_t)total * 2 * sizeof(T)))) return rc;
+  C2<T>* a = (C2<T>*)sp.cbuf2;   // F[u], later the accumulated divergence
+  C2<T>* b = (C2<T>*)sp.cbuf3;   // F[mu_h(u)], then t_hat
+  C2<T>* w = (C2<T>*)sp.cbuf;    // one axis at a time
+  const T* u = (const T*)in;
+  const auto* ep = (const EnvParams<T>*)ctx->env_params_dev;
+  const ClosureSpec mu{p.mu.kind, p.mu.flags, p.mu.n}, mob{p.mob.kind, p.mob.flags, p.mob.n};
+  const dim3 grid(grid_for(cells), p.batch), blk(256);
+  const T ilx = T(1.0 / (p.nx * p.hx)), ily = T(1.0 / (p.ny * p.hy)), ilz = T(1.0 / (p.nz * p.hz));
+  const T inv_n = T(1.0 / (double)cells);
+  hipLaunchKernelGGL(fourier_embed_kernel<T>, grid, blk, 0, ctx->stream, u, a, b, ep, mu, cells);
+  if ((rc = fft_exec(ctx, true, a))) return rc;
+  if ((rc = fft_exec(ctx, true, b))) return rc;
+  hipLaunchKernelGGL(fourier3_that_kernel<T>, grid, blk, 0, ctx->stream, (const C2<T>*)a, b, ep, p.nx, p.ny, p.nz, ilx, ily, ilz);
+  for (int axis = 0; axis < 3; ++axis) {
+    hipLaunchKernelGGL(fourier3_grad_kernel<T>, grid, blk, 0, ctx->stream, (const C2<T>*)b, w, axis, p.nx, p.ny, p.nz, ilx, ily, ilz);
+    if ((rc = fft_exec(ctx, false, w))) return rc;
+    hipLaunchKernelGGL(fourier3_mob_kernel<T>, grid, blk, 0, ctx->stream, u, w, ep, mob, cells, inv_n);
+    if ((rc = fft_exec(ctx, true, w))) return rc;
+    hipLaunchKernelGGL(fourier3_div_kernel<T>, grid, blk, 0, ctx->stream, a, (const C2<T>*)w, axis, axis == 0 ? 1 : 0, p.nx,
+                       p.ny, p.nz, ilx, ily, ilz);
+  }
+  if ((rc = fft_exec(ctx, false, a))) return rc;
+  hipLaunchKernelGGL((fourier_out_kernel<T, true>), grid, blk, 0, ctx->stream, u, (const C2<T>*)a, (T*)out, ep, mob, cells, inv_n);
+  PDEOPT_HIP_CHECK(ctx, hipGetLastError());
+  ctx->last_kernel = "rhs_fourier<CH-3D>(rocfft x9)";
+  return PDEOPT_OK;
+}
+
 }  // namespace
 
 int rhs_fourier(pdeopt_ctx* ctx, const void* in, void* out) {
   if (ctx->halo) return fail(ctx, PDEOPT_EINVAL, "the pseudo-spectral RHS needs the periodic layout");
   int rc = ensure_plans(ctx);
   if (rc) return rc;
+  if (ctx->prob.equation == PDEOPT_EQ_CAHN_HILLIARD_3D)
+    return ctx->prob.dtype == PDEOPT_F32 ? rhs_fourier3_t<float>(ctx, in, out) : rhs_fourier3_t<double>(ctx, in, out);
   return ctx->prob.dtype == PDEOPT_F32 ? rhs_fourier_t<float>(ctx, in, out) : rhs_fourier_t<double>(ctx, in, out);
 }
 

@@ -61,6 +61,7 @@ StageArgs<T> make_args(pdeopt_ctx* ctx, const void* in, const void* y, void* out
   }
   s.out_mode = out_mode;
   s.acc_mode = acc_mode;
+  s.scaled = ctx->slope_scaled ? 1 : 0;
   s.dbg = (int)ctx->opt_debug_ablate;
   return s;
 }
@@ -128,10 +129,19 @@ int launch_generic(pdeopt_ctx* ctx, const StageArgs<T>& s) {
 
 // pointwise stage update for RHS evaluations that are not fused into a stencil kernel
 template <typename T>
-__global__ void stage_update_kernel(const StageArgs<T> a, const T* __restrict__ k, int64_t total) {
+__global__ void stage_update_kernel(const StageArgs<T> a, const T* __restrict__ k, int64_t total, int64_t env_elems) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t st = (int64_t)gridDim.x * blockDim.x;
-  for (; i < total; i += st) stage_update<T>(a, i, k[i]);
+  for (; i < total; i += st) stage_update<T>(a, i, a.scaled ? k[i] * a.ep[i / env_elems].kscale : k[i]);
+}
+
+// field of environment b *= ratio[b]
+template <typename T>
+__global__ void env_scale_kernel(T* __restrict__ f, const double* __restrict__ ratio, int64_t env_elems) {
+  const int b = blockIdx.y;
+  const T r = (T)ratio[b];
+  T* p = f + (int64_t)b * env_elems;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < env_elems; i += (int64_t)gridDim.x * blockDim.x) p[i] *= r;
 }
 
 template <typename T>
@@ -139,12 +149,13 @@ int launch_stage_fourier(pdeopt_ctx* ctx, const StageArgs<T>& s, const void* in,
   if (ctx->win_lo != 0 || ctx->win_n != ctx->prob.batch)
     return fail(ctx, PDEOPT_EINVAL, "spectral RHS works on the whole batch");
   int rc;
-  if (s.out_mode == OUT_K && s.acc_mode == ACC_NONE) return rhs_fourier(ctx, in, out);
+  if (s.out_mode == OUT_K && s.acc_mode == ACC_NONE && !s.scaled) return rhs_fourier(ctx, in, out);
   if ((rc = ensure_buffer(ctx, &ctx->KS, ctx->total_bytes))) return rc;
   if ((rc = rhs_fourier(ctx, in, ctx->KS))) return rc;
   const int64_t total = (int64_t)(ctx->env_elems * ctx->prob.batch);
   const int blocks = (int)std::min<int64_t>((total + 255) / 256, 4096);
-  hipLaunchKernelGGL(stage_update_kernel<T>, dim3(blocks), dim3(256), 0, ctx->stream, s, (const T*)ctx->KS, total);
+  hipLaunchKernelGGL(stage_update_kernel<T>, dim3(blocks), dim3(256), 0, ctx->stream, s, (const T*)ctx->KS, total,
+                     (int64_t)ctx->env_elems);
   PDEOPT_HIP_CHECK(ctx, hipGetLastError());
   return PDEOPT_OK;
 }
@@ -618,6 +629,84 @@ int tsit5_trial_t(pdeopt_ctx* ctx, double t, double dt, double rtol, double atol
 int tsit5_trial(pdeopt_ctx* ctx, double t, double dt, double rtol, double atol, double* err) {
   return ctx->prob.dtype == PDEOPT_F32 ? tsit5_trial_t<float>(ctx, t, dt, rtol, atol, err)
                                        : tsit5_trial_t<double>(ctx, t, dt, rtol, atol, err);
+}
+
+// b_i(theta) of the 4th-order continuous extension (Tsitouras 2011, section 4); b_i(1) = the 5th-order weights
+static void tsit5_dense_weights(double th, double* b) {
+  const double t2 = th * th;
+  b[0] = -1.0530884977290216 * th * (th - 1.3299890189751412) * (t2 - 1.4364028541716351 * th + 0.7139816917074209);
+  b[1] = 0.1017 * t2 * (t2 - 2.1966568338249754 * th + 1.2949852507374631);
+  b[2] = 2.490627285651252793 * t2 * (t2 - 2.38535645472061657 * th + 1.57803468208092486);
+  b[3] = -16.54810288924490272 * (th - 1.21712927295533244) * (th - 0.61620406037800089) * t2;
+  b[4] = 47.37952196281928122 * (th - 1.203071208372362603) * (th - 0.658047292653547382) * t2;
+  b[5] = -34.87065786149660974 * (th - 1.2) * (th - 0.666666666666666667) * t2;
+  b[6] = 2.5 * (th - 1.0) * (th - 0.6) * t2;
+}
+
+template <typename T>
+static int tsit5_dense_t(pdeopt_ctx* ctx, double theta, double dt, int env_first, int env_count, void* dev_out) {
+  double b[7];
+  tsit5_dense_weights(theta, b);
+  const int64_t o = (int64_t)env_first * (int64_t)ctx->env_elems;
+  LinComb<T> lc{};
+  lc.y = (const T*)ctx->Y + o;
+  lc.n = 7;
+  for (int j = 0; j < 7; ++j) {
+    lc.k[j] = (const T*)ctx->K[j] + o;
+    lc.c[j] = T(dt * b[j]);
+  }
+  lc.out = (T*)dev_out + o;
+  const int64_t total = (int64_t)ctx->env_elems * env_count;
+  const int blocks = (int)std::min<int64_t>((total + 255) / 256, 4096);
+  hipLaunchKernelGGL(lincomb_kernel<T>, dim3(blocks), dim3(256), 0, ctx->stream, lc, total);
+  PDEOPT_HIP_CHECK(ctx, hipGetLastError());
+  return PDEOPT_OK;
+}
+
+int tsit5_dense(pdeopt_ctx* ctx, double theta, double dt, int env_first, int env_count, void* dev_out) {
+  if (!ctx->tsit5_pending) return fail(ctx, PDEOPT_ESTATE, "dense output needs a pending Tsit5 trial step");
+  return ctx->prob.dtype == PDEOPT_F32 ? tsit5_dense_t<float>(ctx, theta, dt, env_first, env_count, dev_out)
+                                       : tsit5_dense_t<double>(ctx, theta, dt, env_first, env_count, dev_out);
+}
+
+// FSAL slope of environment b *= ratio[b] (its step size changed between two per-environment trials)
+int tsit5_rescale_fsal(pdeopt_ctx* ctx, const double* ratio) {
+  const size_t need = sizeof(double) * (size_t)ctx->prob.batch;
+  if (ctx->red_cap < need) {
+    if (ctx->red_dev) (void)hipFree(ctx->red_dev);
+    ctx->red_dev = nullptr;
+    ctx->red_cap = 0;
+    PDEOPT_HIP_CHECK(ctx, hipMalloc((void**)&ctx->red_dev, need));
+    ctx->red_cap = need;
+  }
+  PDEOPT_HIP_CHECK(ctx, hipMemcpyAsync(ctx->red_dev, ratio, need, hipMemcpyHostToDevice, ctx->stream));
+  const int64_t ee = (int64_t)ctx->env_elems;
+  const dim3 grid((unsigned)std::min<int64_t>((ee + 255) / 256, 1024), ctx->prob.batch);
+  if (ctx->prob.dtype == PDEOPT_F32)
+    hipLaunchKernelGGL(env_scale_kernel<float>, grid, dim3(256), 0, ctx->stream, (float*)ctx->K[0], (const double*)ctx->red_dev, ee);
+  else
+    hipLaunchKernelGGL(env_scale_kernel<double>, grid, dim3(256), 0, ctx->stream, (double*)ctx->K[0], (const double*)ctx->red_dev, ee);
+  PDEOPT_HIP_CHECK(ctx, hipGetLastError());
+  PDEOPT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));  // `ratio` is the caller's again
+  return PDEOPT_OK;
+}
+
+// per-environment commit: accepted environments take the candidate and its FSAL slope, the others keep theirs
+int tsit5_commit_env(pdeopt_ctx* ctx, const uint8_t* accept) {
+  if (!ctx->tsit5_pending) return fail(ctx, PDEOPT_ESTATE, "no Tsit5 trial step is pending");
+  ctx->tsit5_pending = false;
+  const int batch = ctx->prob.batch;
+  std::swap(ctx->Y, ctx->TB);
+  std::swap(ctx->K[0], ctx->K[6]);
+  const size_t eb = ctx->env_elems * ctx->esize;
+  for (int b = 0; b < batch; ++b) {
+    if (accept[b]) continue;
+    // rejected: the old state / slope (now in TB / K[6]) go back
+    PDEOPT_HIP_CHECK(ctx, hipMemcpyAsync((char*)ctx->Y + eb * b, (const char*)ctx->TB + eb * b, eb, hipMemcpyDeviceToDevice, ctx->stream));
+    PDEOPT_HIP_CHECK(ctx, hipMemcpyAsync((char*)ctx->K[0] + eb * b, (const char*)ctx->K[6] + eb * b, eb, hipMemcpyDeviceToDevice, ctx->stream));
+  }
+  ctx->tsit5_fsal_valid = true;
+  return PDEOPT_OK;
 }
 
 int tsit5_commit(pdeopt_ctx* ctx, int accept) {

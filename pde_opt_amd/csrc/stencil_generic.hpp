@@ -53,6 +53,7 @@ struct StageArgs {
   ClosureSpec fe;
   LcArgs<T> lc;  // OUT_K_LC only
   int out_mode, acc_mode;
+  int scaled;  // multiply k by EnvParams::kscale (per-environment step sizes of the adaptive driver)
   int dbg;  // timing ablations (PDEOPT_OPT_DEBUG_ABLATE): bit0 skip mu phase, bit1 skip flux phase
 };
 
@@ -186,7 +187,8 @@ __global__ __launch_bounds__(256) void stage_generic_kernel(const StageArgs<T> a
   if (i >= a.g.nx || j >= a.g.ny) return;
   const int64_t base = (int64_t)b * a.g.bstride + a.g.off;
   const EnvParams<T>& p = a.ep[b];
-  const T k = rhs_generic_point<T, EQ>(a, a.in + base, p, i, j, b);
+  T k = rhs_generic_point<T, EQ>(a, a.in + base, p, i, j, b);
+  if (a.scaled) k *= p.kscale;
   stage_update<T>(a, base + (int64_t)i * a.g.ld + j, k);
 }
 
@@ -241,7 +243,9 @@ __global__ __launch_bounds__(256) void ch3d_stage_kernel(const StageArgs<T> a) {
   const T kx = (flux(at(ip, j, k), a.rhx, true) - flux(at(im, j, k), a.rhx, false)) * a.rhx;
   const T ky = (flux(at(i, jp, k), a.rhy, true) - flux(at(i, jm, k), a.rhy, false)) * a.rhy;
   const T kz = (flux(at(i, j, kp), a.rhz, true) - flux(at(i, j, km), a.rhz, false)) * a.rhz;
-  stage_update<T>(a, base + c0, kx + ky + kz);
+  T kk = kx + ky + kz;
+  if (a.scaled) kk *= p.kscale;
+  stage_update<T>(a, base + c0, kk);
 }
 
 }  // namespace pdeopt

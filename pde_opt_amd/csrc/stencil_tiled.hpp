@@ -295,7 +295,8 @@ __global__ __launch_bounds__(RPT == 4 ? 512 : 256) void stage_tiled_kernel(const
   for (int r = 0; r < kRowsPerThread; ++r) {
     if (!cell_ok(r)) continue;
     const int64_t idx = pidx0 + r * ld;
-    const Vec k = kout[r];
+    Vec k = kout[r];
+    if (a.scaled) k = k * p.kscale;  // per-environment step size: the slope carries dt_b / dt_ref
     if constexpr (kNeedY && Y_FROM_TILE) {
       // the stage input IS y (stage 1 / Euler): take it from the LDS tile.  Not valid when the
       // mobility pass overwrote the tile in place.

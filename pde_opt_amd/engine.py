@@ -289,6 +289,19 @@ class HipEngine:
         self._check(self._lib.pdeopt_reduce(self._h, int(op), out.ctypes.data_as(C.c_void_p)))
         return out
 
+    def probe(self, cells, env_first: int = 0, env_count: Optional[int] = None) -> np.ndarray:
+        """State at grid cells ``cells`` ((n, 2) index pairs; (n, 3) for 3-D problems) of every environment of
+        the range: ``(envs, n)`` float64, ``(envs, n, 2)`` for the GPE -- a few numbers per environment cross
+        PCIe instead of the field."""
+        n = self.batch - env_first if env_count is None else env_count
+        nd = 3 if (self.problem.nz > 1) else 2
+        c = np.ascontiguousarray(np.asarray(cells, dtype=np.int32).reshape(-1, nd))
+        comps = 2 if self.problem.equation == L.EQ_GPE else 1
+        out = np.empty((n, c.shape[0], comps), dtype=np.float64)
+        self._check(self._lib.pdeopt_probe(self._h, c.ctypes.data_as(C.c_void_p), c.shape[0], int(env_first), int(n),
+                                           out.ctypes.data_as(C.c_void_p)))
+        return out if comps == 2 else out[..., 0]
+
     def observe_u8(self, lo: float, hi: float, env_first: int = 0, env_count: Optional[int] = None) -> np.ndarray:
         """uint8 frames ``rint(clip((x-lo)/(hi-lo), 0, 1) * 255)`` of shape (envs, nx, ny), quantised on the GPU"""
         n = self.batch - env_first if env_count is None else env_count
@@ -316,6 +329,32 @@ class HipEngine:
             self._lib.pdeopt_tsit5_trial(self._h, float(t), float(dt), float(rtol), float(atol), err.ctypes.data_as(C.c_void_p))
         )
         return err
+
+    def tsit5_trial_env(self, t: float, dts, rtol: float, atol: float):
+        """one trial step with a step size per environment (0 leaves an environment alone); returns
+        ``(err_norm[batch], dt_ref)`` -- pass ``dt_ref`` to ``tsit5_dense``"""
+        d = np.ascontiguousarray(np.asarray(dts, dtype=np.float64))
+        if d.shape != (self.batch,):
+            raise ValueError(f"one step size per environment: expected shape ({self.batch},), got {d.shape}")
+        err = np.empty(self.batch, dtype=np.float64)
+        ref = C.c_double()
+        self._check(self._lib.pdeopt_tsit5_trial_env(self._h, float(t), d.ctypes.data_as(C.c_void_p), float(rtol),
+                                                     float(atol), C.byref(ref), err.ctypes.data_as(C.c_void_p)))
+        return err, ref.value
+
+    def tsit5_commit_env(self, accept):
+        a = np.ascontiguousarray(np.asarray(accept, dtype=np.uint8))
+        if a.shape != (self.batch,):
+            raise ValueError(f"one flag per environment: expected shape ({self.batch},), got {a.shape}")
+        self._check(self._lib.pdeopt_tsit5_commit_env(self._h, a.ctypes.data_as(C.c_void_p)))
+
+    def tsit5_dense(self, theta: float, dt: float, env_first: int = 0, env_count: Optional[int] = None) -> np.ndarray:
+        """4th-order dense output ``y(t + theta dt)`` of the pending Tsit5 trial step (diffrax.Tsit5's interpolant)"""
+        n = self.batch - env_first if env_count is None else env_count
+        out = np.empty((n,) + self.state_shape, dtype=self.dtype)
+        self._check(self._lib.pdeopt_tsit5_dense(self._h, float(theta), float(dt), int(env_first), int(n),
+                                                 out.ctypes.data_as(C.c_void_p)))
+        return out
 
     def tsit5_commit(self, accept: bool):
         self._check(self._lib.pdeopt_tsit5_commit(self._h, int(bool(accept))))

@@ -9,7 +9,8 @@ numerics/solvers.py:48,91): steps never stop at save points.
 
 Adaptive stepping (``Tsit5`` + ``PIDController``): trial steps and the scaled RMS error norm run
 on the GPU (``pdeopt_tsit5_trial``); the scalar PID update runs here.  With a batch, all
-environments share the step (the controller sees the worst error norm).
+environments share the step (the controller sees the worst error norm).  ``Tsit5`` save points inside
+a step use its 4th-order dense output (``pdeopt_tsit5_dense``), as diffrax.Tsit5 does.
 """
 
 from __future__ import annotations
@@ -115,8 +116,27 @@ def diffeqsolve(
     def edge(i):  # time at the end of step i-1 / start of step i
         return t1 if i >= total_steps else t0 + i * dt
 
+    # Dense output inside a step: diffrax.Tsit5 evaluates its own 4th-order interpolant; Euler, RK4 and the
+    # reference's custom solvers (LocalLinearInterpolation, solvers.py:48,91) interpolate linearly between
+    # the step's end points.
+    tsit5 = solver.integrator == L.INT_TSIT5
     ts_out, ys_out = [], []
-    done = 0
+    done = 0          # steps completed (a pending Tsit5 trial counts once it is committed)
+    inside = None     # index (1-based end) of the step whose interior is being sampled
+
+    def finish_inside():
+        nonlocal done, inside
+        if inside is not None and tsit5:
+            eng.tsit5_commit(True)
+            done = inside
+        inside = None
+
+    def advance_to(k):
+        nonlocal done
+        finish_inside()
+        advance_steps(done, k - done)
+        done = k
+
     if saveat.t0:
         ts_out.append(t0)
         ys_out.append(take(eng.get_state()))
@@ -128,32 +148,62 @@ def diffeqsolve(
             else:
                 k_end = min(total_steps, max(1, int(math.ceil((tq - t0) / dt - 1e-9))))
             if k_end == 0 or abs(edge(k_end) - tq) <= 1e-12 * max(1.0, abs(tq)):
-                advance_steps(done, k_end - done)
-                done = k_end
+                advance_to(k_end)
                 ys_out.append(take(eng.get_state()))
             else:
-                advance_steps(done, (k_end - 1) - done)
-                done = k_end - 1
-                eng.snapshot()
-                advance_steps(done, 1)
-                done = k_end
                 a, b = edge(k_end - 1), edge(k_end)
-                ys_out.append(take(eng.get_interpolated((tq - a) / (b - a))))
+                if inside != k_end:  # first save point inside this step
+                    advance_to(k_end - 1)
+                    if tsit5:
+                        eng.tsit5_trial(a, b - a, 1.0, 1.0)  # stages only; committed by finish_inside()
+                    else:
+                        eng.snapshot()
+                        advance_steps(done, 1)
+                        done = k_end
+                    inside = k_end
+                th = (tq - a) / (b - a)
+                ys_out.append(take(eng.tsit5_dense(th, b - a) if tsit5 else eng.get_interpolated(th)))
             ts_out.append(tq)
     if saveat.t1 or saveat.ts is None:
-        advance_steps(done, total_steps - done)
-        done = total_steps
+        advance_to(total_steps)
         ts_out.append(t1)
         ys_out.append(take(eng.get_state()))
+    finish_inside()
     stats = {"num_steps": total_steps, "num_accepted_steps": total_steps, "num_rejected_steps": 0,
              "kernel": eng.last_kernel}
     return Solution(np.asarray(ts_out), np.stack(ys_out), stats)
 
 
+def _pid_update(c: PIDController, err: float, prev_inv: float, prev_prev_inv: float, order: float = 5.0):
+    """diffrax.PIDController's step-size factor for one scaled error norm: ``(keep, factor, 1/err)``"""
+    keep = bool(err < 1.0)  # NaN error norm rejects
+    inv = 1.0 / err if err > 0 and math.isfinite(err) else (np.inf if err == 0 else 0.0)
+    k1 = (c.icoeff + c.pcoeff + c.dcoeff) / order
+    k2 = -(c.pcoeff + 2 * c.dcoeff) / order
+    k3 = c.dcoeff / order
+    f = 1.0
+    for base, expo in ((inv, k1), (prev_inv, k2), (prev_prev_inv, k3)):
+        if expo != 0.0:
+            f *= (base**expo) if math.isfinite(base) and base > 0 else (c.factormax if base > 0 else c.factormin)
+    f = min(c.factormax, max(c.factormin, c.safety * f))
+    if not keep:
+        f = min(1.0, f)
+    return keep, f, inv
+
+
+def _clip_dt(c: PIDController, dt: float) -> float:
+    if c.dtmin is not None:
+        dt = max(dt, c.dtmin)
+    if c.dtmax is not None:
+        dt = min(dt, c.dtmax)
+    return dt
+
+
 def _solve_adaptive(eng, equation, solver, t0, t1, dt0, saveat, c: PIDController, max_steps, throw, take):
     if solver.integrator != L.INT_TSIT5:
         raise ValueError("PIDController needs an embedded pair: use Tsit5")
-    order = 5.0
+    if c.per_environment and eng.batch > 1:
+        return _solve_adaptive_per_env(eng, t0, t1, dt0, saveat, c, max_steps, throw, take)
     t, dt = t0, dt0
     accepted = rejected = 0
     ts_req = [float(v) for v in saveat.ts] if saveat.ts is not None else []
@@ -170,43 +220,82 @@ def _solve_adaptive(eng, equation, solver, t0, t1, dt0, saveat, c: PIDController
                 raise RuntimeError(f"max_steps={max_steps} reached at t={t}")
             break
         h = min(dt, t1 - t)
-        if qi < len(ts_req) and ts_req[qi] <= t + h + 1e-14 * max(1.0, abs(t + h)):
-            eng.snapshot()  # a save point falls inside this step: keep the start state for the interpolation
         err = float(np.max(eng.tsit5_trial(t, h, c.rtol, c.atol)))
-        keep = bool(err < 1.0)  # NaN error norm rejects
-        inv = 1.0 / err if err > 0 and math.isfinite(err) else (np.inf if err == 0 else 0.0)
-        k1 = (c.icoeff + c.pcoeff + c.dcoeff) / order
-        k2 = -(c.pcoeff + 2 * c.dcoeff) / order
-        k3 = c.dcoeff / order
-        f = 1.0
-        for base, expo in ((inv, k1), (prev_inv, k2), (prev_prev_inv, k3)):
-            if expo != 0.0:
-                f *= (base**expo) if math.isfinite(base) and base > 0 else (c.factormax if base > 0 else c.factormin)
-        f = min(c.factormax, max(c.factormin, c.safety * f))
-        if not keep:
-            f = min(1.0, f)
-        eng.tsit5_commit(keep)
+        keep, f, inv = _pid_update(c, err, prev_inv, prev_prev_inv)
         if keep:
             accepted += 1
             t_new = t + h
-            # dense output: linear between accepted step end points (the reference's custom
-            # solvers declare LocalLinearInterpolation; diffrax.Tsit5 ships a 4th-order
-            # interpolant -- documented deviation, O(h^2) at interior save points only)
+            # dense output from the accepted step's seven slopes, before the commit recycles them:
+            # diffrax.Tsit5's 4th-order interpolant (Tsitouras 2011, section 4)
             while qi < len(ts_req) and ts_req[qi] <= t_new + 1e-14 * max(1.0, abs(t_new)):
                 th = (ts_req[qi] - t) / h
-                ys_out.append(take(eng.get_interpolated(min(1.0, max(0.0, th)))))
+                ys_out.append(take(eng.tsit5_dense(min(1.0, max(0.0, th)), h)))
                 ts_out.append(ts_req[qi]); qi += 1
+        eng.tsit5_commit(keep)
+        if keep:
             t = t_new if t_new < t1 - 1e-14 * max(1.0, abs(t1)) else t1
             prev_prev_inv, prev_inv = prev_inv, inv
         else:
             rejected += 1
-        dt = h * f
-        if c.dtmin is not None:
-            dt = max(dt, c.dtmin)
-        if c.dtmax is not None:
-            dt = min(dt, c.dtmax)
+        dt = _clip_dt(c, h * f)
     if saveat.t1 or saveat.ts is None:
         ts_out.append(t); ys_out.append(take(eng.get_state()))
     stats = {"num_steps": accepted + rejected, "num_accepted_steps": accepted, "num_rejected_steps": rejected,
              "kernel": eng.last_kernel}
     return Solution(np.asarray(ts_out), np.stack(ys_out), stats)
+
+
+def _solve_adaptive_per_env(eng, t0, t1, dt0, saveat, c: PIDController, max_steps, throw, take):
+    """``PIDController(per_environment=True)``: every environment of the batch runs its own controller -- own
+    time, own step size, own accept / reject -- exactly as if it were solved alone, while the stages of all
+    environments still execute as one batched launch (``pdeopt_tsit5_trial_env``: slopes scaled by
+    dt_b / dt_ref).  Environments that have reached ``t1`` idle with dt = 0."""
+    B = eng.batch
+    t = np.full(B, t0)
+    dt = np.full(B, dt0)
+    prev_inv, prev_prev_inv = np.ones(B), np.ones(B)
+    accepted, rejected = np.zeros(B, dtype=int), np.zeros(B, dtype=int)
+    ts_req = [float(v) for v in saveat.ts] if saveat.ts is not None else []
+    n_t0 = sum(1 for v in ts_req if v <= t0)
+    y_start = eng.get_state()
+    slots = [[y_start[b]] * n_t0 + [None] * (len(ts_req) - n_t0) for b in range(B)]  # per environment, per save point
+    qi = np.full(B, n_t0)
+    eps1 = 1e-14 * max(1.0, abs(t1))
+    while np.any(t < t1):
+        active = t < t1
+        if max_steps is not None and np.any((accepted + rejected)[active] >= max_steps):
+            if throw:
+                raise RuntimeError(f"max_steps={max_steps} reached")
+            break
+        h = np.where(active, np.minimum(dt, t1 - t), 0.0)
+        err, h_ref = eng.tsit5_trial_env(float(t[active].min()), h, c.rtol, c.atol)
+        keep = np.zeros(B, dtype=bool)
+        for b in np.nonzero(active)[0]:
+            keep[b], f, inv = _pid_update(c, float(err[b]), prev_inv[b], prev_prev_inv[b])
+            if keep[b]:
+                accepted[b] += 1
+                t_new = t[b] + h[b]
+                while qi[b] < len(ts_req) and ts_req[qi[b]] <= t_new + 1e-14 * max(1.0, abs(t_new)):
+                    th = min(1.0, max(0.0, (ts_req[qi[b]] - t[b]) / h[b]))
+                    slots[b][qi[b]] = eng.tsit5_dense(th, h_ref, env_first=int(b), env_count=1)[0]
+                    qi[b] += 1
+                t[b] = t_new if t_new < t1 - eps1 else t1
+                prev_prev_inv[b], prev_inv[b] = prev_inv[b], inv
+            else:
+                rejected[b] += 1
+            dt[b] = _clip_dt(c, h[b] * f)
+        eng.tsit5_commit_env(keep)
+    y_end = eng.get_state()
+    for b in range(B):  # save points never reached (max_steps with throw=False): the last state, like diffrax's inf padding would not
+        for q in range(len(ts_req)):
+            if slots[b][q] is None:
+                slots[b][q] = np.full_like(y_end[b], np.nan)
+    ts_out = list(ts_req)
+    ys = [np.stack([slots[b][q] for b in range(B)]) for q in range(len(ts_req))]
+    if saveat.t0:
+        ts_out.insert(n_t0, t0); ys.insert(n_t0, y_start)
+    if saveat.t1 or saveat.ts is None:
+        ts_out.append(float(t.max())); ys.append(y_end)
+    stats = {"num_steps": int((accepted + rejected).max()), "num_accepted_steps": accepted.tolist(),
+             "num_rejected_steps": rejected.tolist(), "kernel": eng.last_kernel}
+    return Solution(np.asarray(ts_out), np.stack(ys), stats)

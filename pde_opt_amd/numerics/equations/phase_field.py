@@ -160,8 +160,9 @@ class AllenCahn2DPeriodic(BaseEquation):
 class CahnHilliard3DPeriodic(BaseEquation):
     """du/dt = div( D(u) grad( mu_h(u) - kappa lap u ) ) on a periodic 3-D box
     (pde_opt/numerics/equations/cahn_hilliard.py:113-200).  Fields are ``(Nx, Ny, Nz)`` (or batched
-    ``(B, Nx, Ny, Nz)``); ``rhs_fd`` runs in two HIP passes (csrc/stencil_generic.hpp, CH-3D), the IMEX
-    solver on rocFFT's 3-D real<->hermitian plans.  ``derivs="fourier"`` has no kernel."""
+    ``(B, Nx, Ny, Nz)``); ``rhs_fd`` runs in two HIP passes (csrc/stencil_generic.hpp, CH-3D), ``rhs_fourier``
+    (:167-175) on 9 batched rocFFT 3-D transforms with the pointwise operators between them
+    (csrc/spectral.hip), the IMEX solver on rocFFT's 3-D real<->hermitian plans."""
 
     domain: Domain
     kappa: float
@@ -198,7 +199,7 @@ class CahnHilliard3DPeriodic(BaseEquation):
         if self.derivs == "fd":
             self.rhs = self.rhs_fd
         elif self.derivs == "fourier":
-            raise NotImplementedError("CahnHilliard3DPeriodic: derivs=\"fourier\" has no HIP kernel (use \"fd\")")
+            self.rhs = self.rhs_fourier
         else:
             raise ValueError(f"Invalid derivative type: {self.derivs}")
 
@@ -208,7 +209,11 @@ class CahnHilliard3DPeriodic(BaseEquation):
         nx, ny, nz = self.domain.points
         hx, hy, hz = self.domain.dx
         return dict(equation=L.EQ_CAHN_HILLIARD_3D, nx=nx, ny=ny, nz=nz, hx=hx, hy=hy, hz=hz,
-                    kappa=float(self.kappa), mu=self._mu_desc, mob=self._mob_desc, derivs=L.DERIVS_FD)
+                    kappa=float(self.kappa), mu=self._mu_desc, mob=self._mob_desc,
+                    derivs=L.DERIVS_FOURIER if self.derivs == "fourier" else L.DERIVS_FD)
 
     def rhs_fd(self, state, t):
         return self._run_rhs(state, t)
+
+    def rhs_fourier(self, state, t):
+        return self._run_rhs(state, t)  # 9 batched rocFFT 3-D transforms (cahn_hilliard.py:167-175)

@@ -127,6 +127,9 @@ class PIDController:
     factormax: float = 10.0
     dtmin: Optional[float] = None
     dtmax: Optional[float] = None
+    # new (batched solves): every environment runs its own controller -- own step size, own accept / reject --
+    # instead of the whole batch stepping with the worst error norm (pdeopt_tsit5_trial_env)
+    per_environment: bool = False
 
 
 @dataclasses.dataclass

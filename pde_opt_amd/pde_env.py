@@ -184,7 +184,9 @@ class VectorPDEEnv:
     per environment on host copies unless ``device_reward`` names an on-device reduction
     (``"var"``, ``"mean"``, ``"min"``, ``"max"``), which avoids the D2H of full fields;
     ``device_observation=(lo, hi)`` additionally forms the uint8 image observations of the declared
-    observation space on the GPU (1 byte per cell crosses PCIe instead of 4 or 8).
+    observation space on the GPU (1 byte per cell crosses PCIe instead of 4 or 8);
+    ``device_observation=("probes", cells)`` returns the state at the listed grid cells instead (sensor-style
+    observations: ``(B, n_cells)`` float64, a few numbers per environment).
     """
 
     def __init__(
@@ -340,8 +342,13 @@ class VectorPDEEnv:
         if self.device_reward is not None:
             rewards = self._engine.reduce(self._RED[self.device_reward])
         if self.device_observation is not None and self.device_reward is not None:
-            lo, hi = self.device_observation
-            obs = self._engine.observe_u8(lo, hi)[:, None]  # (B, 1, nx, ny) uint8, as the declared space
+            if isinstance(self.device_observation[0], str):
+                if self.device_observation[0] != "probes":
+                    raise ValueError(f"unknown device observation {self.device_observation[0]!r}")
+                obs = self._engine.probe(self.device_observation[1])  # (B, n_cells): point sensors
+            else:
+                lo, hi = self.device_observation
+                obs = self._engine.observe_u8(lo, hi)[:, None]  # (B, 1, nx, ny) uint8, as the declared space
         elif self.fetch_observations or self.device_reward is None:
             self._state_host = self._engine.get_state()
             obs = np.stack([self.state_to_observation_func(s) for s in self._state_host])

@@ -136,6 +136,8 @@ class OracleEngine:
                     u = O.euler_step(f, t, u, dt)
                 elif integrator == L.INT_RK4:
                     u = O.rk4_step(f, t, u, dt)
+                elif integrator == L.INT_TSIT5:
+                    u = O.tsit5_step(f, t, u, dt)[0]
                 elif integrator == L.INT_IMEX:
                     u = O.imex_step(f, t, u, dt, self.imex_A, self.symbol)
                 elif integrator == L.INT_STRANG:
@@ -162,13 +164,37 @@ class OracleEngine:
         return self.snap[s] + theta * (self.y[s] - self.snap[s])
 
     def tsit5_trial(self, t, dt, rtol, atol):
-        self.pending, errs = [], []
+        self.pending, self.pending_ks, errs = [], [], []
         for b in range(self.batch):
-            y1, err, _ = O.tsit5_step(lambda tt, v, b=b: self._f(tt, v, b), t, self.y[b], dt)
+            y1, err, _, ks = O.tsit5_step(lambda tt, v, b=b: self._f(tt, v, b), t, self.y[b], dt, return_slopes=True)
+            self.pending_ks.append(ks)
             sc = atol + rtol * np.maximum(np.abs(self.y[b]), np.abs(y1))
             errs.append(np.sqrt(np.mean((err / sc) ** 2)))
             self.pending.append(y1)
         return np.asarray(errs)
+
+    def tsit5_trial_env(self, t, dts, rtol, atol):
+        """the ABI's scheme: slopes scaled by dt_b / dt_ref, shared coefficients dt_ref a_ij"""
+        dts = np.asarray(dts, dtype=float)
+        ref = float(dts.max())
+        self.pending, self.pending_ks, errs = [], [], []
+        for b in range(self.batch):
+            sc = dts[b] / ref
+            y1, err, _, ks = O.tsit5_step(lambda tt, v, b=b, sc=sc: sc * self._f(tt, v, b), t, self.y[b], ref, return_slopes=True)
+            self.pending_ks.append(ks)
+            scale = atol + rtol * np.maximum(np.abs(self.y[b]), np.abs(y1))
+            errs.append(np.sqrt(np.mean((err / scale) ** 2)))
+            self.pending.append(y1)
+        return np.asarray(errs), ref
+
+    def tsit5_commit_env(self, accept):
+        for b, a in enumerate(accept):
+            if a:
+                self.y[b] = self.pending[b]
+
+    def tsit5_dense(self, theta, dt, env_first=0, env_count=None):
+        n = self.batch - env_first if env_count is None else env_count
+        return np.stack([O.tsit5_dense(self.y[b], dt, self.pending_ks[b], theta) for b in range(env_first, env_first + n)])
 
     def tsit5_commit(self, accept):
         if accept:

@@ -97,10 +97,42 @@ def test_imex_3d_vs_oracle_and_pde_model(dtype):
     assert abs(sol[-1].astype(np.float64).mean() - y0.astype(np.float64).mean()) < (1e-14 if dtype is np.float64 else 2e-7)
 
 
+def test_rhs_fourier_against_reference_goldens(golden):
+    """CahnHilliard3DPeriodic.rhs_fourier (cahn_hilliard.py:167-175; 9 transforms) against goldens the
+    reference's own source produced (fp64: spectral constants are f64 in numpy)"""
+    z = golden("ch3d_fourier.npz")
+    tags = sorted(k[: -len("/rhs")] for k in z.files if k.endswith("/rhs"))
+    assert len(tags) == 3
+    for tag in tags:
+        nx, ny, nz = (int(v) for v in tag.split("_")[0].split("x"))
+        u, want = z[tag + "/u"], z[tag + "/rhs"]
+        eq = P.CahnHilliard3DPeriodic(_dom(nx, ny, nz), 0.002, MU["regsol"], MOB["c1mc"], derivs="fourier")
+        got = eq.rhs(u, 0.0)
+        assert got.dtype == want.dtype and got.shape == want.shape
+        assert rel_l2(got, want) < 1e-11, (tag, rel_l2(got, want))
+        assert "rhs_fourier<CH-3D>" in P.engine.default_engine().last_kernel
+        # fp32 state: against the same golden at fp32 accuracy of a 9-transform chain with k^4 amplification
+        got32 = eq.rhs(u.astype(np.float32), 0.0)
+        assert got32.dtype == np.float32 and rel_l2(got32, want) < 5e-4, rel_l2(got32, want)
+    # a batch equals its members, and the spectral RHS drives the explicit integrators
+    nx, ny, nz = 16, 12, 20
+    dom = _dom(nx, ny, nz)
+    eq = P.CahnHilliard3DPeriodic(dom, 0.002, MU["regsol"], MOB["c1mc"], derivs="fourier")
+    u = z["16x12x20_float64/u"]
+    ub = np.stack([u, np.clip(0.5 * u + 0.2, 0.05, 0.95)])
+    np.testing.assert_allclose(eq.rhs(ub, 0.0)[0], eq.rhs(u, 0.0), rtol=0, atol=1e-9 * np.abs(want).max())
+    hx, hy, hz = dom.dx
+    f = lambda t, v: O.ch3d_rhs_fourier(v, hx, hy, hz, 0.002, MU["regsol"], MOB["c1mc"])
+    sol = P.diffeqsolve(eq, P.RK4(), 0.0, 3e-8, 1e-8, ub)
+    for b in range(2):
+        ref = ub[b]
+        for i in range(3):
+            ref = O.rk4_step(f, 0.0, ref, 1e-8)
+        assert rel_l2(sol.ys[-1][b] - ub[b], ref - ub[b]) < 1e-9
+
+
 def test_errors():
     dom = _dom(8, 8, 8)
-    with pytest.raises(NotImplementedError, match="fourier"):
-        P.CahnHilliard3DPeriodic(dom, 0.002, MU["regsol"], MOB["c1mc"], derivs="fourier")
     with pytest.raises(ValueError, match="Invalid derivative type"):
         P.CahnHilliard3DPeriodic(dom, 0.002, MU["regsol"], MOB["c1mc"], derivs="spectral")
     with pytest.raises(ValueError, match="3-D"):

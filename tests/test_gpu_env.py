@@ -168,3 +168,45 @@ def test_detect_vortices_batched_counts_only():
     np.testing.assert_array_equal(counts2, counts[2:4])
     assert w2.shape == (2, n, n) and (np.count_nonzero(w2, axis=(1, 2)) == counts2[:, 0]).all()
     eng.close()
+
+
+def test_point_probes():
+    """pdeopt_probe: the state at listed grid cells for every environment"""
+    from pde_opt_amd import _lib as L
+
+    rng = np.random.default_rng(8)
+    cells = [(0, 0), (63, 127), (5, 17), (40, 3)]
+    for dtype in (np.float32, np.float64):
+        dom = std_domain(P, 64, 128)
+        eq = P.CahnHilliard2DPeriodic(dom, 0.002, MU["regsol"], MOB["c1mc"])
+        y = np.clip(0.5 + 0.1 * rng.standard_normal((5, 64, 128)), 0.05, 0.95).astype(dtype)
+        eng = P.HipEngine()
+        eng.configure(dtype=dtype, batch=5, **eq._engine_problem())
+        eng.set_state(y)
+        got = eng.probe(cells)
+        assert got.shape == (5, 4) and got.dtype == np.float64
+        np.testing.assert_array_equal(got, np.stack([y[:, i, j] for i, j in cells], axis=1).astype(np.float64))
+        np.testing.assert_array_equal(eng.probe(cells[1:3], env_first=2, env_count=2), got[2:4, 1:3])
+        with pytest.raises(ValueError, match="outside"):
+            eng.probe([(64, 0)])
+        eng.close()
+    # GPE: (re, im) per probe; 3-D: (i, j, k) triples
+    eng = P.HipEngine()
+    eng.configure(equation=L.EQ_GPE, dtype=np.float32, nx=32, ny=16, batch=2, hx=1.0, hy=1.0)
+    psi = rng.standard_normal((2, 32, 16, 2)).astype(np.float32)
+    eng.set_state(psi)
+    np.testing.assert_array_equal(eng.probe([(3, 4), (31, 15)]), psi[:, [3, 31], [4, 15]].astype(np.float64))
+    eq3 = P.CahnHilliard3DPeriodic(P.Domain((8, 6, 10), ((0, 1), (0, 1), (0, 1)), "d"), 0.002, MU["regsol"], MOB["c1mc"])
+    u3 = rng.uniform(0.1, 0.9, size=(2, 8, 6, 10))
+    eng.configure(dtype=np.float64, batch=2, **eq3._engine_problem())
+    eng.set_state(u3)
+    np.testing.assert_array_equal(eng.probe([(7, 5, 9), (0, 2, 3)]), np.stack([u3[:, 7, 5, 9], u3[:, 0, 2, 3]], axis=1))
+    eng.close()
+    # as the observation of a vector environment
+    dom = std_domain(P, 64, 128)
+    venv = P.VectorPDEEnv(2, **_env_kwargs(dom), device_reward="var", device_observation=("probes", cells))
+    venv.reset(seed=1)
+    obs, rewards, _, _, _ = venv.step([1, 1])
+    st = venv.states
+    np.testing.assert_array_equal(obs, np.stack([st[:, i, j] for i, j in cells], axis=1).astype(np.float64))
+    venv.close()

@@ -309,6 +309,62 @@ def test_1d_allen_cahn_tanh_tsit5_pid():
     assert sol.stats["num_accepted_steps"] > 10
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_tsit5_dense_output_vs_oracle(dtype):
+    """pdeopt_tsit5_dense: the 4th-order interpolant of diffrax.Tsit5 at SaveAt points inside a step (several per
+    step), fixed and adaptive stepping, batched; against the oracle's restatement of Tsitouras' section 4"""
+    rng = np.random.default_rng(14)
+    dom = std_domain(P, 64, 128)
+    eq = P.CahnHilliard2DPeriodic(dom, 0.002, MU["regsol"], MOB["c1mc"])
+    y0 = np.clip(0.5 + 0.05 * rng.standard_normal((2, 64, 128)), 0.05, 0.95).astype(dtype)
+    hx, hy = dom.dx
+    f = lambda t, u: O.ch_rhs_fd(u, hx, hy, 0.002, MU["regsol"], MOB["c1mc"])
+    dt = 2e-7
+    ts = [0.0, 0.2 * dt, 0.7 * dt, 1.6 * dt, 1.9 * dt, 2 * dt, 3 * dt]
+    sol = P.diffeqsolve(eq, P.Tsit5(), ts[0], ts[-1], dt, y0, saveat=P.SaveAt(ts=ts))
+    for b in range(2):
+        y, out = y0[b].astype(np.float64), [y0[b].astype(np.float64)]
+        for i, inner in enumerate(([0.2, 0.7], [0.6, 0.9], [])):
+            y1, _, _, ks = O.tsit5_step(f, i * dt, y, dt, return_slopes=True)
+            out += [O.tsit5_dense(y, dt, ks, th) for th in inner]
+            y = y1
+            if i >= 1:
+                out.append(y)
+        want = np.stack(out)
+        inc, inc_ref = sol.ys[:, b].astype(np.float64) - y0[b], want - y0[b]
+        assert rel_l2(inc[1:], inc_ref[1:]) < (1e-10 if dtype is np.float64 else 5e-3), rel_l2(inc[1:], inc_ref[1:])
+        assert np.max(np.abs(sol.ys[:, b] - want)) < (1e-13 if dtype is np.float64 else 5e-7)
+
+
+@pytest.mark.parametrize("shape", [(48, 1), (64, 128)])
+def test_per_environment_step_sizes_equal_solo_solves(shape):
+    """pdeopt_tsit5_trial_env / commit_env: each environment of a batch steps as it would alone (generic and
+    LDS-tiled stage kernels); slopes are stored scaled by dt_b / dt_ref, so results agree to rounding"""
+    nx, ny = shape
+    dom = std_domain(P, nx, ny)
+    eq = P.AllenCahn2DPeriodic(dom, 0.002, lambda c: c**3 - c, lambda c: np.ones_like(c))
+    u = np.ones((nx, ny))
+    u[: nx // 2] = -1.0
+    rng = np.random.default_rng(9)
+    y0 = np.stack([u, 0.05 * rng.standard_normal((nx, ny)), 0.9 * u + 0.3 * rng.standard_normal((nx, ny))])
+    ts = [0.0, 0.013, 0.05, 0.2]
+    ctl = dict(rtol=1e-5, atol=1e-7)
+    eng = P.HipEngine()
+    solo = [P.diffeqsolve(eq, P.Tsit5(), 0.0, 0.2, 1e-4, y0[b], saveat=P.SaveAt(ts=ts),
+                          stepsize_controller=P.PIDController(**ctl), engine=eng) for b in range(3)]
+    both = P.diffeqsolve(eq, P.Tsit5(), 0.0, 0.2, 1e-4, y0, saveat=P.SaveAt(ts=ts),
+                         stepsize_controller=P.PIDController(**ctl, per_environment=True), engine=eng)
+    for b in range(3):
+        np.testing.assert_allclose(both.ys[:, b], solo[b].ys, rtol=0, atol=1e-10)
+        assert abs(both.stats["num_accepted_steps"][b] - solo[b].stats["num_accepted_steps"]) <= 1
+    assert len(set(both.stats["num_accepted_steps"])) > 1
+    # a uniform trial after per-environment ones recomputes the FSAL slope (it carried per-environment scales)
+    again = P.diffeqsolve(eq, P.Tsit5(), 0.0, 0.2, 1e-4, y0[1], saveat=P.SaveAt(ts=ts),
+                          stepsize_controller=P.PIDController(**ctl), engine=eng)
+    np.testing.assert_array_equal(again.ys, solo[1].ys)
+    eng.close()
+
+
 def test_tsit5_fixed_step_vs_oracle():
     rng = np.random.default_rng(4)
     dom = std_domain(P, 32, 32)

@@ -118,3 +118,100 @@ def test_smoothed_boundary_host_wiring():
         P.AllenCahn2DSmoothedBoundary(dom, 1.5, SBM_F, MU["regsol"], MOB["c1mc"], SBM_THETA, derivs="fourier")
     with pytest.raises(ValueError, match="geometry"):
         P.AllenCahn2DSmoothedBoundary(std_domain(P, 8, 8), 1.5, SBM_F, MU["regsol"], MOB["c1mc"], SBM_THETA)
+
+
+def test_tsit5_dense_output_weights_and_order():
+    """The 4th-order continuous extension of Tsitouras' pair (the interpolant diffrax.Tsit5 evaluates at
+    SaveAt points inside a step): b_i(1) are the 5th-order weights, b_i(0) = 0, the quadrature conditions
+    sum b_i c_i^q = theta^(q+1)/(q+1) hold for q = 0..3, and the local error at mid-step falls as h^5."""
+    C = np.array((0.0,) + O._TS_C)
+    np.testing.assert_allclose(O.tsit5_dense_weights(1.0), O._TS_B, rtol=0, atol=2e-15)
+    np.testing.assert_array_equal(O.tsit5_dense_weights(0.0), np.zeros(7))
+    for th in (0.1, 0.37, 0.5, 0.93):
+        b = np.array(O.tsit5_dense_weights(th))
+        for q in range(4):
+            assert abs((b * C**q).sum() - th ** (q + 1) / (q + 1)) < 1e-14
+    f = lambda t, y: -y + np.sin(3 * t)
+    exact = lambda t: 0.1 * (np.sin(3 * t) - 3 * np.cos(3 * t)) + 1.3 * np.exp(-t)  # y' = -y + sin 3t, y(0) = 1
+    errs = []
+    for h in (0.2, 0.1, 0.05):
+        y0 = np.array([exact(0.0)])
+        _, _, _, ks = O.tsit5_step(f, 0.0, y0, h, return_slopes=True)
+        errs.append(abs(O.tsit5_dense(y0, h, ks, 0.5)[0] - exact(0.5 * h)))
+    assert errs[0] / errs[1] > 24 and errs[1] / errs[2] > 24, errs  # ~2^5
+
+
+def test_saveat_several_points_inside_one_step():
+    """two save points inside the same step, then one in the next: the step is taken once (RK4: linear dense
+    output; Tsit5: its 4th-order interpolant, as diffrax)"""
+    dom, eq = _ac()
+    y0 = 0.1 * np.random.default_rng(4).standard_normal(dom.points)
+    hx, hy = dom.dx
+    f = lambda t, u: O.ac_rhs_fd(u, hx, hy, 0.002, MU["cubic"], MOB["one"])
+    dt = 1e-4
+    ts = [0.0, 0.2e-4, 0.7e-4, 1.6e-4, 1.9e-4, 2e-4, 3e-4]
+    eng = OracleEngine()
+    sol = P.diffeqsolve(eq, P.RK4(), ts[0], ts[-1], dt, y0, saveat=P.SaveAt(ts=ts), engine=eng)
+    want = O.solve_saveat(lambda t, y, h: O.rk4_step(f, t, y, h), y0, ts, dt)
+    np.testing.assert_allclose(sol.ys, want, rtol=0, atol=1e-15)
+    assert sum(c[3] for c in eng.calls if c[0] == "advance") == 3  # three steps in total, none repeated
+    sol = P.diffeqsolve(eq, P.Tsit5(), ts[0], ts[-1], dt, y0, saveat=P.SaveAt(ts=ts), engine=OracleEngine())
+    y, out = y0, [y0]
+    for i, inner in enumerate(([0.2, 0.7], [0.6, 0.9], [])):
+        y1, _, _, ks = O.tsit5_step(f, i * dt, y, dt, return_slopes=True)
+        out += [O.tsit5_dense(y, dt, ks, th) for th in inner]
+        y = y1
+        if i >= 1:
+            out.append(y)
+    np.testing.assert_allclose(sol.ys, np.stack(out), rtol=0, atol=1e-15)
+
+
+def test_adaptive_tsit5_interior_save_points_are_fourth_order():
+    """tests/test_solvers.py:64-104 saves 200 interior points under Tsit5 + PIDController; here the interior
+    points of a coarse adaptive solve are compared with a fine fixed-step solve: the 4th-order dense output
+    keeps them at the accuracy of the steps themselves (linear interpolation would be off by O(h^2))."""
+    nx = 48
+    dom = std_domain(P, nx, 1)
+    eq = P.AllenCahn2DPeriodic(dom, 0.002, lambda c: c**3 - c, lambda c: np.ones_like(c))
+    u0 = np.ones((nx, 1))
+    u0[: nx // 2] = -1.0
+    ts = np.linspace(0.0, 0.5, 41)
+    sol = P.diffeqsolve(eq, P.Tsit5(), 0.0, 0.5, 5e-5, u0, saveat=P.SaveAt(ts=ts),
+                        stepsize_controller=P.PIDController(rtol=1e-6, atol=1e-8), engine=OracleEngine())
+    assert sol.stats["num_accepted_steps"] < 4 * len(ts)  # several save points per step do occur
+    hx, hy = dom.dx
+    f = lambda t, u: O.ac_rhs_fd(u, hx, hy, 0.002, lambda c: c**3 - c, lambda c: np.ones_like(c))
+    ref, y, k = [u0], u0, 0
+    for i in range(1, 2001):  # fine reference: 2000 RK4 steps of 2.5e-4
+        y = O.rk4_step(f, 0.0, y, 2.5e-4)
+        if i % 50 == 0:
+            ref.append(y)
+    err = np.max(np.abs(sol.ys - np.stack(ref)))
+    assert err < 2e-5, err
+
+
+def test_per_environment_step_sizes_equal_solo_solves():
+    """PIDController(per_environment=True): each environment of a batch takes the steps it would take alone
+    (per-env error norm AND per-env dt); the default shares the worst-case step."""
+    nx = 48
+    dom = std_domain(P, nx, 1)
+    eq = P.AllenCahn2DPeriodic(dom, 0.002, lambda c: c**3 - c, lambda c: np.ones_like(c))
+    u = np.ones((nx, 1))
+    u[: nx // 2] = -1.0
+    rng = np.random.default_rng(9)
+    y0 = np.stack([u, 0.05 * rng.standard_normal((nx, 1)), 0.9 * u + 0.3 * rng.standard_normal((nx, 1))])
+    ts = [0.0, 0.013, 0.05, 0.2]
+    ctl = dict(rtol=1e-5, atol=1e-7)
+    solo = [P.diffeqsolve(eq, P.Tsit5(), 0.0, 0.2, 1e-4, y0[b], saveat=P.SaveAt(ts=ts),
+                          stepsize_controller=P.PIDController(**ctl), engine=OracleEngine()) for b in range(3)]
+    both = P.diffeqsolve(eq, P.Tsit5(), 0.0, 0.2, 1e-4, y0, saveat=P.SaveAt(ts=ts),
+                         stepsize_controller=P.PIDController(**ctl, per_environment=True), engine=OracleEngine())
+    assert both.ys.shape == (4, 3, nx, 1)
+    for b in range(3):
+        np.testing.assert_allclose(both.ys[:, b], solo[b].ys, rtol=0, atol=1e-12)
+        assert both.stats["num_accepted_steps"][b] == solo[b].stats["num_accepted_steps"]
+        assert both.stats["num_rejected_steps"][b] == solo[b].stats["num_rejected_steps"]
+    assert len(set(both.stats["num_accepted_steps"])) > 1  # the environments really do step differently
+    shared = P.diffeqsolve(eq, P.Tsit5(), 0.0, 0.2, 1e-4, y0, saveat=P.SaveAt(ts=ts),
+                           stepsize_controller=P.PIDController(**ctl), engine=OracleEngine())
+    assert shared.stats["num_accepted_steps"] >= max(both.stats["num_accepted_steps"])
