@@ -217,6 +217,111 @@ def api_throughput(P, name, rank, steps, warmup):
                    f"(1 byte/cell D2H), {steps} steps after {warmup} warm-up, one GPU"}
 
 
+DECOMP_GRIDS = {1: (1, 1), 2: (2, 1), 4: (2, 2), 8: (4, 2)}
+
+
+def run_decomp(args, P, world, rank, local_rank, dist):
+    """--workload ch_rk4_4096_decomp (BASELINE config 5): ONE Cahn-Hilliard field of 4096^2 cells, RK4 dt 2e-7,
+    decomposed over px x py GPUs (1x1, 2x1, 2x2, 4x2 for N = 1, 2, 4, 8) with an RCCL all-gather of packed halo
+    strips per fused stage pair (pde_opt_amd/decomp.py: the collective overlaps the interior tiles, substep pairs
+    replay from a device graph).  A step = 100 substeps of the one field; strong scaling (the field is fixed)."""
+    from pde_opt_amd.decomp import CartesianGrid, DecomposedSolver, NativeComm, TorchComm
+
+    n, dt, substeps = args.decomp_grid, 2e-7, 100
+    if world not in DECOMP_GRIDS:
+        raise SystemExit(f"ch_rk4_4096_decomp runs on {sorted(DECOMP_GRIDS)} GPUs, not {world}")
+    px, py = DECOMP_GRIDS[world]
+    dom = P.Domain((n, n), ((-0.005 * n, 0.005 * n),) * 2, "dimensionless")
+    eq = P.CahnHilliard2DPeriodic(dom, 0.002, REGSOL, C1MC)
+    grid = CartesianGrid(px, py, rank)
+    # under torchrun: the library's own RCCL communicator and in-library substep loop (auto / native); the torch
+    # all-gather drivers stay selectable for comparison
+    native = args.decomp_mode in ("auto", "native", "native-overlap")
+    comm = None if dist is None else (NativeComm() if native else TorchComm())
+    sol = DecomposedSolver(eq, grid, comm=comm, dtype=np.float32, device=local_rank)
+    sol.use_overlap = args.decomp_mode in ("native-overlap", "overlap", "graph")
+    sol.use_graph = args.decomp_mode == "graph"
+    rng = np.random.default_rng(0)  # every rank draws the same global field and keeps its tile
+    y0 = np.clip(0.5 + 0.01 * rng.standard_normal((n, n)), 0.05, 0.95).astype(np.float32)
+    sol.set_global_state(y0)
+    eng = sol.backend.engine
+
+    def barrier():
+        eng.sync()
+        if dist is not None:
+            import torch
+
+            torch.cuda.synchronize()
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        sol.advance(dt, substeps)
+    barrier()
+    launches0 = eng.stage_launches()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        sol.advance(dt, substeps)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    launches = eng.stage_launches() - launches0
+    if dist is not None:
+        import torch
+
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt[0])
+    tile = sol.local_state()
+    spot = None
+    if rank == 0 and not args.no_parity_spot:
+        # rank 0's tile after a few fresh substeps against the C oracle run on the WHOLE periodic field
+        from oracle import c_oracle as CO
+
+        nspot = 7  # through the same driver path as the timed loop (graph-replayed pairs + one eager substep)
+        sol.set_global_state(y0)
+        sol.advance(dt, nspot)
+        barrier_local = eng.sync()
+        got = sol.local_state().astype(np.float64)
+        _, cmu, cmob = _oracle_closures(WORKLOADS["ch_rk4_1024_f32"])
+        ref = CO.rk4(0, y0, dom.dx[0], dom.dx[1], 0.002, cmu, cmob, dt, nspot, threads=usable_cores()).astype(np.float64)
+        si, sj = grid.tile_slices(n, n)
+        base = y0[si, sj].astype(np.float64)
+        rel = float(np.linalg.norm((got - base) - (ref[si, sj] - base)) / np.linalg.norm(ref[si, sj] - base))
+        spot = {"parity_spot_rel_err": rel, "parity_spot_max_abs_err": float(np.max(np.abs(got - ref[si, sj]))),
+                "parity_spot_tol": 2e-3, "parity_spot_ok": bool(rel < 2e-3),
+                "parity_spot": f"rank 0's {got.shape[0]}x{got.shape[1]} tile after {nspot} substeps ({sol.mode}) vs oracle/c_oracle.c on the whole periodic field"}
+    if dist is not None and world > 1:
+        dist.barrier()
+    if rank == 0:
+        total_bytes = WORDS["rk4"] * 4 * n * n * substeps * args.steps
+        line = {
+            "metric": "env-steps/sec (ch_rk4_4096_decomp: one 4096^2 field, 100 substeps/env-step) & achieved HBM GB/s",
+            "value": args.steps / elapsed, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "ch_rk4_4096_decomp", "grid": [n, n], "tiles": [px, py], "tile": list(sol.tile_shape),
+                       "integrator": "rk4", "dt": dt, "substeps_per_env_step": substeps, "halo": 4,
+                       "exchange": "one all-gather of packed halo strips per fused stage pair (2 per substep)",
+                       "strip_bytes": int(sol.backend.strip_elems) * 4, "driver_mode": sol.mode, "kernel": eng.last_kernel},
+            "substeps_per_s": args.steps * substeps / elapsed, "us_per_substep": 1e6 * elapsed / (args.steps * substeps),
+            "achieved_gbs_whole_job": total_bytes / elapsed / 1e9,
+            "nonfinite_cells": float(np.size(tile) - np.isfinite(tile).sum()),
+            **(spot or {}),
+            "roofline": {"bound": "hbm", "achieved": total_bytes / elapsed / 1e9 / world, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": total_bytes / elapsed / 1e9 / world / HBM_PEAK_GBS, "traffic": None,
+                         "launches_timed": launches,
+                         "note": "per-GPU share of SURVEY 8(d)'s algorithmic bytes over the WALL time of the substep loop "
+                                 "(exchange latency included: this row is latency-bound by design, DESIGN.md section 6)"},
+        }
+        print(json.dumps(line))
+        sys.stdout.flush()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    eng.close()
+    if spot is not None and not spot["parity_spot_ok"]:
+        raise SystemExit(f"parity spot check FAILED: {spot}")
+
+
 def usable_cores():
     """host cores this process may use: the affinity mask, clipped by the cgroup CPU quota (a GPU box hands
     one GPU's job a share of the host, not all of os.cpu_count())"""
@@ -348,7 +453,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="ch_rk4_1024_f32", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="ch_rk4_1024_f32", choices=sorted(WORKLOADS) + ["ch_rk4_4096_decomp"])
     ap.add_argument("--batch-per-gpu", type=int, default=0)
     ap.add_argument("--kernel-path", type=int, default=0, help="0 auto, 1 generic, 2 tiled")
     ap.add_argument("--tile-rows", type=int, default=0, help="0 auto, 16 or 32")
@@ -358,6 +463,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity-spot", action="store_true")
     ap.add_argument("--no-api", action="store_true", help="skip the VectorPDEEnv.step throughput leg")
+    ap.add_argument("--decomp-mode", default="auto", choices=["auto", "native", "native-overlap", "plain", "overlap", "graph"],
+                    help="ch_rk4_4096_decomp: driver path (auto = native: the library's own RCCL communicator, substep "
+                         "loop in C; native-overlap: + collective on a second stream under the interior tiles; "
+                         "plain / overlap / graph = torch all-gather drivers)")
+    ap.add_argument("--decomp-grid", type=int, default=4096, help="ch_rk4_4096_decomp: cells per side of the one field")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
 
@@ -390,6 +500,8 @@ def main():
     import pde_opt_amd as P
     from pde_opt_amd import _lib as L
 
+    if args.workload == "ch_rk4_4096_decomp":
+        return run_decomp(args, P, world, rank, local_rank, dist)
     w = WORKLOADS[args.workload]
     batch = args.batch_per_gpu or w["batch"]
     eq, y0, solver = make_problem(P, args.workload, batch, rank)

@@ -275,6 +275,31 @@ int pdeopt_halo_pack(pdeopt_ctx* ctx, int field, void* dev_send);
 int pdeopt_halo_unpack(pdeopt_ctx* ctx, int field, const void* dev_recv, const int* neighbours);
 int pdeopt_rk4_phase_plan(pdeopt_ctx* ctx, int* fields /* [4] */, int* nphases);
 int pdeopt_rk4_phase(pdeopt_ctx* ctx, int phase, double dt);
+/* The same phase split in two launches so that the halo exchange can be in flight while most of the tile is
+ * computed: part 1 = the INTERIOR workgroup tiles (they read no halo cell), part 2 = the EDGE tiles (first / last
+ * tile row and column), part 0 = everything (== pdeopt_rk4_phase).  Per phase:
+ *     pack(field) -> [all-gather on a second stream]  ||  rk4_phase_part(phase, dt, 1)
+ *     -> unpack(field) -> rk4_phase_part(phase, dt, 2)
+ * Fused stage pairs only (pdeopt_rk4_phase_plan reports 2 phases); the substep's buffer rotation happens with
+ * part 2 (or 0) of the last phase. */
+typedef enum { PDEOPT_PART_ALL = 0, PDEOPT_PART_INTERIOR = 1, PDEOPT_PART_EDGE = 2 } pdeopt_tile_part;
+int pdeopt_rk4_phase_part(pdeopt_ctx* ctx, int phase, double dt, int part);
+/* n RK4 substeps of a SINGLE-RANK padded tile, loop-back halo exchange included, in one call (every neighbour
+ * is the tile itself: the periodic problem in the decomposed layout; one rank's share of the decomposed
+ * driver without the collective). */
+int pdeopt_rk4_loopback_advance(pdeopt_ctx* ctx, double dt, int64_t n_substeps);
+/* The whole decomposed substep loop inside the library, on an RCCL communicator of its own: one process per
+ * GPU, the host language only carries rank 0's 128-byte id to the other ranks (pdeopt_comm_unique_id ->
+ * broadcast by any means -> pdeopt_comm_init on every rank's ctx).  pdeopt_rk4_decomposed_advance then runs
+ * n substeps of   pack -> ncclAllGather of strips -> unpack -> phase   with no host round trip per substep;
+ * overlap != 0 puts the collective on a second HIP stream and computes the interior tiles of the phase while
+ * it is in flight (fused stage pairs).  RCCL is resolved at run time (dlopen of the librccl.so the process
+ * already uses), the library has no link-time dependency on it. */
+int pdeopt_comm_unique_id(char out[128]);
+int pdeopt_comm_init(pdeopt_ctx* ctx, int world, int rank, const char id[128]);
+int pdeopt_comm_destroy(pdeopt_ctx* ctx);
+int pdeopt_rk4_decomposed_advance(pdeopt_ctx* ctx, double dt, int64_t n_substeps, const int* neighbours /* [8] */,
+                                  int overlap);
 /* ctx whose work is ordered on a caller-owned HIP stream (e.g. torch's current stream, so RCCL
  * collectives issued through torch.distributed order with the kernels without host syncs) */
 int pdeopt_ctx_create_on_stream(int device, void* hip_stream, pdeopt_ctx** out);

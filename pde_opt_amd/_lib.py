@@ -43,6 +43,7 @@ CNT_LAST_GROUPS = 1
 COPY_H2D, COPY_D2H, COPY_D2D = 0, 1, 2
 FIELD_Y, FIELD_TA, FIELD_TB, FIELD_ACC = 0, 1, 2, 3
 PATH_AUTO, PATH_GENERIC, PATH_TILED = 0, 1, 2
+PART_ALL, PART_INTERIOR, PART_EDGE = 0, 1, 2
 
 
 class HipUnavailableError(RuntimeError):
@@ -135,6 +136,12 @@ _SIGNATURES = {
     "pdeopt_halo_unpack": (C.c_int, [_VP, C.c_int, _VP, C.POINTER(C.c_int)]),
     "pdeopt_rk4_phase_plan": (C.c_int, [_VP, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "pdeopt_rk4_phase": (C.c_int, [_VP, C.c_int, C.c_double]),
+    "pdeopt_rk4_phase_part": (C.c_int, [_VP, C.c_int, C.c_double, C.c_int]),
+    "pdeopt_rk4_loopback_advance": (C.c_int, [_VP, C.c_double, C.c_int64]),
+    "pdeopt_comm_unique_id": (C.c_int, [C.c_char_p]),
+    "pdeopt_comm_init": (C.c_int, [_VP, C.c_int, C.c_int, C.c_char_p]),
+    "pdeopt_comm_destroy": (C.c_int, [_VP]),
+    "pdeopt_rk4_decomposed_advance": (C.c_int, [_VP, C.c_double, C.c_int64, C.POINTER(C.c_int), C.c_int]),
     "pdeopt_ctx_create_on_stream": (C.c_int, [C.c_int, _VP, C.POINTER(_VP)]),
     "pdeopt_buffer_alloc": (C.c_int, [_VP, C.c_int64, C.POINTER(_VP)]),
     "pdeopt_buffer_free": (C.c_int, [_VP, _VP]),

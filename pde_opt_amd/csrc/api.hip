@@ -219,6 +219,7 @@ int pdeopt_ctx_destroy(pdeopt_ctx* ctx) {
   if (!ctx) return PDEOPT_OK;
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  comm_destroy(ctx);
   free_fields(ctx);
   if (ctx->red_dev) (void)hipFree(ctx->red_dev);
   if (ctx->red_mean_dev) (void)hipFree(ctx->red_mean_dev);
@@ -786,7 +787,49 @@ int pdeopt_rk4_phase(pdeopt_ctx* ctx, int phase, double dt) {
   if (!ctx) return PDEOPT_EINVAL;
   if (!ctx->configured) return fail(ctx, PDEOPT_ESTATE, "pdeopt_configure has not been called");
   PDEOPT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-  return rk4_phase(ctx, phase, dt);
+  return rk4_phase(ctx, phase, dt, 0);
+}
+
+int pdeopt_rk4_phase_part(pdeopt_ctx* ctx, int phase, double dt, int part) {
+  if (!ctx) return PDEOPT_EINVAL;
+  if (!ctx->configured) return fail(ctx, PDEOPT_ESTATE, "pdeopt_configure has not been called");
+  PDEOPT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  return rk4_phase(ctx, phase, dt, part);
+}
+
+int pdeopt_comm_unique_id(char out[128]) {
+  if (!out) return PDEOPT_EINVAL;
+  return comm_unique_id(nullptr, out);
+}
+
+int pdeopt_comm_init(pdeopt_ctx* ctx, int world, int rank, const char id[128]) {
+  if (!ctx || !id) return PDEOPT_EINVAL;
+  if (world < 1 || rank < 0 || rank >= world) return fail(ctx, PDEOPT_EINVAL, "rank %d of %d", rank, world);
+  PDEOPT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  return comm_init(ctx, world, rank, id);
+}
+
+int pdeopt_comm_destroy(pdeopt_ctx* ctx) {
+  if (!ctx) return PDEOPT_EINVAL;
+  PDEOPT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  comm_destroy(ctx);
+  return PDEOPT_OK;
+}
+
+int pdeopt_rk4_decomposed_advance(pdeopt_ctx* ctx, double dt, int64_t n_substeps, const int* neighbours, int overlap) {
+  if (!ctx || !neighbours) return PDEOPT_EINVAL;
+  if (!ctx->configured || !ctx->halo) return fail(ctx, PDEOPT_ESTATE, "no padded layout is configured");
+  if (n_substeps < 0) return fail(ctx, PDEOPT_EINVAL, "n_substeps < 0");
+  PDEOPT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  return rk4_decomposed_advance(ctx, dt, n_substeps, neighbours, overlap);
+}
+
+int pdeopt_rk4_loopback_advance(pdeopt_ctx* ctx, double dt, int64_t n_substeps) {
+  if (!ctx) return PDEOPT_EINVAL;
+  if (!ctx->configured || !ctx->halo) return fail(ctx, PDEOPT_ESTATE, "no padded layout is configured");
+  if (n_substeps < 0) return fail(ctx, PDEOPT_EINVAL, "n_substeps < 0");
+  PDEOPT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  return rk4_loopback_advance(ctx, dt, n_substeps);
 }
 
 int pdeopt_ctx_create_on_stream(int device, void* hip_stream, pdeopt_ctx** out) {

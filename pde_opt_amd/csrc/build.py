@@ -22,7 +22,7 @@ ROOT = os.path.dirname(PKG)
 LIB = os.path.join(PKG, "libpdeopt_hip.so")
 OBJ_DIR = os.path.join(HERE, "build")
 
-SOURCES = ["api.hip", "stencil.hip", "reduce.hip", "spectral.hip", "halo.hip", "strang_fused.hip"]
+SOURCES = ["api.hip", "stencil.hip", "reduce.hip", "spectral.hip", "halo.hip", "strang_fused.hip", "comm.hip"]
 
 
 def _headers() -> list[str]:
@@ -83,7 +83,7 @@ def _compile(src: str, force: bool, extra: list[str]) -> str:
 def build(force: bool = False, verbose: bool = True, extra_flags: list[str] | None = None) -> str:
     os.makedirs(OBJ_DIR, exist_ok=True)
     extra = list(extra_flags or [])
-    with ThreadPoolExecutor(max_workers=min(6, len(SOURCES))) as ex:
+    with ThreadPoolExecutor(max_workers=min(7, len(SOURCES))) as ex:
         objs = list(ex.map(lambda s: _compile(s, force, extra), SOURCES))
     # the link stamp records which objects (flag sets included) the library was made of
     stamp = os.path.join(OBJ_DIR, "link.stamp")
@@ -94,7 +94,7 @@ def build(force: bool = False, verbose: bool = True, extra_flags: list[str] | No
     )
     if need_link:
         cmd = [_hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB, *objs,
-               "-L/opt/rocm/lib", "-lrocfft", "-Wl,-rpath,/opt/rocm/lib"]
+               "-L/opt/rocm/lib", "-lrocfft", "-ldl", "-Wl,-rpath,/opt/rocm/lib"]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{' '.join(cmd)}\n{r.stdout}\n{r.stderr}")

@@ -6,6 +6,7 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <cstring>
 #include <string>
 #include <vector>
 
@@ -90,6 +91,7 @@ struct AuxField {
   bool loaded = false;
 };
 
+struct CommState;    // RCCL communicator + strip buffers of the decomposed driver (comm.hip)
 struct Spectral;     // rocFFT plans + work buffers (spectral.hip)
 struct StrangFused;  // LDS-FFT split-step state (strang_fused.hip)
 
@@ -168,12 +170,14 @@ struct pdeopt_ctx {
   void* spots_dev = nullptr;
   std::vector<pdeopt_light_spot> spots_host;  // [batch][PDEOPT_MAX_SPOTS]
   double spots_x_first = 0.0, spots_y_first = 0.0;
+  int launch_part = 0;        // tiles of the next stage-pair launches: 0 all, 1 interior, 2 edge (pdeopt_rk4_phase_part)
   int win_lo = 0, win_n = 0;  // environment window the stage launchers operate on
   int64_t last_groups = 1;    // environment groups of the last advance (PDEOPT_CNT_LAST_GROUPS)
   double imex_A = 0.5, ts_re = 1.0, ts_im = 0.0, strang_dx = 1.0;
   double* red_dev = nullptr;  // reduction scratch
   size_t red_cap = 0;
   double* red_mean_dev = nullptr;
+  pdeopt::CommState* comm = nullptr;
   pdeopt::Spectral* spectral = nullptr;
   pdeopt::StrangFused* strang_fused = nullptr;
 };
@@ -241,9 +245,15 @@ int launch_lerp(pdeopt_ctx* ctx, const void* a, const void* b, void* out, double
 int halo_pack(pdeopt_ctx* ctx, int field, void* dev_send);
 int halo_unpack(pdeopt_ctx* ctx, int field, const void* dev_recv, const int* nbr);
 size_t halo_strip_elems(const pdeopt_ctx* ctx);
-int rk4_phase(pdeopt_ctx* ctx, int phase, double dt);
+int rk4_phase(pdeopt_ctx* ctx, int phase, double dt, int part = 0);
+int rk4_loopback_advance(pdeopt_ctx* ctx, double dt, int64_t n);
 int rk4_phase_plan(pdeopt_ctx* ctx, int* fields, int* nphases);
 void* field_ptr(pdeopt_ctx* ctx, int field);
+// comm.hip
+int comm_unique_id(pdeopt_ctx* ctx, char* out128);
+int comm_init(pdeopt_ctx* ctx, int world, int rank, const char* id128);
+void comm_destroy(pdeopt_ctx* ctx);
+int rk4_decomposed_advance(pdeopt_ctx* ctx, double dt, int64_t n, const int* nbr, int overlap);
 // reduce.hip
 int reduce_state(pdeopt_ctx* ctx, int op, double* out);
 int probe_state(pdeopt_ctx* ctx, const int32_t* cells, int n_probes, int env_first, int env_count, double* host_out);

@@ -459,8 +459,12 @@ int rk4_phase_plan(pdeopt_ctx* ctx, int* fields, int* nphases) {
   return PDEOPT_OK;
 }
 
-int rk4_phase(pdeopt_ctx* ctx, int phase, double dt) {
+// part: 0 = the whole tile; 1 = interior tiles only, 2 = edge tiles only (fused stage pairs; the caller runs
+// part 1 while the halo exchange of this phase is in flight and part 2 after pdeopt_halo_unpack).  The
+// substep's buffer rotation happens with the LAST launch of the last phase (part 0 or 2).
+int rk4_phase(pdeopt_ctx* ctx, int phase, double dt, int part) {
   if (ctx->prob.equation == PDEOPT_EQ_GPE) return fail(ctx, PDEOPT_EINVAL, "no explicit RHS for the GPE");
+  if (part < 0 || part > 2) return fail(ctx, PDEOPT_EINVAL, "part %d outside 0..2", part);
   int rc;
   if ((rc = ensure_buffer(ctx, &ctx->TA, ctx->total_bytes))) return rc;
   if ((rc = ensure_buffer(ctx, &ctx->TB, ctx->total_bytes))) return rc;
@@ -471,18 +475,41 @@ int rk4_phase(pdeopt_ctx* ctx, int phase, double dt) {
   ctx->win_lo = 0;
   ctx->win_n = ctx->prob.batch;
   if (n == 2) {
-    if (phase == 0)
-      return launch_pair_dt(ctx, PAIR_12, ctx->Y, nullptr, nullptr, ctx->TB, ctx->ACC, dt / 2, dt / 6, dt / 2, dt / 3);
-    rc = launch_pair_dt(ctx, PAIR_34, ctx->TB, ctx->Y, ctx->ACC, ctx->TA, nullptr, dt, dt / 3, 0.0, dt / 6);
-    std::swap(ctx->Y, ctx->TA);
+    ctx->launch_part = part;
+    if (phase == 0) {
+      rc = launch_pair_dt(ctx, PAIR_12, ctx->Y, nullptr, nullptr, ctx->TB, ctx->ACC, dt / 2, dt / 6, dt / 2, dt / 3);
+    } else {
+      rc = launch_pair_dt(ctx, PAIR_34, ctx->TB, ctx->Y, ctx->ACC, ctx->TA, nullptr, dt, dt / 3, 0.0, dt / 6);
+      if (part != 1) std::swap(ctx->Y, ctx->TA);
+    }
+    ctx->launch_part = 0;
     return rc;
   }
+  if (part != 0)
+    return fail(ctx, PDEOPT_EINVAL, "interior / edge launches exist for the fused stage pairs only (this problem runs one kernel per stage)");
   switch (phase) {
     case 0: return launch_stage(ctx, ctx->Y, ctx->Y, ctx->TA, ctx->ACC, dt / 2, dt / 6, OUT_Y_PLUS_AK, ACC_INIT);
     case 1: return launch_stage(ctx, ctx->TA, ctx->Y, ctx->TB, ctx->ACC, dt / 2, dt / 3, OUT_Y_PLUS_AK, ACC_ADD);
     case 2: return launch_stage(ctx, ctx->TB, ctx->Y, ctx->TA, ctx->ACC, dt, dt / 3, OUT_Y_PLUS_AK, ACC_ADD);
     default: return launch_stage(ctx, ctx->TA, ctx->Y, ctx->Y, ctx->ACC, 0.0, dt / 6, OUT_ACC_PLUS_BK, ACC_NONE);
   }
+}
+
+// n RK4 substeps of a single-rank padded tile with the loop-back halo exchange, entirely in the library: the
+// per-substep pack -> unpack -> phase sequence of the decomposed driver without a host round trip per call
+// (what one rank of pde_opt_amd/decomp.py executes, minus the collective).
+int rk4_loopback_advance(pdeopt_ctx* ctx, double dt, int64_t n) {
+  int fields[4], np_ = 0;
+  rk4_phase_plan(ctx, fields, &np_);
+  const int nbr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  int rc = PDEOPT_OK;
+  for (int64_t s = 0; s < n && !rc; ++s)
+    for (int ph = 0; ph < np_ && !rc; ++ph) {
+      if ((rc = halo_pack(ctx, fields[ph], nullptr))) break;
+      if ((rc = halo_unpack(ctx, fields[ph], nullptr, nbr))) break;
+      rc = rk4_phase(ctx, ph, dt, 0);
+    }
+  return rc;
 }
 
 // ------------------------------------------------------------------------------------------

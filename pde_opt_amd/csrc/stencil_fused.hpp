@@ -71,7 +71,17 @@ struct PairArgs {
   ClosureSpec mu, mob;
   int dbg;  // TIMING-ONLY ablation bits (PDEOPT_OPT_DEBUG_ABLATE): 1 skip mu passes, 2 skip marches, 4 skip ring,
             // 8 skip the tile loads, 16 skip the stores
+  int part;  // which tiles this launch computes: 0 all, 1 interior tiles only, 2 edge tiles only (tiles in the
+             // first / last tile row or column: the ones that read halo cells of a decomposed field, so the
+             // interior can run while the halo exchange is in flight)
 };
+
+// does this launch skip tile (ti, tj)?  (uniform per workgroup; evaluated before any barrier)
+__device__ __forceinline__ bool tile_skipped(int part, int ti, int tj, int tiles_i, int tiles_j) {
+  if (part == 0) return false;
+  const bool edge = ti == 0 || ti == tiles_i - 1 || tj == 0 || tj == tiles_j - 1;
+  return (part == 1) == edge;
+}
 
 // flux through the face between cells a and b (b = a + 1 along the axis with spacing 1/rh):
 // avg_face(D) * grad_face(mu)  (derivatives.py:24-31,39-46; cahn_hilliard.py:105-106).  Every face
@@ -165,6 +175,7 @@ __global__ __launch_bounds__(NT) PDEOPT_PAIR_WAVES_ATTR void stage_pair_kernel(c
   const int tj = t % tiles_j;
   const int ti = (t / tiles_j) % tiles_i;
   const int b = t / (tiles_j * tiles_i);
+  if (tile_skipped(a.part, ti, tj, tiles_i, tiles_j)) return;
   const int i0 = ti * TX;
   const int j0 = tj * TY;
 

@@ -34,6 +34,7 @@ __global__ __launch_bounds__(256) void stage_pair_ac_kernel(const PairArgs<T> a,
   const int tj = t % tiles_j;
   const int ti = (t / tiles_j) % tiles_i;
   const int b = t / (tiles_j * tiles_i);
+  if (tile_skipped(a.part, ti, tj, tiles_i, tiles_j)) return;
   const int i0 = ti * TX;
   const int j0 = tj * TY;
 

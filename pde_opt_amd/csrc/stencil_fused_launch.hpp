@@ -26,6 +26,7 @@ int launch_pair(pdeopt_ctx* ctx, int pair, const void* in, const void* y, const 
   s.mu = ClosureSpec{p.mu.kind, p.mu.flags, p.mu.n};
   s.mob = ClosureSpec{p.mob.kind, p.mob.flags, p.mob.n};
   s.dbg = (int)ctx->opt_debug_ablate;
+  s.part = ctx->launch_part;
   ctx->n_stage_launches++;
   const int cl = classify_closures(p.mu, p.mob);
   // tile height of the pair kernels.  CH: 32 rows (512-thread workgroups) where they divide the grid --

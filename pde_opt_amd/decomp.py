@@ -13,8 +13,30 @@ Every rank owns an (nx/px) x (ny/py) tile stored with a 4-cell halo.  Per RK4 su
 The exchange is ONE all-gather of packed strips per phase (edges and corners together), the pattern
 BASELINE.json names; strips are 2*h*(nx+ny)+4*h^2 elements (128 KiB at 2048^2 fp32), far below the
 per-link xGMI bandwidth, so the collective is latency-bound: fewer, fatter exchanges (halo 4 for a
-fused stage pair) is the lever, not bandwidth.  IMEX / Strang would need a distributed FFT
-(all-to-all transposes): replicas only for the spectral integrators.
+fused stage pair) is one lever, hiding the latency the other.  On the GPU the driver therefore
+
+  * can overlap (``use_overlap``): the all-gather runs on its own stream while the INTERIOR workgroup tiles of
+    the phase (the ones that read no halo cell, ~85 % of a 2048^2 tile) are computed; the EDGE tiles follow
+    the unpack (``pdeopt_rk4_phase_part``);
+  * can replay (``use_graph``, TorchComm): two substeps (pack, collective, interior, unpack, edge x 2 phases
+    x 2) are captured once into a device graph (``torch.cuda.graph`` on the engine's stream, the RCCL
+    collective included) and replayed, so a substep costs the host half a graph launch instead of ~18 ctypes /
+    torch calls;
+  * a single rank (loop-back exchange) runs the whole substep loop inside the library
+    (``pdeopt_rk4_loopback_advance``).
+
+  * ``NativeComm``: the library opens its own RCCL communicator (``pdeopt_comm_init``, the id broadcast by the
+    host) and runs the WHOLE loop -- pack, ``ncclAllGather``, interior tiles on the compute stream while the
+    collective is in flight on a second stream, unpack, edge tiles -- inside ``pdeopt_rk4_decomposed_advance``:
+    no Python, no graph, ~10 asynchronous launches per substep issued from C.
+
+``DecomposedSolver.mode`` reports which path ran ("native+overlap", "native", "loopback", "graph+overlap",
+"overlap", "plain"); a failed capture falls back to the eager overlapped path, CPU backends (gloo tests) to the
+plain sequence above.  Measured on ONE rank (a 1-rank RCCL group, 2048^2 tile, us per substep): in-library
+loop-back 46; torch all-gather plain 69 (host-bound: ~8 calls per substep), eager overlap 111 (more host
+calls), graph replay 99 (HIP graph launches cost ~5 us per node); see DESIGN.md section 6 for the native path.
+IMEX / Strang would need a distributed FFT (all-to-all transposes): replicas only for the spectral
+integrators.
 
 ``TileBackend`` is the HIP engine by default; tests inject a CPU backend built on the oracle to
 check the exchange protocol under gloo (world_size 2 and 4) without a GPU.
@@ -113,9 +135,13 @@ class TorchComm:
         # 0 and cannot be shared with a non-blocking stream: an explicit stream is required.)
         self.stream = None
         self.stream_handle = None
+        self.comm_stream = None
         if dist.get_backend(group) == "nccl":
-            self.stream = torch.cuda.Stream()
+            self.stream = torch.cuda.Stream()         # the engine's stream: kernels, pack / unpack
             self.stream_handle = self.stream.cuda_stream
+            self.comm_stream = torch.cuda.Stream()    # collectives, overlapped with the interior tiles
+            self.ev_packed = torch.cuda.Event()
+            self.ev_gathered = torch.cuda.Event()
 
     def make_buffers(self, backend):
         import torch
@@ -132,6 +158,73 @@ class TorchComm:
                 self._dist.all_gather_into_tensor(recv, send, group=self.group)
         else:
             self._dist.all_gather_into_tensor(recv, send, group=self.group)
+
+    @property
+    def can_overlap(self) -> bool:
+        return self.comm_stream is not None
+
+    def all_gather_overlapped(self, send, recv):
+        """the collective on the communication stream, ordered after everything issued so far on the engine's
+        stream (the pack); ``wait_gathered`` makes the engine's stream wait for it"""
+        self.ev_packed.record(self.stream)
+        self.comm_stream.wait_event(self.ev_packed)
+        with self._torch.cuda.stream(self.comm_stream):
+            self._dist.all_gather_into_tensor(recv, send, group=self.group)
+        self.ev_gathered.record(self.comm_stream)
+
+    def wait_gathered(self):
+        self.stream.wait_event(self.ev_gathered)
+
+    def capture(self, body):
+        """record ``body()`` (work on the engine's stream + the overlapped collectives) into a device graph"""
+        torch = self._torch
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=self.stream):
+            body()
+        return g
+
+    def replay(self, g):
+        """launch a captured graph ON THE ENGINE'S STREAM (``g.replay()`` alone would use torch's current
+        stream, unordered with the engine's eager work before and after it)"""
+        with self._torch.cuda.stream(self.stream):
+            g.replay()
+
+
+class NativeComm:
+    """The library's own RCCL communicator (csrc/comm.hip): the whole substep loop -- pack, ncclAllGather of
+    strips, unpack, stencil phases, the collective overlapped with the interior tiles on a second HIP stream --
+    runs inside ``pdeopt_rk4_decomposed_advance`` with no Python per substep.  The host side only carries rank
+    0's 128-byte RCCL id to the other ranks: ``broadcast(id_or_None) -> id`` (default: torch.distributed's
+    object broadcast, whatever its backend)."""
+
+    def __init__(self, world: Optional[int] = None, rank: Optional[int] = None, broadcast=None):
+        if world is None or rank is None:
+            import torch.distributed as dist
+
+            world, rank = dist.get_world_size(), dist.get_rank()
+        self.world, self.rank = int(world), int(rank)
+        self._broadcast = broadcast or self._torch_broadcast
+        self._attached = False
+
+    @staticmethod
+    def _torch_broadcast(uid):
+        import torch.distributed as dist
+
+        box = [uid]
+        dist.broadcast_object_list(box, src=0)
+        return box[0]
+
+    def make_buffers(self, backend):
+        if not self._attached:
+            eng = backend.engine
+            uid = self._broadcast(eng.comm_unique_id() if self.rank == 0 else None)
+            eng.comm_init(self.world, self.rank, uid)  # collective: every rank calls it
+            self._attached = True
+        return None, None  # the strip buffers live in the library
+
+    def all_gather(self, send, recv):
+        raise RuntimeError("NativeComm exchanges inside pdeopt_rk4_decomposed_advance")
 
 
 # ---------------------------------------------------------------------------------- HIP backend
@@ -165,8 +258,11 @@ class HipTileBackend:
     def unpack(self, field: int, recv, neighbours: Sequence[int]):
         self.engine.halo_unpack(field, self._ptr(recv), neighbours)
 
-    def phase(self, phase: int, dt: float):
-        self.engine.rk4_phase(phase, dt)
+    def phase(self, phase: int, dt: float, part: int = 0):
+        self.engine.rk4_phase(phase, dt, part)
+
+    def loopback_advance(self, dt: float, n: int):
+        self.engine.rk4_loopback_advance(dt, n)
 
     def set_state(self, tile):
         self.engine.set_state(np.asarray(tile, dtype=self.dtype))
@@ -196,6 +292,16 @@ class DecomposedSolver:
         self.send, self.recv = self.comm.make_buffers(self.backend)
         self.neighbours = grid.neighbours()
         self.exchanges = 0
+        self.mode = "plain"
+        # Both default OFF, by measurement on this stack (one rank, us per substep of a 2048^2 / 4096^2 tile):
+        # in-library loop with the collective on the compute stream 51 / 116; the same with the collective on a
+        # second stream 114 / 187 -- the two cross-stream event hops of a phase cost ~30 us, more than the interior
+        # tiles (20 / 50 us) can hide unless the collective itself takes longer than that; torch all-gather plain
+        # 74 / 134, eager overlap 111 / 170, graph replay 99 / 179 (HIP graph launches: ~5 us per node).
+        self.use_graph = False    # device-graph replay of substep pairs (TorchComm)
+        self.use_overlap = False  # interior tiles overlap the collective (fused stage pairs on the GPU)
+        self._graph = None
+        self._graph_dt = None
 
     def set_global_state(self, u_global):
         si, sj = self.grid.tile_slices(*self.equation.domain.points)
@@ -207,12 +313,60 @@ class DecomposedSolver:
         self.backend.unpack(field, self.recv, self.neighbours)
         self.exchanges += 1
 
+    def _substep_overlapped(self, plan, dt):
+        be, c = self.backend, self.comm
+        for phase, field in enumerate(plan):
+            be.pack(field, self.send)
+            c.all_gather_overlapped(self.send, self.recv)     # on the communication stream ...
+            be.phase(phase, dt, L.PART_INTERIOR)              # ... while the interior tiles run
+            c.wait_gathered()
+            be.unpack(field, self.recv, self.neighbours)
+            be.phase(phase, dt, L.PART_EDGE)
+
     def advance(self, dt: float, n_substeps: int):
+        n = int(n_substeps)
         plan = self.backend.phase_plan()
-        for _ in range(int(n_substeps)):
-            for phase, field in enumerate(plan):
-                self.exchange(field)
-                self.backend.phase(phase, dt)
+        be, c = self.backend, self.comm
+        if isinstance(c, NativeComm):
+            self.mode = "native+overlap" if (self.use_overlap and len(plan) == 2) else "native"  # default: native
+            be.engine.rk4_decomposed_advance(dt, n, self.neighbours, overlap=self.use_overlap)
+            self.exchanges += n * len(plan)
+            return
+        if isinstance(c, LoopbackComm) and hasattr(be, "loopback_advance"):
+            self.mode = "loopback"
+            be.loopback_advance(dt, n)  # the whole loop inside the library
+            self.exchanges += n * len(plan)
+            return
+        overlap = self.use_overlap and getattr(c, "can_overlap", False) and getattr(be, "on_device", False) and len(plan) == 2
+        if not overlap:
+            self.mode = "plain"
+            for _ in range(n):
+                for phase, field in enumerate(plan):
+                    self.exchange(field)
+                    be.phase(phase, dt)
+            return
+        done = 0
+        if self.use_graph and n >= 4:
+            if self._graph is None or self._graph_dt != dt:
+                # buffers, the communicator and the kernels' lazy allocations exist before the capture
+                for _ in range(2):
+                    self._substep_overlapped(plan, dt)
+                done = 2
+                try:
+                    self._graph = c.capture(lambda: [self._substep_overlapped(plan, dt) for _ in range(2)])
+                    self._graph_dt = dt
+                except Exception as e:  # capture not supported by this stack: stay eager
+                    self._graph, self.use_graph, self.capture_error = None, False, repr(e)
+            if self._graph is not None:
+                self.mode = "graph+overlap"
+                while done + 2 <= n:
+                    c.replay(self._graph)  # two substeps: the field buffers are back in place
+                    done += 2
+        if self._graph is None:
+            self.mode = "overlap"
+        for _ in range(n - done):
+            self._substep_overlapped(plan, dt)
+        self.exchanges += n * len(plan)
 
     def local_state(self):
         return self.backend.get_state()

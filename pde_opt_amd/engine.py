@@ -382,8 +382,35 @@ class HipEngine:
         self._check(self._lib.pdeopt_rk4_phase_plan(self._h, f, C.byref(n)))
         return [f[i] for i in range(n.value)]
 
-    def rk4_phase(self, phase: int, dt: float):
-        self._check(self._lib.pdeopt_rk4_phase(self._h, int(phase), float(dt)))
+    def rk4_phase(self, phase: int, dt: float, part: int = 0):
+        """one phase of an RK4 substep on a padded tile; ``part``: 0 all tiles, 1 interior tiles (no halo reads),
+        2 edge tiles"""
+        self._check(self._lib.pdeopt_rk4_phase_part(self._h, int(phase), float(dt), int(part)))
+
+    def rk4_loopback_advance(self, dt: float, n_substeps: int):
+        """n substeps of a single-rank padded tile, loop-back exchange included, in one library call"""
+        self._check(self._lib.pdeopt_rk4_loopback_advance(self._h, float(dt), int(n_substeps)))
+
+    # -- RCCL communicator owned by the library (decomposed driver without a host round trip per substep) ----
+    def comm_unique_id(self) -> bytes:
+        """rank 0: the 128-byte id every rank passes to ``comm_init`` (carry it with any transport)"""
+        buf = C.create_string_buffer(128)
+        rc = self._lib.pdeopt_comm_unique_id(buf)
+        if rc != L.OK:
+            raise L.PdeoptError(rc, self._lib.pdeopt_last_error(None).decode())
+        return buf.raw
+
+    def comm_init(self, world: int, rank: int, unique_id: bytes):
+        if len(unique_id) != 128:
+            raise ValueError("the RCCL unique id is 128 bytes")
+        self._check(self._lib.pdeopt_comm_init(self._h, int(world), int(rank), unique_id))
+
+    def comm_destroy(self):
+        self._check(self._lib.pdeopt_comm_destroy(self._h))
+
+    def rk4_decomposed_advance(self, dt: float, n_substeps: int, neighbours: Sequence[int], overlap: bool = True):
+        nb = (C.c_int * 8)(*[int(v) for v in neighbours])
+        self._check(self._lib.pdeopt_rk4_decomposed_advance(self._h, float(dt), int(n_substeps), nb, int(bool(overlap))))
 
     def buffer_alloc(self, nbytes: int) -> int:
         p = C.c_void_p()

@@ -113,6 +113,40 @@ def test_generic_kernel_in_padded_layout():
     np.testing.assert_array_equal(got, want)
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("shape", [(64, 128), (96, 384), (256, 256)])
+def test_interior_plus_edge_launches_equal_one_launch(dtype, shape):
+    """pdeopt_rk4_phase_part: the interior tiles (run while the halo exchange is in flight) and the edge tiles
+    (after the unpack) together do exactly what the single launch does -- bitwise, also when a tile row /
+    column is both first and last (64 x 128: every tile is an edge tile)"""
+    rng = np.random.default_rng(6)
+    nx, ny = shape
+    dom = std_domain(P, nx, ny)
+    eq = P.CahnHilliard2DPeriodic(dom, 0.002, MU["regsol"], MOB["c1mc"])
+    y0 = np.clip(0.5 + 0.05 * rng.standard_normal((nx, ny)), 0.05, 0.95).astype(dtype)
+    outs = []
+    for split in (False, True):
+        be = HipTileBackend(eq, (nx, ny), dtype)
+        be.set_state(y0)
+        plan = be.phase_plan()
+        assert len(plan) == 2
+        for _ in range(5):
+            for phase, field in enumerate(plan):
+                be.pack(field, None)
+                if split:
+                    be.phase(phase, 2e-7, L.PART_INTERIOR)  # reads no halo cell: may precede the unpack
+                    be.unpack(field, None, [0] * 8)
+                    be.phase(phase, 2e-7, L.PART_EDGE)
+                else:
+                    be.unpack(field, None, [0] * 8)
+                    be.phase(phase, 2e-7)
+        outs.append(be.get_state())
+        be.engine.close()
+    np.testing.assert_array_equal(outs[1], outs[0])
+    want, _ = _monolithic(eq, y0, 2e-7, 5, 0)
+    np.testing.assert_array_equal(outs[0], want)
+
+
 def test_config5_tile_size_smoke():
     """one 2048^2 tile of BASELINE config 5 (4096^2 over 2x2) with self-neighbours: finite + mass"""
     rng = np.random.default_rng(2)
@@ -154,12 +188,42 @@ def test_rccl_allgather_path_single_rank():
         want, _ = _monolithic(eq, y0, 2e-7, 5, 0)
         comm = TorchComm()
         assert comm.stream_handle  # a real (non-null) stream shared by RCCL and the engine
-        sol = DecomposedSolver(eq, CartesianGrid(1, 1, 0), comm=comm, dtype=np.float32)
-        sol.set_global_state(y0)
-        sol.advance(2e-7, 50)
-        torch.cuda.synchronize()
-        want, _ = _monolithic(eq, y0, 2e-7, 50, 0)
-        np.testing.assert_array_equal(sol.local_state(), want)
-        assert sol.send.is_cuda and sol.recv.numel() == sol.backend.strip_elems
+        want, _ = _monolithic(eq, y0, 2e-7, 51, 0)
+        modes = {}
+        for graph, overlap in ((True, True), (False, True), (False, False)):
+            sol = DecomposedSolver(eq, CartesianGrid(1, 1, 0), comm=comm, dtype=np.float32)
+            sol.use_graph, sol.use_overlap = graph, overlap
+            sol.set_global_state(y0)
+            sol.advance(2e-7, 51)  # odd: graph-replayed pairs + one eager substep
+            torch.cuda.synchronize()
+            got = sol.local_state()
+            bad = np.abs(got - want)
+            print("mode", sol.mode, "max diff", float(bad.max()), "rows", np.where(bad.max(axis=1) > 0)[0][:8], flush=True)
+            errors = locals().setdefault("errors", [])
+            if bad.max() > 0:
+                errors.append((graph, overlap, sol.mode, float(bad.max())))
+            assert sol.send.is_cuda and sol.recv.numel() == sol.backend.strip_elems
+            assert sol.exchanges == 2 * 51
+            modes[(graph, overlap)] = sol.mode
+            if graph and sol.mode != "graph+overlap":
+                print("device-graph capture of the exchange unavailable:", getattr(sol, "capture_error", None))
+        # the library's own RCCL communicator: the whole loop in C, with and without the overlapped collective
+        from pde_opt_amd.decomp import NativeComm
+
+        for overlap in (True, False):
+            sol = DecomposedSolver(eq, CartesianGrid(1, 1, 0), comm=NativeComm(), dtype=np.float32)
+            sol.use_overlap = overlap
+            sol.set_global_state(y0)
+            sol.advance(2e-7, 51)
+            got = sol.local_state()
+            print("mode", sol.mode, "max diff", float(np.abs(got - want).max()), flush=True)
+            assert sol.mode == ("native+overlap" if overlap else "native")
+            if not np.array_equal(got, want):
+                errors.append(("native", overlap, sol.mode, float(np.abs(got - want).max())))
+            sol.backend.engine.close()
+        assert not errors, errors
+        assert modes[(False, True)] == "overlap" and modes[(False, False)] == "plain"
+        assert modes[(True, True)] in ("graph+overlap", "overlap")
+        print("decomposed driver modes:", modes)
     finally:
         dist.destroy_process_group()
