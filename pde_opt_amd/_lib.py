@@ -143,6 +143,8 @@ _SIGNATURES = {
     "pdeopt_comm_destroy": (C.c_int, [_VP]),
     "pdeopt_rk4_decomposed_advance": (C.c_int, [_VP, C.c_double, C.c_int64, C.POINTER(C.c_int), C.c_int]),
     "pdeopt_ctx_create_on_stream": (C.c_int, [C.c_int, _VP, C.POINTER(_VP)]),
+    "pdeopt_host_alloc": (C.c_int, [_VP, C.c_int64, C.POINTER(_VP)]),
+    "pdeopt_host_free": (C.c_int, [_VP, _VP]),
     "pdeopt_buffer_alloc": (C.c_int, [_VP, C.c_int64, C.POINTER(_VP)]),
     "pdeopt_buffer_free": (C.c_int, [_VP, _VP]),
     "pdeopt_buffer_copy": (C.c_int, [_VP, _VP, _VP, C.c_int64, C.c_int]),

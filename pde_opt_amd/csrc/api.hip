@@ -220,6 +220,8 @@ int pdeopt_ctx_destroy(pdeopt_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   comm_destroy(ctx);
+  for (void* h : ctx->host_allocs) (void)hipHostFree(h);
+  ctx->host_allocs.clear();
   free_fields(ctx);
   if (ctx->red_dev) (void)hipFree(ctx->red_dev);
   if (ctx->red_mean_dev) (void)hipFree(ctx->red_mean_dev);
@@ -841,6 +843,31 @@ int pdeopt_ctx_create_on_stream(int device, void* hip_stream, pdeopt_ctx** out) 
     (*out)->stream_borrowed = true;
   }
   return PDEOPT_OK;
+}
+
+int pdeopt_host_alloc(pdeopt_ctx* ctx, int64_t bytes, void** host) {
+  if (!ctx || !host || bytes <= 0) return PDEOPT_EINVAL;
+  PDEOPT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  *host = nullptr;
+  hipError_t e = hipHostMalloc(host, (size_t)bytes, hipHostMallocDefault);
+  if (e != hipSuccess) {
+    *host = nullptr;
+    return fail(ctx, PDEOPT_ENOMEM, "hipHostMalloc(%lld bytes) failed: %s", (long long)bytes, hipGetErrorString(e));
+  }
+  ctx->host_allocs.push_back(*host);
+  return PDEOPT_OK;
+}
+
+int pdeopt_host_free(pdeopt_ctx* ctx, void* host) {
+  if (!ctx) return PDEOPT_EINVAL;
+  for (size_t i = 0; i < ctx->host_allocs.size(); ++i)
+    if (ctx->host_allocs[i] == host) {
+      PDEOPT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+      (void)hipHostFree(host);
+      ctx->host_allocs.erase(ctx->host_allocs.begin() + (long)i);
+      return PDEOPT_OK;
+    }
+  return fail(ctx, PDEOPT_EINVAL, "pointer was not returned by pdeopt_host_alloc on this ctx");
 }
 
 int pdeopt_buffer_alloc(pdeopt_ctx* ctx, int64_t bytes, void** dev) {

@@ -177,6 +177,7 @@ struct pdeopt_ctx {
   double* red_dev = nullptr;  // reduction scratch
   size_t red_cap = 0;
   double* red_mean_dev = nullptr;
+  std::vector<void*> host_allocs;  // pdeopt_host_alloc
   pdeopt::CommState* comm = nullptr;
   pdeopt::Spectral* spectral = nullptr;
   pdeopt::StrangFused* strang_fused = nullptr;

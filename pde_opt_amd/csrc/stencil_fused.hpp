@@ -170,11 +170,8 @@ __global__ __launch_bounds__(NT) PDEOPT_PAIR_WAVES_ATTR void stage_pair_kernel(c
   T* const sU = reinterpret_cast<T*>(smem_raw) + V;   // rows: tile row + 4, cols: tile col + HV*V
   T* const sMu = sU + (TX + 8) * P + V;               // rows: tile row + 3
 
-  int t = blockIdx.x;
-  if (xcd_remap) t = (t & 7) * (nblk >> 3) + (t >> 3);
-  const int tj = t % tiles_j;
-  const int ti = (t / tiles_j) % tiles_i;
-  const int b = t / (tiles_j * tiles_i);
+  int ti, tj, b;
+  decode_tile(blockIdx.x, tiles_i, tiles_j, nblk, xcd_remap, &ti, &tj, &b);
   if (tile_skipped(a.part, ti, tj, tiles_i, tiles_j)) return;
   const int i0 = ti * TX;
   const int j0 = tj * TY;
@@ -524,10 +521,10 @@ int launch_pair_ch_inst(pdeopt_ctx* ctx, const PairArgs<T>& s) {
   const bool ragged = p.nx % TX != 0 || p.ny % (kLanesPerRow * V) != 0;
   if (ragged)
     hipLaunchKernelGGL((stage_pair_kernel<T, CL, PAIR, 2, true, NT>), dim3(nblk), dim3(NT), lds, ctx->stream, s, tiles_i,
-                       tiles_j, nblk, (nblk % 8 == 0) ? 1 : 0);
+                       tiles_j, nblk, tile_flags(nblk, tiles_i, tiles_j));
   else
     hipLaunchKernelGGL((stage_pair_kernel<T, CL, PAIR, 2, false, NT>), dim3(nblk), dim3(NT), lds, ctx->stream, s, tiles_i,
-                       tiles_j, nblk, (nblk % 8 == 0) ? 1 : 0);
+                       tiles_j, nblk, tile_flags(nblk, tiles_i, tiles_j));
   PDEOPT_HIP_CHECK(ctx, hipGetLastError());
   return PDEOPT_OK;
 }

@@ -29,11 +29,8 @@ __global__ __launch_bounds__(256) void stage_pair_ac_kernel(const PairArgs<T> a,
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   T* const sU = reinterpret_cast<T*>(smem_raw) + V;  // rows: tile row + 2, cols: tile col + V
 
-  int t = blockIdx.x;
-  if (xcd_remap) t = (t & 7) * (nblk >> 3) + (t >> 3);
-  const int tj = t % tiles_j;
-  const int ti = (t / tiles_j) % tiles_i;
-  const int b = t / (tiles_j * tiles_i);
+  int ti, tj, b;
+  decode_tile(blockIdx.x, tiles_i, tiles_j, nblk, xcd_remap, &ti, &tj, &b);
   if (tile_skipped(a.part, ti, tj, tiles_i, tiles_j)) return;
   const int i0 = ti * TX;
   const int j0 = tj * TY;
@@ -188,10 +185,10 @@ int launch_pair_ac_inst(pdeopt_ctx* ctx, const PairArgs<T>& s) {
   const bool ragged = p.nx % (8 * RPT) != 0 || p.ny % (kLanesPerRow * V) != 0;
   if (ragged)
     hipLaunchKernelGGL((stage_pair_ac_kernel<T, CL, PAIR, RPT, true>), dim3(nblk), dim3(256), lds, ctx->stream, s, tiles_i,
-                       tiles_j, nblk, (nblk % 8 == 0) ? 1 : 0);
+                       tiles_j, nblk, tile_flags(nblk, tiles_i, tiles_j));
   else
     hipLaunchKernelGGL((stage_pair_ac_kernel<T, CL, PAIR, RPT, false>), dim3(nblk), dim3(256), lds, ctx->stream, s, tiles_i,
-                       tiles_j, nblk, (nblk % 8 == 0) ? 1 : 0);
+                       tiles_j, nblk, tile_flags(nblk, tiles_i, tiles_j));
   PDEOPT_HIP_CHECK(ctx, hipGetLastError());
   return PDEOPT_OK;
 }

@@ -62,11 +62,8 @@ __global__ __launch_bounds__(Ac4Geom::NT) void ac_rk4_quad_kernel(const QuadArgs
   T* const sY = reinterpret_cast<T*>(smem_raw) + V;  // rows: tile row + 4, cols: tile col + V
   T* const sW = sY + G::kRows * P + V;
 
-  int t = blockIdx.x;
-  if (xcd_remap) t = (t & 7) * (nblk >> 3) + (t >> 3);
-  const int tj = t % tiles_j;
-  const int ti = (t / tiles_j) % tiles_i;
-  const int b = t / (tiles_j * tiles_i);
+  int ti, tj, b;
+  decode_tile(blockIdx.x, tiles_i, tiles_j, nblk, xcd_remap, &ti, &tj, &b);
   const int i0 = ti * TX;
   const int j0 = tj * TY;
 
@@ -231,7 +228,7 @@ inline int launch_ac_quad(pdeopt_ctx* ctx, const void* y, void* out, double dt) 
   const bool ragged = p.nx % G::TX != 0 || p.ny % G::TY != 0;
   ctx->n_stage_launches++;
   ctx->last_kernel = G::TX == 32 ? "rk4_quad<f32,AC,poly,rows32>" : "rk4_quad<f32,AC,poly,rows16>";
-  const int remap = (nblk % 8 == 0) ? 1 : 0;
+  const int remap = tile_flags(nblk, tiles_i, tiles_j);
 #ifndef PDEOPT_AC4_M0
 #define PDEOPT_AC4_M0 1
 #endif

@@ -57,6 +57,41 @@ struct StageArgs {
   int dbg;  // timing ablations (PDEOPT_OPT_DEBUG_ABLATE): bit0 skip mu phase, bit1 skip flux phase
 };
 
+// Workgroup -> (tile row, tile column, environment).  `flags` (host: tile_flags()): bit 0 = XCD-aware block map,
+// bits 8-15 / 16-23 = log2(tiles_j) + 1 / log2(tiles_i) + 1 when both are powers of two.  The shift form matters:
+// the quotients are wave-uniform, but gfx950 has no scalar integer division, so `t % tiles_j` etc. expand into
+// ~20 VALU instructions each (v_cvt / v_rcp_iflag / v_mul_hi ...) -- 3 divisions were 8 % of the stage-pair
+// kernel's VALU instructions.
+__device__ __forceinline__ void decode_tile(int t, int tiles_i, int tiles_j, int nblk, int flags, int* ti, int* tj, int* b) {
+  if (flags & 1) t = (t & 7) * (nblk >> 3) + (t >> 3);
+#ifdef PDEOPT_TILE_DIV  // A/B build: always the division form
+  const int sj = 0, si = 0;
+#else
+  const int sj = (flags >> 8) & 0xff, si = (flags >> 16) & 0xff;
+#endif
+  if (sj && si) {
+    *tj = t & (tiles_j - 1);
+    const int q = t >> (sj - 1);
+    *ti = q & (tiles_i - 1);
+    *b = q >> (si - 1);
+  } else {
+    *tj = t % tiles_j;
+    *ti = (t / tiles_j) % tiles_i;
+    *b = t / (tiles_j * tiles_i);
+  }
+}
+inline int tile_flags(int nblk, int tiles_i, int tiles_j) {
+  auto lg = [](int v) {
+    int l = 0;
+    while ((1 << l) < v) ++l;
+    return (1 << l) == v ? l : -1;
+  };
+  int f = (nblk % 8 == 0) ? 1 : 0;
+  const int li = lg(tiles_i), lj = lg(tiles_j);
+  if (li >= 0 && lj >= 0) f |= ((lj + 1) << 8) | ((li + 1) << 16);
+  return f;
+}
+
 __device__ __forceinline__ int wrap_idx(int i, int n) {
   i %= n;
   return i < 0 ? i + n : i;

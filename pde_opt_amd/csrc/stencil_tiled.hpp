@@ -114,11 +114,8 @@ __global__ __launch_bounds__(RPT == 4 ? 512 : 256) void stage_tiled_kernel(const
 
   // ---- workgroup -> tile.  Blocks are dealt round-robin over the 8 XCDs (b and b+8 share one);
   // give each XCD a contiguous run of tiles (= whole environments) so halo re-reads hit its L2.
-  int t = blockIdx.x;
-  if (xcd_remap) t = (t & 7) * (nblk >> 3) + (t >> 3);
-  const int tj = t % tiles_j;
-  const int ti = (t / tiles_j) % tiles_i;
-  const int b = t / (tiles_j * tiles_i);
+  int ti, tj, b;
+  decode_tile(blockIdx.x, tiles_i, tiles_j, nblk, xcd_remap, &ti, &tj, &b);
   const int i0 = ti * TX;
   const int j0 = tj * (kLanesPerRow * V);
 
@@ -351,7 +348,7 @@ int launch_tiled_rpt(pdeopt_ctx* ctx, const StageArgs<T>& s) {
   const size_t lds = tiled_lds_bytes<T, EQ, RPT>();
   hipLaunchKernelGGL((stage_tiled_kernel<T, EQ, CL, OUT_MODE, ACC_MODE, Y_FROM_TILE, RPT>), dim3(nblk),
                      dim3(RPT == 4 ? 512 : 256), lds, ctx->stream, s, tiles_i, tiles_j, nblk,
-                     (nblk % 8 == 0) ? 1 : 0);
+                     tile_flags(nblk, tiles_i, tiles_j));
   PDEOPT_HIP_CHECK(ctx, hipGetLastError());
   return PDEOPT_OK;
 }

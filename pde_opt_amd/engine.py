@@ -252,9 +252,12 @@ class HipEngine:
             raise ValueError(f"state shape {a.shape} does not match (batch,)+{self.state_shape}")
         self._check(self._lib.pdeopt_set_state(self._h, int(env_first), a.shape[0], a.ctypes.data_as(C.c_void_p)))
 
-    def get_state(self, env_first: int = 0, env_count: Optional[int] = None) -> np.ndarray:
+    def get_state(self, env_first: int = 0, env_count: Optional[int] = None, out: Optional[np.ndarray] = None) -> np.ndarray:
         n = self.batch - env_first if env_count is None else env_count
-        out = np.empty((n,) + self.state_shape, dtype=self.dtype)
+        if out is None:
+            out = np.empty((n,) + self.state_shape, dtype=self.dtype)
+        elif out.shape != (n,) + self.state_shape or out.dtype != self.dtype or not out.flags.c_contiguous:
+            raise ValueError("out must be a C-contiguous array of the state dtype and shape (envs,) + state_shape")
         self._check(self._lib.pdeopt_get_state(self._h, int(env_first), int(n), out.ctypes.data_as(C.c_void_p)))
         return out
 
@@ -302,10 +305,25 @@ class HipEngine:
                                            out.ctypes.data_as(C.c_void_p)))
         return out if comps == 2 else out[..., 0]
 
-    def observe_u8(self, lo: float, hi: float, env_first: int = 0, env_count: Optional[int] = None) -> np.ndarray:
-        """uint8 frames ``rint(clip((x-lo)/(hi-lo), 0, 1) * 255)`` of shape (envs, nx, ny), quantised on the GPU"""
+    def pinned_empty(self, shape, dtype) -> np.ndarray:
+        """numpy array over page-locked host memory owned by this engine (``pdeopt_host_alloc``): the target of
+        per-step fetches (``observe_u8(out=...)``, ``get_state(out=...)``).  Valid until the engine is closed."""
+        dt = np.dtype(dtype)
+        nbytes = int(np.prod(shape)) * dt.itemsize
+        p = C.c_void_p()
+        self._check(self._lib.pdeopt_host_alloc(self._h, nbytes, C.byref(p)))
+        buf = (C.c_char * nbytes).from_address(p.value)
+        return np.frombuffer(buf, dtype=dt).reshape(shape)
+
+    def observe_u8(self, lo: float, hi: float, env_first: int = 0, env_count: Optional[int] = None,
+                   out: Optional[np.ndarray] = None) -> np.ndarray:
+        """uint8 frames ``rint(clip((x-lo)/(hi-lo), 0, 1) * 255)`` of shape (envs, nx, ny), quantised on the GPU;
+        ``out``: a reusable (ideally ``pinned_empty``) array to write them into"""
         n = self.batch - env_first if env_count is None else env_count
-        out = np.empty((n,) + self.state_shape, dtype=np.uint8)
+        if out is None:
+            out = np.empty((n,) + self.state_shape, dtype=np.uint8)
+        elif out.shape != (n,) + self.state_shape or out.dtype != np.uint8 or not out.flags.c_contiguous:
+            raise ValueError("out must be a C-contiguous uint8 array of shape (envs, nx, ny)")
         self._check(self._lib.pdeopt_observe_u8(self._h, float(lo), float(hi), int(env_first), int(n),
                                                 out.ctypes.data_as(C.c_void_p)))
         return out

@@ -213,8 +213,13 @@ class VectorPDEEnv:
         fetch_observations: bool = True,
         device_observation: Optional[tuple] = None,
         engine=None,
+        reuse_observation_buffer: bool = False,
     ):
         self.num_envs = int(num_envs)
+        # True: device-formed uint8 frames land in ONE page-locked host array that every step overwrites and
+        # returns (copy what you keep) -- no 32 MiB allocation + page faults + pageable D2H per step
+        self.reuse_observation_buffer = bool(reuse_observation_buffer)
+        self._obs_buffer = None
         self.equation_type, self.domain, self.solver_type = equation_type, domain, solver_type
         check_equation_solver_compatibility(solver_type, equation_type)
         self.end_time, self.step_dt, self.numeric_dt = end_time, step_dt, numeric_dt
@@ -348,7 +353,9 @@ class VectorPDEEnv:
                 obs = self._engine.probe(self.device_observation[1])  # (B, n_cells): point sensors
             else:
                 lo, hi = self.device_observation
-                obs = self._engine.observe_u8(lo, hi)[:, None]  # (B, 1, nx, ny) uint8, as the declared space
+                if self.reuse_observation_buffer and self._obs_buffer is None and hasattr(self._engine, "pinned_empty"):
+                    self._obs_buffer = self._engine.pinned_empty((self.num_envs,) + tuple(self.domain.points), np.uint8)
+                obs = self._engine.observe_u8(lo, hi, out=self._obs_buffer)[:, None]  # (B, 1, nx, ny) uint8, as the declared space
         elif self.fetch_observations or self.device_reward is None:
             self._state_host = self._engine.get_state()
             obs = np.stack([self.state_to_observation_func(s) for s in self._state_host])

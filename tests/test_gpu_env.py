@@ -117,6 +117,18 @@ def test_device_observation_uint8():
     assert diff.max() <= 1 and (diff > 0).mean() < 1e-3
     np.testing.assert_allclose(rewards, states.astype(np.float64).mean(axis=(1, 2)), rtol=1e-12)
     venv.close()
+    # one reused page-locked frame buffer: same frames, same array object every step
+    venv = P.VectorPDEEnv(2, **kw, device_reward="mean", device_observation=(0.0, 1.0), reuse_observation_buffer=True)
+    venv.reset(seed=5)
+    obs1, _, _, _, _ = venv.step([1, 1])
+    np.testing.assert_array_equal(obs1, obs)
+    first = obs1.copy()
+    obs2, _, _, _, _ = venv.step([1, 1])
+    assert obs2.base is obs1.base and np.any(obs2 != first)
+    eng = venv._engine
+    st = eng.get_state(out=eng.pinned_empty((2, 64, 128), np.float32))
+    np.testing.assert_array_equal(st, venv.states)
+    venv.close()
 
 
 def test_detect_vortices_against_reference_goldens(golden):

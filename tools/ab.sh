@@ -3,7 +3,7 @@
 A=$1; B=$2; shift 2
 for r in 1 2 3; do
   for lib in $A $B; do
-    PDEOPT_LIB=$PWD/$lib python bench.py --no-cpu-baseline --steps 5 --warmup 2 "$@" | python -c "
+    PDEOPT_LIB=$PWD/$lib python bench.py --no-cpu-baseline --no-parity-spot --no-api --steps 5 --warmup 2 "$@" | python -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
 print('$lib', round(d['value'],1), 'env-steps/s', round(d['ms_per_step'],2), 'ms/step')"

@@ -13,7 +13,7 @@ for pat in sys.argv[2:]:
         name = lines[s].split(":")[0]
         if pat not in name:
             continue
-        end = next((i for i in range(s, len(lines)) if lines[i].strip().startswith("s_endpgm")), len(lines))
+        end = next((i for i in range(s, len(lines)) if lines[i].startswith(".Lfunc_end")), len(lines))
         ops = collections.Counter()
         for l in lines[s:end]:
             m = re.match(r"\s+([a-z_0-9]+)\s", l)

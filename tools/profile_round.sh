@@ -9,7 +9,9 @@ for w in ac_rk4_512_f32 ch_imex_1024_f32 gpe_strang_512_c64 ch_rk4_1024_f64; do
 done
 cd $ROOT
 python bench.py > gpurun_out/round/bench.json 2> gpurun_out/round/bench.err
-for w in ac_rk4_512_f32 ch_imex_1024_f32 gpe_strang_512_c64 ch_rk4_1024_f64; do
+for w in ac_rk4_512_f32 ch_imex_1024_f32 gpe_strang_512_c64 gpe_strang_512_c64_spots ch_rk4_1024_f64 ch_rk4_4096_decomp; do
   python bench.py --workload $w --no-cpu-baseline --steps 5 --warmup 2 2>/dev/null | tail -1 > gpurun_out/round/bench_$w.json
 done
+python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29541 bench.py --gpus 1 \
+  --workload ch_rk4_4096_decomp --decomp-grid 2048 --no-cpu-baseline --steps 5 --warmup 2 2>/dev/null | tail -1 > gpurun_out/round/bench_decomp_tile2048_native_rccl_1rank.json
 tail -c 600 gpurun_out/round/bench.json

@@ -2,11 +2,12 @@
 # Everything the round's evidence comes from, in one gpurun call:
 #   gpurun --timeout 2400 -- 'bash tools/round_end.sh 2>&1 | tail -12'
 # GPU test suite -> tools/profile_round.sh (bench lines, kernel traces, PMC traffic) -> tools/pmc_busy.sh (pipe
-# occupancy of the headline kernel).  Afterwards, here: tools/install_profiles.sh <old> <new>.
+# occupancy of the headline kernel) -> tools/valubench.  Afterwards, here: tools/install_profiles.sh <tag>.
 cd ${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p gpurun_out
-timeout 900 python -m pytest tests -x -q -m gpu > gpurun_out/pytest_gpu.log 2>&1
+timeout 900 python -m pytest tests -q -m gpu > gpurun_out/pytest_gpu.log 2>&1
 grep -E "passed|failed|error" gpurun_out/pytest_gpu.log | tail -2
-timeout 1200 bash tools/profile_round.sh
+timeout 1500 bash tools/profile_round.sh
 timeout 300 bash tools/pmc_busy.sh busy > gpurun_out/busy_summary.txt 2>&1
+[ -x tools/valubench.bin ] && ./tools/valubench.bin > gpurun_out/valubench.txt 2>&1
 tail -4 gpurun_out/busy_summary.txt | cut -c1-400
