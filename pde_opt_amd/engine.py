@@ -57,6 +57,7 @@ class HipEngine:
         self.batch = 0
         self.state_shape: tuple = ()
         self._aux_thunks: dict = {}
+        self._aux_keys: dict = {}
         self._callback_error = None
 
     # -- plumbing ---------------------------------------------------------------------------
@@ -128,6 +129,9 @@ class HipEngine:
         p.nx, p.ny, p.batch = int(nx), int(ny), int(batch)
         p.hx, p.hy, p.kappa, p.gpe_k = float(hx), float(hy), float(kappa), float(gpe_k)
         p.mu, p.mob = _closure_struct(mu), _closure_struct(mob)
+        old = self.problem
+        if old is None or (old.equation, old.dtype, old.nx, old.ny, old.nz, old.batch) != (p.equation, p.dtype, p.nx, p.ny, p.nz, p.batch):
+            self._aux_keys.clear()  # a new shape frees the library's auxiliary fields
         self._check(self._lib.pdeopt_configure(self._h, C.byref(p)))
         self.problem = p
         self.dtype = L.np_dtype(p.dtype)
@@ -173,10 +177,18 @@ class HipEngine:
             a = np.broadcast_to(a, want)
         return np.ascontiguousarray(a)
 
-    def set_aux(self, which: int, field, per_env: bool = False):
+    def set_aux(self, which: int, field, per_env: bool = False, key=None):
+        """``key``: identity of the field's contents (``KeyedArray.key``); a field this engine already holds under
+        the same key is not transferred again"""
+        which = int(which)
+        if key is not None and self._aux_keys.get(which) == (key, bool(per_env)):
+            return
+        self._aux_keys.pop(which, None)
         a = self._aux_array(which, field, per_env)
         self._check(self._lib.pdeopt_set_aux(self._h, int(which), a.ctypes.data_as(C.c_void_p), int(per_env)))
         self._aux_thunks.pop(int(which), None)  # the static upload replaced a time-dependent source
+        if key is not None:
+            self._aux_keys[which] = (key, bool(per_env))
 
     def set_aux_time_fn(self, which: int, fn, per_env: bool = False):
         """Time-dependent auxiliary field: ``fn(t)`` returns the field ((nx, ny), or (batch, nx, ny) with
@@ -198,6 +210,7 @@ class HipEngine:
                 self._callback_error = e
                 return 1
 
+        self._aux_keys.pop(which, None)
         cb = L.AUX_FN(thunk)
         self._check(self._lib.pdeopt_set_aux_time_fn(self._h, which, cb, None, int(per_env)))
         self._aux_thunks[which] = cb  # keep the ctypes thunk alive while the library may call it
@@ -381,6 +394,7 @@ class HipEngine:
     def set_halo_layout(self, halo: int):
         """0 = periodic field, 4 = rank-local tile padded by a 4-cell halo (takes effect at the next configure)"""
         self._check(self._lib.pdeopt_set_option(self._h, L.OPT_HALO_LAYOUT, int(halo)))
+        self._aux_keys.clear()  # a layout change re-allocates on the next configure
 
     def halo_strip_elems(self) -> int:
         v = C.c_int64()

@@ -46,6 +46,23 @@ def spectral_table(domain) -> dict:
     return tab
 
 
+class KeyedArray(np.ndarray):
+    """ndarray that remembers what it was built from (``key``), so a consumer that has already uploaded the same
+    field can skip the transfer: PDEEnv.step rebuilds the equation and the solver every step (pde_env.py:286-291),
+    and an unchanged 1024^2 ``fourier_symbol`` would otherwise cost an 8 MiB upload plus a multiplier rebuild."""
+
+    key = None
+
+    def __array_finalize__(self, obj):
+        self.key = None  # views and results of arithmetic are new data
+
+
+def keyed(arr: np.ndarray, key) -> KeyedArray:
+    out = np.asarray(arr).view(KeyedArray)
+    out.key = key
+    return out
+
+
 class _Spectral:
     """Published spectral attribute, computed on first access (class access keeps ``hasattr`` true
     for ``check_equation_solver_compatibility``)."""
@@ -91,7 +108,12 @@ class CahnHilliard2DPeriodic(BaseEquation):
     @property
     def fourier_symbol(self):
         """kappa (2 pi i k)^4, the stiff linear symbol of the IMEX solver (cahn_hilliard.py:74)"""
-        return self.kappa * self.two_pi_i_k_4
+        tab = spectral_table(self.domain)
+        key = ("kappa_k4", float(self.kappa))
+        hit = tab.get("_symbol")
+        if hit is None or hit.key[-1] != key:
+            hit = tab["_symbol"] = keyed(self.kappa * tab["two_pi_i_k_4"], (id(tab), key))
+        return hit
 
     _per_env_controls = frozenset({"kappa", "mu", "D"})
 

@@ -82,8 +82,9 @@ class SemiImplicitFourierSpectral(AbstractSolver):
 
     def configure_engine(self, engine, equation):
         engine.set_integrator_params(imex_A=float(self.A))
-        engine.set_aux(L.AUX_IMEX_SYMBOL, np.asarray(self.fourier_symbol))
-
+        # a symbol this engine already holds (same table, same kappa: the per-step rebuild of PDEEnv.step) is
+        # not uploaded again -- the library would also rebuild its spectral multiplier
+        engine.set_aux(L.AUX_IMEX_SYMBOL, self.fourier_symbol, key=getattr(self.fourier_symbol, "key", None))
 
 @dataclasses.dataclass
 class StrangSplitting(AbstractSolver):

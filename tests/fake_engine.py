@@ -34,7 +34,7 @@ class OracleEngine:
         self.gpe_k_env = np.full(batch, float(gpe_k))
         self.time_scale, self.strang_dx = 1.0, 1.0
 
-    def set_aux(self, which, field, per_env=False):
+    def set_aux(self, which, field, per_env=False, key=None):
         self.aux[which] = (np.asarray(field), bool(per_env))
         self.aux_fn.pop(which, None)  # a static upload replaces a time-dependent source
         if which == L.AUX_IMEX_SYMBOL:

@@ -126,7 +126,7 @@ def test_device_observation_uint8():
     obs2, _, _, _, _ = venv.step([1, 1])
     assert obs2.base is obs1.base and np.any(obs2 != first)
     eng = venv._engine
-    st = eng.get_state(out=eng.pinned_empty((2, 64, 128), np.float32))
+    st = eng.get_state(out=eng.pinned_empty((2, 64, 128), eng.dtype))
     np.testing.assert_array_equal(st, venv.states)
     venv.close()
 

@@ -12,7 +12,9 @@ import collections, csv, glob, json, os, sys
 workload, tag, sub = sys.argv[1:4]
 acc, cnt, names = collections.defaultdict(float), collections.Counter(), set()
 for d in sys.argv[4:]:
-    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+    # gpurun_out/ accumulates runs: only the NEWEST pass of every directory counts
+    files = sorted(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True), key=os.path.getmtime)
+    for f in files[-1:]:
         for r in csv.DictReader(open(f)):
             if sub in r["Kernel_Name"]:
                 acc[r["Counter_Name"]] += float(r["Counter_Value"])
