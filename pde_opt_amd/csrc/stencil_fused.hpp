@@ -240,6 +240,44 @@ __global__ __launch_bounds__(NT) PDEOPT_PAIR_WAVES_ATTR void stage_pair_kernel(c
 
   // ---- P1: stage-A input, tile + 4  (PAIR_K: the only stage's input, tile + 2 = LDS rows 2 .. TX+5)
   constexpr int kRow0 = PAIR == PAIR_K ? 2 : 0;
+#ifndef PDEOPT_P1_FLAT
+  // One tile row per wave and trip: lane l < PV loads vector l of the row.  The row index is wave-uniform, so
+  // its periodic wrap and the row offset are scalar work and a trip costs the VALU nothing but the load and the
+  // LDS store; the column wrap and the column offset are formed once per thread.  (The flat "vector idx = tid +
+  // it NT" mapping needed a division by PV, two wraps and a 64-bit address per vector: ~100 of the ~700 VALU
+  // instructions a thread executes per tile.)  A wave reads 34 (36) contiguous vectors of one row.
+  {
+    constexpr int NW = NT / 64;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    if (lane < PV) {
+      const int gj = wrap_col(j0 - HV * V + lane * V);
+      const T* __restrict__ colp = in + gj;
+      T* const lds = sU + lane * V;
+      // all loads of the thread first, then the LDS stores: the trips' latencies overlap.  Every trip loads
+      // (a wave past the last row re-reads that row: unconditional loads keep the registers simple), only
+      // the store of a partial last trip is guarded -- by a wave-uniform condition
+      constexpr int kRows = TX + 8 - 2 * kRow0, kTrips = (kRows + NW - 1) / NW;
+      Vec f[kTrips];
+#pragma unroll
+      for (int k = 0; k < kTrips; ++k) {
+        int row = kRow0 + wave + k * NW;
+        if constexpr (kRows % NW != 0) row = row < kRow0 + kRows ? row : kRow0 + kRows - 1;
+        const int gi = wrap_row(i0 - 4 + row);
+        if (PDEOPT_ABL(a, 8)) {
+          for (int e = 0; e < V; ++e) f[k][e] = T(0.5) + T(1e-4) * T(gj + e);
+        } else {
+          f[k] = *reinterpret_cast<const Vec*>(colp + (int64_t)gi * ld);
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < kTrips; ++k) {
+        const int row = kRow0 + wave + k * NW;
+        if (kRows % NW == 0 || k + 1 < kTrips || row < kRow0 + kRows) *reinterpret_cast<Vec*>(lds + row * P) = f[k];
+      }
+    }
+  }
+#else
   constexpr int kLoadVecs = (TX + 8 - 2 * kRow0) * PV;
 #pragma unroll
   for (int it = 0; it < (kLoadVecs + NT - 1) / NT; ++it) {
@@ -258,6 +296,7 @@ __global__ __launch_bounds__(NT) PDEOPT_PAIR_WAVES_ATTR void stage_pair_kernel(c
       }
     }
   }
+#endif
   __syncthreads();
 
   // mu on `nrows` rows starting at mu-row `rm0` (mu row rm <-> sU row rm + 1)

@@ -96,18 +96,7 @@ __global__ __launch_bounds__(256) void stage_pair_ac_kernel(const PairArgs<T> a,
   }
 
   // ---- P1: stage-A input, tile + 2 rows / one halo vector of columns
-  constexpr int kLoadVecs = (TX + 4) * PV;
-#pragma unroll
-  for (int it = 0; it < (kLoadVecs + 255) / 256; ++it) {
-    const int idx = tid + it * 256;
-    if (idx < kLoadVecs) {
-      const int row = idx / PV;
-      const int cv = idx - row * PV;
-      const int gi = wrap_row(i0 - 2 + row);
-      const int gj = wrap_col(j0 - V + cv * V);
-      *reinterpret_cast<Vec*>(sU + row * P + cv * V) = *reinterpret_cast<const Vec*>(in + (int64_t)gi * ld + gj);
-    }
-  }
+  load_rows_per_wave<T, V, PV, 256, TX + 4, Vec>(sU, P, in, ld, i0 - 2, j0 - V, wrap_row, wrap_col, tid);
   __syncthreads();
 
   // k at one vector: tile row r, LDS vector column cv

@@ -87,18 +87,7 @@ __global__ __launch_bounds__(Ac4Geom::NT) void ac_rk4_quad_kernel(const QuadArgs
   auto cell_ok = [&](int r) { return !RAGGED || (col_ok && (i0 + r0 + r) < g.nx); };
 
   // ---- load y on tile + 4 into both arrays' source (sY); stage 1 reads sY directly
-  constexpr int kLoadVecs = G::kRows * PV;
-#pragma unroll
-  for (int it = 0; it < (kLoadVecs + NT - 1) / NT; ++it) {
-    const int idx = tid + it * NT;
-    if (idx < kLoadVecs) {
-      const int row = idx / PV;
-      const int cv = idx - row * PV;
-      const int gi = wrap_row(i0 - 4 + row);
-      const int gj = wrap_col(j0 - V + cv * V);
-      *reinterpret_cast<Vec*>(sY + row * P + cv * V) = *reinterpret_cast<const Vec*>(in + (int64_t)gi * ld + gj);
-    }
-  }
+  load_rows_per_wave<T, V, PV, NT, G::kRows, Vec>(sY, P, in, ld, i0 - 4, j0 - V, wrap_row, wrap_col, tid);
   __syncthreads();
 
   // Constant mobility (CL_POLY_M0): k = -R (mu_h(u) - kappa lap u) is ONE cubic in u plus two weighted

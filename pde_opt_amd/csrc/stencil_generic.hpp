@@ -79,6 +79,11 @@ __device__ __forceinline__ void decode_tile(int t, int tiles_i, int tiles_j, int
     *ti = (t / tiles_j) % tiles_i;
     *b = t / (tiles_j * tiles_i);
   }
+  // the division form computes in VGPRs; tell the compiler the results are wave-uniform either way, so that
+  // everything derived from them (environment base offsets, tile origins, row wraps) is scalar work
+  *tj = __builtin_amdgcn_readfirstlane(*tj);
+  *ti = __builtin_amdgcn_readfirstlane(*ti);
+  *b = __builtin_amdgcn_readfirstlane(*b);
 }
 inline int tile_flags(int nblk, int tiles_i, int tiles_j) {
   auto lg = [](int v) {
@@ -90,6 +95,39 @@ inline int tile_flags(int nblk, int tiles_i, int tiles_j) {
   const int li = lg(tiles_i), lj = lg(tiles_j);
   if (li >= 0 && lj >= 0) f |= ((lj + 1) << 8) | ((li + 1) << 16);
   return f;
+}
+
+// Tile + halo -> LDS, one tile row per wave and trip: lane l < PV loads vector l (V elements) of a row.  The row
+// index is wave-uniform, so its periodic wrap and the row offset are scalar work and a trip costs the VALU nothing
+// but the load and the LDS store; the column wrap and offset are formed once per thread.  (A flat "vector idx =
+// tid + it NT" mapping needs a division by PV, two wraps and a 64-bit address per vector: it was ~14 % of the
+// VALU instructions of the VALU-bound fused kernels.)  All loads are issued before the stores; a wave past the last
+// row re-reads that row and skips the store.  sdst: LDS row 0 / vector 0; P: LDS row pitch in elements;
+// i_first / j_first: global row / column of LDS row 0 / vector 0.
+template <typename T, int V, int PV, int NT, int ROWS, typename Vec, typename WR, typename WC>
+__device__ __forceinline__ void load_rows_per_wave(T* __restrict__ sdst, const int P, const T* __restrict__ in, const int64_t ld,
+                                                   const int i_first, const int j_first, WR wrap_row, WC wrap_col,
+                                                   const int tid) {
+  constexpr int NW = NT / 64, kTrips = (ROWS + NW - 1) / NW;
+  static_assert(PV <= 64, "a row of vectors fits one wave");
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63;
+  if (lane < PV) {
+    const T* __restrict__ colp = in + wrap_col(j_first + lane * V);
+    T* const lds = sdst + lane * V;
+    Vec f[kTrips];
+#pragma unroll
+    for (int k = 0; k < kTrips; ++k) {
+      int row = wave + k * NW;
+      if constexpr (ROWS % NW != 0) row = row < ROWS ? row : ROWS - 1;
+      f[k] = *reinterpret_cast<const Vec*>(colp + (int64_t)wrap_row(i_first + row) * ld);
+    }
+#pragma unroll
+    for (int k = 0; k < kTrips; ++k) {
+      const int row = wave + k * NW;
+      if (ROWS % NW == 0 || k + 1 < kTrips || row < ROWS) *reinterpret_cast<Vec*>(lds + row * P) = f[k];
+    }
+  }
 }
 
 __device__ __forceinline__ int wrap_idx(int i, int n) {

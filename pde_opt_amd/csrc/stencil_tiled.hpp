@@ -150,23 +150,9 @@ __global__ __launch_bounds__(RPT == 4 ? 512 : 256) void stage_tiled_kernel(const
   }
 
   // ---- phase 1: tile + halo -> LDS
-  constexpr int kLoadVecs = (TX + 2 * HR) * PV;
-#pragma unroll
-  for (int it = 0; it < (kLoadVecs + NT - 1) / NT; ++it) {
-    const int idx = tid + it * NT;
-    if (idx < kLoadVecs) {
-      const int row = idx / PV;
-      const int cv = idx - row * PV;
-      int gi = i0 - HR + row;
-      int gj = j0 - V + cv * V;
-      if (g.periodic) {
-        gi = tile_wrap(gi, g.nx, ragged);
-        gj = tile_wrap(gj, g.ny, ragged);
-      }
-      const Vec v = *reinterpret_cast<const Vec*>(in + (int64_t)gi * ld + gj);
-      *reinterpret_cast<Vec*>(su + row * P + cv * V) = v;
-    }
-  }
+  load_rows_per_wave<T, V, PV, NT, TX + 2 * HR, Vec>(
+      su, P, in, ld, i0 - HR, j0 - V, [&](int gi) { return g.periodic ? tile_wrap(gi, g.nx, ragged) : gi; },
+      [&](int gj) { return g.periodic ? tile_wrap(gj, g.ny, ragged) : gj; }, tid);
   __syncthreads();
 
   const T kap = p.kappa;
