@@ -173,9 +173,17 @@ __global__ __launch_bounds__(C* N / PTS) void strang_col_reg_kernel(Cx<T>* __res
   const int j = tid / C, c = tid - j * C;
   Cx<T>* const seq = reinterpret_cast<Cx<T>*>(smem_raw) + c * NP;
   const int env = blockIdx.y;
+#ifdef PDEOPT_COL_XCD_PAIR
+  // workgroups are dealt to the 8 XCDs round-robin by linear id: hand each XCD PAIRS of adjacent column
+  // blocks so that the two halves of a 128-byte line are fetched into the same L2 (narrow blocks)
+  const int bx_ = blockIdx.x;
+  const int cblk = (bx_ & ~15) + 2 * (bx_ & 7) + ((bx_ >> 3) & 1);
+#else
+  const int cblk = blockIdx.x;
+#endif
   // uniform base pointers + 32-bit per-thread offsets: one VGPR per address instead of a 64-bit pair
   // (the 16-point threads of the N = 1024 pass run at the 128-VGPR limit of a 1024-thread workgroup)
-  Cx<T>* const gb = psi + (int64_t)env * N * ny + blockIdx.x * C;
+  Cx<T>* const gb = psi + (int64_t)env * N * ny + cblk * C;
   Cx<T> v[PTS];
 #pragma unroll
   for (int m = 0; m < PTS; ++m) v[m] = gb[E::natural(j, m) * ny + c];
@@ -194,8 +202,8 @@ __global__ __launch_bounds__(C* N / PTS) void strang_col_reg_kernel(Cx<T>* __res
   // WL: stage 0 in the load layout, everything after it with a column per wave
   const int ji = tid % E::TT;
   Cx<T>* const seqi = reinterpret_cast<Cx<T>*>(smem_raw) + (tid / E::TT) * NP;
-  const Cx<T>* const mb = WL ? mult + (int64_t)(blockIdx.x * C + tid / E::TT) * N  // transposed: [ny][nx]
-                             : mult + blockIdx.x * C;
+  const Cx<T>* const mb = WL ? mult + (int64_t)(cblk * C + tid / E::TT) * N  // transposed: [ny][nx]
+                             : mult + cblk * C;
   if constexpr (WL)
     E::template dif_split<-1>(v, seq, j, seqi, ji, tw);
   else

@@ -182,7 +182,8 @@ class VectorPDEEnv:
 
     ``reward`` / observations: ``reward_function`` and ``state_to_observation_func`` are applied
     per environment on host copies unless ``device_reward`` names an on-device reduction
-    (``"var"``, ``"mean"``, ``"min"``, ``"max"``), which avoids the D2H of full fields;
+    (``"var"``, ``"mean"``, ``"min"``, ``"max"``, or ``("vortices", amp_thresh, tol)`` = the number of quantised
+    vortices of a GPE state, ``rl_utils.detect_vortices`` on the device), which avoids the D2H of full fields;
     ``device_observation=(lo, hi)`` additionally forms the uint8 image observations of the declared
     observation space on the GPU (1 byte per cell crosses PCIe instead of 4 or 8);
     ``device_observation=("probes", cells)`` returns the state at the listed grid cells instead (sensor-style
@@ -344,7 +345,15 @@ class VectorPDEEnv:
         if rem > 0:
             self._engine.advance(solver.integrator, rem, 1, n_full * self.numeric_dt)
         self._time += self.step_dt
-        if self.device_reward is not None:
+        if isinstance(self.device_reward, tuple):
+            # ("vortices", amp_thresh, tol): rl_utils.detect_vortices' num_vortices per environment, counted on the
+            # device (pde_opt/rl_utils.py:19-84): 24 bytes per environment cross PCIe instead of the wavefunction
+            if self.device_reward[0] != "vortices":
+                raise ValueError(f"unknown device reward {self.device_reward[0]!r}")
+            amp, tol = (tuple(self.device_reward[1:]) + (0.0, 0.5))[:2]
+            counts, _ = self._engine.detect_vortices(amp_thresh=float(amp), tol=float(tol), want_winding=False)
+            rewards = counts[:, 0].astype(np.float64)
+        elif self.device_reward is not None:
             rewards = self._engine.reduce(self._RED[self.device_reward])
         if self.device_observation is not None and self.device_reward is not None:
             if isinstance(self.device_observation[0], str):

@@ -195,6 +195,18 @@ def test_vector_env_spot_controls_match_single_envs():
     venv.close()
     for e in singles:
         e.close()
+    # the vortex census as a device reward equals rl_utils.detect_vortices on the fetched states
+    from pde_opt_amd.rl_utils import detect_vortices
+
+    venv = P.VectorPDEEnv(3, **kw, fetch_observations=False, device_reward=("vortices", 1e-4, 0.5))
+    venv.reset(seed=5)
+    for _ in range(3):
+        obs, rewards, _, _, _ = venv.step([2, 2, 0])
+    assert obs is None
+    st = venv.states
+    want = [detect_vortices(st[b, ..., 0] + 1j * st[b, ..., 1], amp_thresh=1e-4)["num_vortices"] for b in range(3)]
+    np.testing.assert_array_equal(rewards, want)
+    venv.close()
 
 
 @pytest.mark.parametrize("solver", ["euler", "rk4", "tsit5"])

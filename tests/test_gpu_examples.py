@@ -9,7 +9,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("name", ["run_cahn_hilliard", "thomas_fermi", "pde_env_random_policy", "smoothed_boundary"])
+@pytest.mark.parametrize("name", ["run_cahn_hilliard", "thomas_fermi", "pde_env_random_policy", "smoothed_boundary", "gpe_stirring_control"])
 def test_example_runs(name):
     env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
     r = subprocess.run([sys.executable, os.path.join(ROOT, "examples", name + ".py"), "--quick"], env=env,
