@@ -28,7 +28,7 @@ from ... import _lib as L
 from ..domains import Domain
 from ..functions.lights import GaussianSpots
 from .base_eq import TimeSplittingEquation, depends_on_time
-from .phase_field import spectral_table
+from .phase_field import keyed, spectral_table
 
 # constants published by the reference module (gross_pitaevskii.py:12-15)
 hbar = 1.05e-34
@@ -58,11 +58,14 @@ class GPE2DTSControl(TimeSplittingEquation):
         self.dx = self.domain.dx[0]
         tab = spectral_table(self.domain)  # shared per grid: PDEEnv.step rebuilds the equation every step
         for name, arr in tab.items():
-            setattr(self, name, arr)
+            if not name.startswith("_"):
+                setattr(self, name, arr)
         if "mesh" not in tab:
             tab["mesh"] = self.domain.mesh()
-            tab["A_kinetic"] = 0.5j * tab["two_pi_i_k_2"]
-            tab["A_zero"] = tab["A_kinetic"] * 0.0
+            # keyed: PDEEnv.step rebuilds equation and solver every step; an A_term the engine already holds is
+            # not uploaded again (the library would rebuild its spectral multiplier exp(A_term tau / 2))
+            tab["A_kinetic"] = keyed(0.5j * tab["two_pi_i_k_2"], (tab["_serial"], "A_kinetic"))
+            tab["A_zero"] = keyed(tab["A_kinetic"] * 0.0, (tab["_serial"], "A_zero"))
         self.fft = np.fft.fftn
         self.ifft = np.fft.ifftn
         self.xmesh, self.ymesh = tab["mesh"]

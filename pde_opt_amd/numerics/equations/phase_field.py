@@ -26,6 +26,7 @@ from .base_eq import BaseEquation
 _SPECTRAL_NAMES = ("kx", "ky", "two_pi_i_kx", "two_pi_i_ky", "two_pi_i_kx_2", "two_pi_i_ky_2",
                    "two_pi_i_k_2", "two_pi_i_k_4")
 _spectral_cache: dict = {}
+_table_serial = iter(range(1, 1 << 62))  # identity of a table in upload keys (id() may be reused after eviction)
 
 
 def spectral_table(domain) -> dict:
@@ -38,7 +39,7 @@ def spectral_table(domain) -> dict:
         kx, ky = domain.fft_mesh()
         ikx, iky = 2j * np.pi * kx, 2j * np.pi * ky
         k2 = ikx**2 + iky**2
-        tab = dict(kx=kx, ky=ky, two_pi_i_kx=ikx, two_pi_i_ky=iky, two_pi_i_kx_2=ikx**2,
+        tab = dict(_serial=next(_table_serial), kx=kx, ky=ky, two_pi_i_kx=ikx, two_pi_i_ky=iky, two_pi_i_kx_2=ikx**2,
                    two_pi_i_ky_2=iky**2, two_pi_i_k_2=k2, two_pi_i_k_4=k2**2)
         if len(_spectral_cache) > 8:
             _spectral_cache.clear()
@@ -112,7 +113,7 @@ class CahnHilliard2DPeriodic(BaseEquation):
         key = ("kappa_k4", float(self.kappa))
         hit = tab.get("_symbol")
         if hit is None or hit.key[-1] != key:
-            hit = tab["_symbol"] = keyed(self.kappa * tab["two_pi_i_k_4"], (id(tab), key))
+            hit = tab["_symbol"] = keyed(self.kappa * tab["two_pi_i_k_4"], (tab["_serial"], key))
         return hit
 
     _per_env_controls = frozenset({"kappa", "mu", "D"})

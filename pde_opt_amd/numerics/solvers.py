@@ -104,7 +104,7 @@ class StrangSplitting(AbstractSolver):
 
     def configure_engine(self, engine, equation):
         engine.set_integrator_params(time_scale=complex(self.time_scale), strang_dx=float(self.dx))
-        engine.set_aux(L.AUX_GPE_A_TERM, np.asarray(self.A_term))
+        engine.set_aux(L.AUX_GPE_A_TERM, self.A_term, key=getattr(self.A_term, "key", None))
 
 
 # ---- step-size controllers / save specification (diffrax stand-ins) ---------------------------
