@@ -115,3 +115,28 @@ def test_missing_aux_is_an_error():
     eng.set_state(np.full((16, 16), 0.5))
     with pytest.raises(P.PdeoptError, match="SBM_PSI"):
         eng.rhs(0.0)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_two_pass_ch_sbm_equals_the_literal_one_pass_kernel(dtype):
+    """CH-SBM evaluates `inner` once per cell into a work field and then the flux divergence (two launches); the
+    literal kernel re-evaluates it at 5 points per cell.  Same expressions, equal to rounding, batched and per stage."""
+    from pde_opt_amd import _lib as L
+
+    rng = np.random.default_rng(21)
+    psi = sbm_psi(80, 72)
+    eq = _eq("ch", sbm_domain(P, psi))
+    y0 = np.clip(0.5 + 0.1 * rng.standard_normal((3,) + psi.shape), 0.1, 0.9).astype(dtype)
+    outs, kernels = [], []
+    for literal in (False, True):
+        eng = P.HipEngine()
+        eng.set_fuse_stages(-1 if literal else 1)  # auto picks by size: two passes from 2^18 cells on
+        sol = P.diffeqsolve(eq, P.RK4(), 0.02, 0.02 + 5 * 2e-3, 2e-3, y0, engine=eng)
+        outs.append(sol.ys[-1])
+        kernels.append(eng.last_kernel)
+        eng.close()
+    assert kernels == ["stage_two_pass<CH-SBM>", "stage_generic<CH-SBM>"], kernels
+    assert np.isfinite(outs[0]).all() and np.any(outs[0] != y0)
+    # the two kernels are different instantiations: hipcc contracts their FMAs differently, a few ulp of the state
+    inc0, inc1 = outs[0].astype(np.float64) - y0, outs[1].astype(np.float64) - y0
+    assert rel_l2(inc0, inc1) < (1e-12 if dtype is np.float64 else 2e-5), rel_l2(inc0, inc1)
