@@ -342,7 +342,8 @@ int pdeopt_sync(pdeopt_ctx* ctx);
 int pdeopt_timer_start(pdeopt_ctx* ctx);           /* hipEventRecord on the ctx stream */
 int pdeopt_timer_stop(pdeopt_ctx* ctx, double* ms); /* record + synchronise + elapsed */
 typedef enum {
-  PDEOPT_CNT_STAGE_LAUNCHES = 0, /* fused stencil+update kernel launches so far */
+  PDEOPT_CNT_STAGE_LAUNCHES = 0, /* kernel launches of the integrators so far: fused stencil + update launches, and the
+                                    FFT passes of the hand-written Strang / IMEX pipelines */
   PDEOPT_CNT_LAST_GROUPS = 1     /* environment groups the last pdeopt_advance ran the batch in (1 = one sweep) */
 } pdeopt_counter;
 int pdeopt_get_counter(pdeopt_ctx* ctx, int which, int64_t* value);

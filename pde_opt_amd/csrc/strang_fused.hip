@@ -281,6 +281,7 @@ int launch_row(pdeopt_ctx* ctx, StrangFused& sf, double tr, double ti, double t 
                      pot.per_env ? cells : (int64_t)0, (const EnvParams<T>*)ctx->env_params_dev + w0,
                      (const Cx<T>*)sf.tw_y, (T)tr, (T)ti, p.nx, sf.partial + w0 * (p.nx / F),
                      MODE == ROW_MID ? make_spot_args<T>(ctx, t) : SpotArgs<T>{});
+  ctx->n_stage_launches++;
   PDEOPT_HIP_CHECK(ctx, hipGetLastError());
   return PDEOPT_OK;
 }
@@ -299,6 +300,7 @@ int launch_col(pdeopt_ctx* ctx, StrangFused& sf) {
   hipLaunchKernelGGL(kern, dim3(p.ny / C, ctx->win_n), dim3(C * N / PTS), lds, ctx->stream, (Cx<T>*)ctx->Y + w0 * cells,
                      (const Cx<T>*)sf.mult, (const Cx<T>*)sf.tw_x, p.ny, (const double*)sf.partial + w0 * bpe, bpe,
                      ctx->strang_dx * ctx->strang_dx);
+  ctx->n_stage_launches++;
   PDEOPT_HIP_CHECK(ctx, hipGetLastError());
   return PDEOPT_OK;
 }
@@ -518,6 +520,7 @@ int imex_rows(pdeopt_ctx* ctx, StrangFused& sf, bool forward, double dt) {
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, ctx->stream, (const Cx<T>*)cw, (T*)ctx->Y + w0 * cells,
                        (const Cx<T>*)sf.tw_y, (T)dt, p.nx, ctx->win_n);
   }
+  ctx->n_stage_launches++;
   PDEOPT_HIP_CHECK(ctx, hipGetLastError());
   return PDEOPT_OK;
 }
@@ -535,6 +538,7 @@ int imex_cols(pdeopt_ctx* ctx, StrangFused& sf) {
   hipLaunchKernelGGL(kern, dim3(p.ny / C, npairs), dim3(C * N / PTS), lds, ctx->stream,
                      (Cx<T>*)sf.cwork + (int64_t)(ctx->win_lo / 2) * p.nx * p.ny,
                      (const Cx<T>*)sf.imex_mult, (const Cx<T>*)sf.tw_x, p.ny, (const double*)nullptr, 0, 1.0);
+  ctx->n_stage_launches++;
   PDEOPT_HIP_CHECK(ctx, hipGetLastError());
   return PDEOPT_OK;
 }
