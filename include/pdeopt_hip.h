@@ -181,6 +181,12 @@ int pdeopt_configure(pdeopt_ctx* ctx, const pdeopt_problem* problem);
  * [env_count][PDEOPT_CLOSURE_MAX_COEF]. */
 int pdeopt_set_env_params(pdeopt_ctx* ctx, int env_first, int env_count, const double* kappa,
                           const double* mu_coef, const double* mob_coef);
+/* IMEX with one implicit operator PER ENVIRONMENT: environment b integrates with fourier_symbol_b = sigma[b] x the
+ * uploaded IMEX_SYMBOL (cahn_hilliard.py:74: fourier_symbol = kappa (2 pi i k)^4, so sigma[b] = kappa_b / kappa_ref
+ * when kappa is the per-environment control).  Needs a real symbol.  While some sigma != 1 the hand-written FFT
+ * passes carry ONE environment per complex field instead of two (a pair shares its multiplier), the multiplier is
+ * formed in the column pass as 1 / (N (1 + sigma_b A dt symbol)); all sigma == 1 restores the paired passes. */
+int pdeopt_set_env_imex_scale(pdeopt_ctx* ctx, int env_first, int env_count, const double* sigma);
 /* per-environment GPE interaction strength k (gross_pitaevskii.py:38-39): with a batch every
  * environment carries its own control value (BASELINE config 4 is an RL environment whose agent may act on k) */
 int pdeopt_set_env_gpe_k(pdeopt_ctx* ctx, int env_first, int env_count, const double* k);

@@ -112,6 +112,7 @@ _SIGNATURES = {
     "pdeopt_set_aux": (C.c_int, [_VP, C.c_int, _VP, C.c_int]),
     "pdeopt_set_aux_time_fn": (C.c_int, [_VP, C.c_int, AUX_FN, _VP, C.c_int]),
     "pdeopt_set_env_gpe_k": (C.c_int, [_VP, C.c_int, C.c_int, _VP]),
+    "pdeopt_set_env_imex_scale": (C.c_int, [_VP, C.c_int, C.c_int, _VP]),
     "pdeopt_set_gpe_spots": (C.c_int, [_VP, C.c_int, C.c_int, C.c_int, _VP, C.c_double, C.c_double]),
     "pdeopt_set_state": (C.c_int, [_VP, C.c_int, C.c_int, _VP]),
     "pdeopt_get_state": (C.c_int, [_VP, C.c_int, C.c_int, _VP]),

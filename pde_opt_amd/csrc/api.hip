@@ -81,6 +81,7 @@ void fill_env_params(pdeopt_ctx* ctx) {
     e[b].kappa = T(p.kappa);
     e[b].gpe_k = T(p.gpe_k);
     e[b].kscale = T(1);
+    e[b].imex_scale = T(1);
     for (int k = 0; k < kMaxCoef; ++k) {
       e[b].mu[k] = k < p.mu.n ? T(p.mu.coef[k]) : T(0);
       e[b].mob[k] = k < p.mob.n ? T(p.mob.coef[k]) : T(0);
@@ -107,6 +108,15 @@ template <typename T>
 void patch_env_gpe_k(pdeopt_ctx* ctx, int first, int count, const double* k) {
   auto* e = reinterpret_cast<EnvParams<T>*>(ctx->env_params_host.data());
   for (int i = 0; i < count; ++i) e[first + i].gpe_k = T(k[i]);
+}
+
+template <typename T>
+bool patch_imex_scale(pdeopt_ctx* ctx, int first, int count, const double* sigma) {
+  auto* e = reinterpret_cast<EnvParams<T>*>(ctx->env_params_host.data());
+  for (int i = 0; i < count; ++i) e[first + i].imex_scale = T(sigma[i]);
+  bool any = false;
+  for (int b = 0; b < ctx->prob.batch; ++b) any = any || e[b].imex_scale != T(1);
+  return any;
 }
 
 template <typename T>
@@ -344,6 +354,7 @@ int pdeopt_configure(pdeopt_ctx* ctx, const pdeopt_problem* pr) {
   if ((rc = ensure_buffer(ctx, &ctx->env_params_dev, ctx->env_params_host.size()))) return rc;
   ctx->win_lo = 0;
   ctx->win_n = pr->batch;
+  ctx->imex_per_env = false;
   ctx->configured = true;
   return upload_env_params(ctx);
 }
@@ -448,6 +459,18 @@ int pdeopt_set_gpe_spots(pdeopt_ctx* ctx, int env_first, int env_count, int n_sp
   PDEOPT_HIP_CHECK(ctx, hipMemcpyAsync(ctx->spots_dev, packed.data(), bytes, hipMemcpyHostToDevice, ctx->stream));
   PDEOPT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   return PDEOPT_OK;
+}
+
+int pdeopt_set_env_imex_scale(pdeopt_ctx* ctx, int env_first, int env_count, const double* sigma) {
+  if (!ctx || !sigma) return PDEOPT_EINVAL;
+  int rc = check_envs(ctx, env_first, env_count);
+  if (rc) return rc;
+  for (int i = 0; i < env_count; ++i)
+    if (!(sigma[i] > 0.0)) return fail(ctx, PDEOPT_EINVAL, "imex scale %g of environment %d must be positive", sigma[i], env_first + i);
+  PDEOPT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  ctx->imex_per_env = ctx->prob.dtype == PDEOPT_F32 ? patch_imex_scale<float>(ctx, env_first, env_count, sigma)
+                                                    : patch_imex_scale<double>(ctx, env_first, env_count, sigma);
+  return upload_env_params(ctx);
 }
 
 int pdeopt_set_env_gpe_k(pdeopt_ctx* ctx, int env_first, int env_count, const double* k) {

@@ -25,7 +25,7 @@ struct EnvParams {
   T kappa;
   T gpe_k;
   T kscale;  // slope scale dt_b / dt_ref of per-environment step sizes (pdeopt_tsit5_trial_env); 1 otherwise
-  T r1;
+  T imex_scale;  // sigma_b: this environment's fourier_symbol = sigma_b x the uploaded one (pdeopt_set_env_imex_scale)
   T mu[kMaxCoef];
   T mob[kMaxCoef];
   T fe[kMaxCoef];  // free-energy density closure (smoothed-boundary equations)
@@ -170,6 +170,7 @@ struct pdeopt_ctx {
   void* spots_dev = nullptr;
   std::vector<pdeopt_light_spot> spots_host;  // [batch][PDEOPT_MAX_SPOTS]
   double spots_x_first = 0.0, spots_y_first = 0.0;
+  bool imex_per_env = false;  // some environment has imex_scale != 1: one environment per complex field
   int launch_part = 0;        // tiles of the next stage-pair launches: 0 all, 1 interior, 2 edge (pdeopt_rk4_phase_part)
   int win_lo = 0, win_n = 0;  // environment window the stage launchers operate on
   int64_t last_groups = 1;    // environment groups of the last advance (PDEOPT_CNT_LAST_GROUPS)

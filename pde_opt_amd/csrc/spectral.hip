@@ -682,6 +682,8 @@ int advance_imex(pdeopt_ctx* ctx, double, double dt, int64_t n) {
   if (!ctx->aux[PDEOPT_AUX_IMEX_SYMBOL].dev)
     return fail(ctx, PDEOPT_ESTATE, "IMEX needs the IMEX_SYMBOL aux field (fourier_symbol)");
   if (imex_fused_supported(ctx)) return advance_imex_fused(ctx, dt, n);  // FFTs in LDS, 4 kernels per substep
+  if (ctx->imex_per_env)
+    return fail(ctx, PDEOPT_EINVAL, "per-environment IMEX scales need the hand-written FFT passes (power-of-two grids 64..1024)");
   int rc = ensure_plans(ctx);
   if (rc) return rc;
   return ctx->prob.dtype == PDEOPT_F32 ? imex_t<float>(ctx, dt, n) : imex_t<double>(ctx, dt, n);

@@ -35,6 +35,8 @@ struct StrangFused {
   bool mult_valid = false;
   // IMEX on the same transforms
   void* cwork = nullptr;      // complex work field [batch][nx][ny]
+  size_t cwork_bytes = 0;
+  bool imex_sym_real = true;  // the uploaded fourier_symbol has no imaginary part (per-environment scales need that)
   void* imex_mult = nullptr;  // 1 / ((1 + A dt symbol) nx ny)
   double imex_dt = NAN, imex_A = NAN;
   bool imex_valid = false;
@@ -165,7 +167,9 @@ __global__ __launch_bounds__(C* N / PTS) void strang_col_reg_kernel(Cx<T>* __res
                                                                   const Cx<T>* __restrict__ mult,
                                                                   const Cx<T>* __restrict__ tw, int ny,
                                                                   const double* __restrict__ partial,
-                                                                  int blocks_per_env, double dx2) {
+                                                                  int blocks_per_env, double dx2,
+                                                                  const EnvParams<T>* __restrict__ sigma_ep = nullptr,
+                                                                  T inv_n = T(0)) {
   using E = RegFft<T, N, PTS>;
   constexpr int NP = fft_lds_pitch<N>();
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -210,9 +214,16 @@ __global__ __launch_bounds__(C* N / PTS) void strang_col_reg_kernel(Cx<T>* __res
     E::template dif<-1, false>(v, seq, tw, j);
   T scale = T(1);
   if constexpr (SCALED) scale = (T)scale_sh;
+  // IMEX with a per-environment implicit operator (one environment per complex field): the stored multiplier is
+  // M0 = 1 / (N (1 + A dt symbol)), real; this environment's is 1 / (N (1 + sigma (1 / (N M0) - 1)))
+  const T sigma = sigma_ep ? sigma_ep[env].imex_scale : T(1);
 #pragma unroll
   for (int sl = 0; sl < PTS; ++sl) {
     Cx<T> m = WL ? mb[E::freq(ji, sl)] : mb[E::freq(j, sl) * ny + c];
+    if (sigma_ep) {
+      m.re = inv_n / (T(1) + sigma * (inv_n / m.re - T(1)));
+      m.im = T(0);
+    }
     m.re *= scale;
     m.im *= scale;
     v[sl] = cmul(v[sl], m);
@@ -299,7 +310,7 @@ int launch_col(pdeopt_ctx* ctx, StrangFused& sf) {
   const int bpe = p.nx / row_pass_rows_rt<T>(p.ny);  // norm partials per environment
   hipLaunchKernelGGL(kern, dim3(p.ny / C, ctx->win_n), dim3(C * N / PTS), lds, ctx->stream, (Cx<T>*)ctx->Y + w0 * cells,
                      (const Cx<T>*)sf.mult, (const Cx<T>*)sf.tw_x, p.ny, (const double*)sf.partial + w0 * bpe, bpe,
-                     ctx->strang_dx * ctx->strang_dx);
+                     ctx->strang_dx * ctx->strang_dx, (const EnvParams<T>*)nullptr, T(0));
   ctx->n_stage_launches++;
   PDEOPT_HIP_CHECK(ctx, hipGetLastError());
   return PDEOPT_OK;
@@ -442,7 +453,8 @@ int strang_fused_t(pdeopt_ctx* ctx, double t0, double dt, int64_t n) {
 // 16) with no hermitian packing.  An odd batch leaves the last sequence with a zero imaginary part.
 template <typename T, int N>
 __global__ __launch_bounds__(256) void imex_row_fwd_reg_kernel(const T* __restrict__ k, Cx<T>* __restrict__ c,
-                                                               const Cx<T>* __restrict__ tw, int nx, int batch) {
+                                                               const Cx<T>* __restrict__ tw, int nx, int batch,
+                                                               int pack /* environments per complex field: 2, or 1 */) {
   using E = RegFft<T, N>;
   constexpr int PTS = reg_default_pts<N>(), TT = E::TT, F = 256 / TT, NP = fft_lds_pitch<N>();
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -452,8 +464,8 @@ __global__ __launch_bounds__(256) void imex_row_fwd_reg_kernel(const T* __restri
   const int64_t prow = (int64_t)blockIdx.x * F + f;  // row index in the pair-packed field
   const int pair = (int)(prow / nx);
   const int64_t r = prow - (int64_t)pair * nx;
-  const T* const ka = k + ((int64_t)(2 * pair) * nx + r) * N;
-  const bool has_b = 2 * pair + 1 < batch;
+  const T* const ka = k + ((int64_t)(pack * pair) * nx + r) * N;
+  const bool has_b = pack == 2 && 2 * pair + 1 < batch;
   const T* const kb = ka + (int64_t)nx * N;
   Cx<T> v[PTS];
 #pragma unroll
@@ -470,7 +482,7 @@ __global__ __launch_bounds__(256) void imex_row_fwd_reg_kernel(const T* __restri
 template <typename T, int N>
 __global__ __launch_bounds__(256) void imex_row_inv_reg_kernel(const Cx<T>* __restrict__ c, T* __restrict__ y,
                                                                const Cx<T>* __restrict__ tw, T dt, int nx,
-                                                               int batch) {
+                                                               int batch, int pack) {
   using E = RegFft<T, N>;
   constexpr int PTS = reg_default_pts<N>(), TT = E::TT, F = 256 / TT, NP = fft_lds_pitch<N>();
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -485,8 +497,8 @@ __global__ __launch_bounds__(256) void imex_row_inv_reg_kernel(const Cx<T>* __re
 #pragma unroll
   for (int sl = 0; sl < PTS; ++sl) v[sl] = g[E::freq(j, sl)];
   E::template dit<+1>(v, seq, tw, j);
-  T* const ya = y + ((int64_t)(2 * pair) * nx + r) * N;
-  const bool has_b = 2 * pair + 1 < batch;
+  T* const ya = y + ((int64_t)(pack * pair) * nx + r) * N;
+  const bool has_b = pack == 2 && 2 * pair + 1 < batch;
   T* const yb = ya + (int64_t)nx * N;
 #pragma unroll
   for (int m = 0; m < PTS; ++m) {
@@ -503,22 +515,23 @@ int imex_rows(pdeopt_ctx* ctx, StrangFused& sf, bool forward, double dt) {
   const pdeopt_problem& p = ctx->prob;
   // environment window (win_lo even): pointers pre-offset, the kernels see win_n environments
   const int64_t cells = (int64_t)p.nx * p.ny, w0 = ctx->win_lo;
-  const int npairs = (ctx->win_n + 1) / 2;
+  const int pack = ctx->imex_per_env ? 1 : 2;  // environments per complex field
+  const int npairs = (ctx->win_n + pack - 1) / pack;
   const size_t lds = (size_t)F * fft_lds_pitch<N>() * sizeof(Cx<T>);
   const int blocks = (int)((int64_t)npairs * p.nx / F);
-  Cx<T>* const cw = (Cx<T>*)sf.cwork + (w0 / 2) * cells;
+  Cx<T>* const cw = (Cx<T>*)sf.cwork + (w0 / pack) * cells;
   if (forward) {
     auto kern = imex_row_fwd_reg_kernel<T, N>;
     int rc = allow_lds(ctx, kern, lds);
     if (rc) return rc;
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, ctx->stream, (const T*)ctx->TA + w0 * cells, cw,
-                       (const Cx<T>*)sf.tw_y, p.nx, ctx->win_n);
+                       (const Cx<T>*)sf.tw_y, p.nx, ctx->win_n, pack);
   } else {
     auto kern = imex_row_inv_reg_kernel<T, N>;
     int rc = allow_lds(ctx, kern, lds);
     if (rc) return rc;
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, ctx->stream, (const Cx<T>*)cw, (T*)ctx->Y + w0 * cells,
-                       (const Cx<T>*)sf.tw_y, (T)dt, p.nx, ctx->win_n);
+                       (const Cx<T>*)sf.tw_y, (T)dt, p.nx, ctx->win_n, pack);
   }
   ctx->n_stage_launches++;
   PDEOPT_HIP_CHECK(ctx, hipGetLastError());
@@ -530,14 +543,17 @@ int imex_cols(pdeopt_ctx* ctx, StrangFused& sf) {
   constexpr int C = cols_per_block<T>();
   constexpr int PTS = col_pts<T, N>();
   const pdeopt_problem& p = ctx->prob;
-  const int npairs = (ctx->win_n + 1) / 2;
+  const int pack = ctx->imex_per_env ? 1 : 2;
+  const int npairs = (ctx->win_n + pack - 1) / pack;
   const size_t lds = (size_t)C * fft_lds_pitch<N>() * sizeof(Cx<T>);
   auto kern = strang_col_reg_kernel<T, N, C, PTS, false>;  // FFT_x -> * multiplier -> IFFT_x, in place
   int rc = allow_lds(ctx, kern, lds);
   if (rc) return rc;
   hipLaunchKernelGGL(kern, dim3(p.ny / C, npairs), dim3(C * N / PTS), lds, ctx->stream,
-                     (Cx<T>*)sf.cwork + (int64_t)(ctx->win_lo / 2) * p.nx * p.ny,
-                     (const Cx<T>*)sf.imex_mult, (const Cx<T>*)sf.tw_x, p.ny, (const double*)nullptr, 0, 1.0);
+                     (Cx<T>*)sf.cwork + (int64_t)(ctx->win_lo / pack) * p.nx * p.ny,
+                     (const Cx<T>*)sf.imex_mult, (const Cx<T>*)sf.tw_x, p.ny, (const double*)nullptr, 0, 1.0,
+                     ctx->imex_per_env ? (const EnvParams<T>*)ctx->env_params_dev + ctx->win_lo : nullptr,
+                     (T)(1.0 / ((double)p.nx * p.ny)));
   ctx->n_stage_launches++;
   PDEOPT_HIP_CHECK(ctx, hipGetLastError());
   return PDEOPT_OK;
@@ -555,7 +571,15 @@ int imex_fused_t(pdeopt_ctx* ctx, double dt, int64_t n) {
     if ((rc = upload_table<T>(ctx, &sf.tw_y, p.ny))) return rc;
   }
   if ((rc = ensure_buffer(ctx, &ctx->TA, ctx->total_bytes))) return rc;
-  if ((rc = ensure_buffer(ctx, &sf.cwork, (size_t)cells * ((p.batch + 1) / 2) * sizeof(Cx<T>)))) return rc;
+  // one complex field per PAIR of environments, or per environment when their implicit operators differ
+  const size_t cwork_need = (size_t)cells * (ctx->imex_per_env ? (size_t)p.batch : (size_t)((p.batch + 1) / 2)) * sizeof(Cx<T>);
+  if (sf.cwork && sf.cwork_bytes < cwork_need) {
+    PDEOPT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    (void)hipFree(sf.cwork);
+    sf.cwork = nullptr;
+  }
+  if ((rc = ensure_buffer(ctx, &sf.cwork, cwork_need))) return rc;
+  sf.cwork_bytes = std::max(sf.cwork_bytes, cwork_need);
   if (!sf.imex_valid || sf.imex_dt != dt || sf.imex_A != ctx->imex_A) {
     // 1 / ((1 + A dt fourier_symbol) nx ny): solvers.py:62-63 with the 1/N of the inverse folded in
     const AuxField& a = ctx->aux[PDEOPT_AUX_IMEX_SYMBOL];
@@ -571,7 +595,11 @@ int imex_fused_t(pdeopt_ctx* ctx, double dt, int64_t n) {
     // two real environments per complex field (imex_row_fwd_reg_kernel), which needs the real-to-real form
     std::vector<std::complex<double>> mfull((size_t)cells);
     const double inv_n = 1.0 / (double)cells;
-    for (int64_t i = 0; i < cells; ++i) mfull[i] = inv_n / (1.0 + ctx->imex_A * dt * sym[i]);
+    sf.imex_sym_real = true;
+    for (int64_t i = 0; i < cells; ++i) {
+      mfull[i] = inv_n / (1.0 + ctx->imex_A * dt * sym[i]);
+      sf.imex_sym_real = sf.imex_sym_real && sym[i].imag() == 0.0;
+    }
     std::vector<Cx<T>> m((size_t)cells);
     for (int kx = 0; kx < p.nx; ++kx) {
       const int mx = (p.nx - kx) % p.nx;
@@ -589,6 +617,8 @@ int imex_fused_t(pdeopt_ctx* ctx, double dt, int64_t n) {
     sf.imex_dt = dt;
     sf.imex_A = ctx->imex_A;
   }
+  if (ctx->imex_per_env && !sf.imex_sym_real)
+    return fail(ctx, PDEOPT_EINVAL, "per-environment IMEX scales need a real fourier_symbol");
   // group by group (an even number of environments each): state + slope + spectrum work field are 12 B/cell
   int group = p.batch;
   if (ctx->opt_group_envs > 0) {

@@ -228,6 +228,12 @@ class HipEngine:
         self._check(self._lib.pdeopt_set_gpe_spots(self._h, int(env_first), a.shape[0], a.shape[1],
                                                    a.ctypes.data_as(C.c_void_p), float(x_first), float(y_first)))
 
+    def set_env_imex_scale(self, env_first: int, sigma):
+        """IMEX: environment b integrates with ``sigma[b] x`` the uploaded ``fourier_symbol`` (a per-environment
+        ``kappa``); all ones restores the paired transforms"""
+        a = np.ascontiguousarray(np.atleast_1d(np.asarray(sigma, dtype=np.float64)))
+        self._check(self._lib.pdeopt_set_env_imex_scale(self._h, int(env_first), a.shape[0], a.ctypes.data_as(C.c_void_p)))
+
     def set_env_gpe_k(self, env_first: int, k):
         """per-environment GPE interaction strength (the control value travels with the environment)"""
         a = np.ascontiguousarray(np.atleast_1d(np.asarray(k, dtype=np.float64)))

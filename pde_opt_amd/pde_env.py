@@ -176,9 +176,11 @@ class VectorPDEEnv:
     *coefficients* (same closure structure across the batch) travel in per-environment tables, fields
     that depend on the control (the GPE potential for ``e`` / ``lights`` / ``trap_factor``, face velocities
     of advection-diffusion) are uploaded per environment, so the whole batch still runs in one launch per
-    stage.  A control the kernels cannot vary inside one batch (see ``_per_env_controls`` of the equation
-    class; the IMEX solver's ``fourier_symbol`` when ``kappa`` is the control) raises ``ValueError`` as
-    soon as two environments disagree on it -- never a silently shared value.
+    stage.  Under the IMEX solver a per-environment ``kappa`` also means a per-environment implicit operator
+    (``fourier_symbol = kappa (2 pi i k)^4``): the transforms then carry one environment per complex field
+    instead of two (``pdeopt_set_env_imex_scale``).  A control the kernels cannot vary inside one batch (see
+    ``_per_env_controls`` of the equation class) raises ``ValueError`` as soon as two environments disagree on
+    it -- never a silently shared value.
 
     ``reward`` / observations: ``reward_function`` and ``state_to_observation_func`` are applied
     per environment on host copies unless ``device_reward`` names an on-device reduction
@@ -314,13 +316,6 @@ class VectorPDEEnv:
             raise ValueError(
                 f"{type(eq0).__name__}: the control parameter {name!r} cannot differ between the environments "
                 f"of one VectorPDEEnv (per-environment controls: {sorted(type(eq0)._per_env_controls)})")
-        from .numerics.solvers import SemiImplicitFourierSpectral
-
-        if self.solver_type is SemiImplicitFourierSpectral and name == "kappa":
-            raise ValueError(
-                "SemiImplicitFourierSpectral with a per-environment kappa: fourier_symbol = kappa (2 pi i k)^4 "
-                "would differ between environments, and the batched IMEX transforms share one implicit "
-                "operator; use one PDEEnv per kappa or an explicit integrator")
 
     def step(self, actions: Sequence):
         from .integrate import constant_step_plan
@@ -339,6 +334,11 @@ class VectorPDEEnv:
         type(eq0)._engine_upload_batch(self._engine, eqs, 0.0, self.step_dt)
         solver = self.solver_type(**prepare_solver_params(self.solver_type, self.solver_parameters, eq0))
         solver.configure_engine(self._engine, eq0)
+        if solver.integrator == L.INT_IMEX:
+            # fourier_symbol = kappa (2 pi i k)^4 (cahn_hilliard.py:74): with kappa as the per-environment control
+            # every environment has its own implicit operator = sigma_b x environment 0's
+            k0 = float(getattr(eq0, "kappa", 1.0))
+            self._engine.set_env_imex_scale(0, [float(getattr(e, "kappa", k0)) / k0 for e in eqs])
         n_full, rem = constant_step_plan(0.0, self.step_dt, self.numeric_dt)
         if n_full:
             self._engine.advance(solver.integrator, self.numeric_dt, n_full, 0.0)

@@ -32,6 +32,7 @@ class OracleEngine:
         self.fe = fe
         self.kappa_env = np.full(batch, float(kappa))
         self.gpe_k_env = np.full(batch, float(gpe_k))
+        self.imex_sigma = np.ones(batch)
         self.time_scale, self.strang_dx = 1.0, 1.0
 
     def set_aux(self, which, field, per_env=False, key=None):
@@ -80,6 +81,10 @@ class OracleEngine:
         for a0, a1, x0, x1, y0, y1, c in self.spots[b]:
             w = w + (a0 + a1 * t) * np.exp(-((X - x0 - x1 * t) ** 2 + (Y - y0 - y1 * t) ** 2) * c)
         return w
+
+    def set_env_imex_scale(self, env_first, sigma):
+        sigma = np.atleast_1d(np.asarray(sigma, dtype=float))
+        self.imex_sigma[env_first:env_first + len(sigma)] = sigma
 
     def set_env_gpe_k(self, env_first, k):
         k = np.atleast_1d(np.asarray(k, dtype=float))
@@ -139,7 +144,7 @@ class OracleEngine:
                 elif integrator == L.INT_TSIT5:
                     u = O.tsit5_step(f, t, u, dt)[0]
                 elif integrator == L.INT_IMEX:
-                    u = O.imex_step(f, t, u, dt, self.imex_A, self.symbol)
+                    u = O.imex_step(f, t, u, dt, self.imex_A, self.imex_sigma[b] * self.symbol)
                 elif integrator == L.INT_STRANG:
                     # b = -i (V(t0) + k |psi0|^2): the ABI's decomposition of gross_pitaevskii.py:67-75
                     def bterm(tt, yy, b=b):

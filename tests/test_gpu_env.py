@@ -103,6 +103,29 @@ def test_vector_env_matches_single_envs():
         e.close()
 
 
+def test_vector_env_imex_with_per_environment_kappa():
+    """IMEX + kappa as the per-environment control: every environment gets its own implicit operator"""
+    dom = std_domain(P, 64, 64)
+    kw = _env_kwargs(dom, P.SemiImplicitFourierSpectral, {"A": 0.5}, step_dt=1e-5, numeric_dt=1e-6)
+    venv = P.VectorPDEEnv(3, **kw, device_reward="var")
+    venv.reset(seed=20)
+    singles = []
+    for b in range(3):
+        e = P.PDEEnv(**kw)
+        e.reset(seed=20 + b)
+        singles.append(e)
+    for actions in ([0, 1, 2], [2, 2, 0]):
+        venv.step(actions)
+        states = venv.states
+        for b, e in enumerate(singles):
+            e.step(actions[b])
+            assert rel_l2(states[b] - _reset(dom, 20 + b), e._state - _reset(dom, 20 + b)) < 1e-9
+    venv.step([1, 1, 1])  # equal kappas again: paired transforms
+    venv.close()
+    for e in singles:
+        e.close()
+
+
 def test_device_observation_uint8():
     dom = std_domain(P, 64, 128)
     kw = _env_kwargs(dom)

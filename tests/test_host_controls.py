@@ -191,9 +191,17 @@ def test_vector_env_rejects_controls_it_cannot_vary():
                           reset_control_value=0.002, static_equation_parameters={"mu": MU["regsol"], "D": MOB["c1mc"]},
                           control_equation_parameter_name="kappa", solver_parameters={"A": 0.5}, engine=OracleEngine(), **common)
     venv.reset(seed=0)
-    venv.step([0, 0])  # equal controls are fine
-    with pytest.raises(ValueError, match="per-environment kappa"):
-        venv.step([0, 1])
+    venv.step([0, 0])
+    venv.step([0, 1])  # per-environment kappa under IMEX: per-environment implicit operator
+    singles = []
+    for b in range(2):
+        e = P.PDEEnv(equation_type=P.CahnHilliard2DPeriodic, solver_type=P.SemiImplicitFourierSpectral,
+                     reset_control_value=0.002, static_equation_parameters={"mu": MU["regsol"], "D": MOB["c1mc"]},
+                     control_equation_parameter_name="kappa", solver_parameters={"A": 0.5}, engine=OracleEngine(), **common)
+        e.reset(seed=b)
+        e.step(0)
+        e.step(b)
+        np.testing.assert_allclose(venv.states[b], e._state, rtol=0, atol=1e-14)
     # derivs is structural: cannot differ inside one batch
     venv = P.VectorPDEEnv(2, equation_type=P.CahnHilliard2DPeriodic, solver_type=P.RK4,
                           reset_control_value=0.0, static_equation_parameters={"kappa": 0.002, "mu": MU["regsol"], "D": MOB["c1mc"]},
