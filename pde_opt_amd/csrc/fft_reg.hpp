@@ -45,6 +45,9 @@ struct RegFft {
   static constexpr int TT = N / PTS;  // threads per sequence
   static constexpr int L = P::stages;
   static constexpr bool kWaveLocal = TT <= 64;
+  static constexpr int kPts = PTS;
+  using LdsT = C;                                   // element type of a sequence's LDS image
+  static constexpr int NP = fft_lds_pitch<N>();     // and its length
   static_assert(PTS == 8 || PTS == 16, "8 or 16 points per thread");
   static_assert(PTS % P::radix(0) == 0, "a thread owns whole butterflies");
 

@@ -2,7 +2,7 @@
 # usage: tools/sweep.sh "<common bench args>" "<arg name>" v1 v2 ...   (runs bench.py per value, prints one line each)
 COMMON=$1; NAME=$2; shift 2
 for v in "$@"; do
-  python bench.py --no-cpu-baseline $COMMON $NAME $v 2>&1 | tail -1 | python -c "
+  python bench.py --no-cpu-baseline --no-parity-spot --no-api $COMMON $NAME $v 2>&1 | tail -1 | python -c "
 import json,sys
 line=sys.stdin.read()
 try:
