@@ -56,7 +56,11 @@ typedef enum {
   /* smoothed-boundary variants: psi = domain.geometry.smooth is an aux field */
   PDEOPT_EQ_ALLEN_CAHN_SBM = 4,     /* allen_cahn.py:88-159    -R (mu_h - kappa/psi div(psi grad u) - wall sqrt(2 f)) */
   PDEOPT_EQ_CAHN_HILLIARD_SBM = 5,  /* cahn_hilliard.py:204-289 div(psi D grad(inner))/psi + source                  */
-  PDEOPT_EQ_CAHN_HILLIARD_3D = 6    /* cahn_hilliard.py:113-200: fields are [batch][nx][ny][nz] */
+  PDEOPT_EQ_CAHN_HILLIARD_3D = 6,   /* cahn_hilliard.py:113-200: fields are [batch][nx][ny][nz] */
+  /* shapes.py:39-64, Shape.smooth_shape: u_t = 2 (c lap u + (1 - c) u_nn) - 18 u (1 - u)(1 - 2u) / eps^2 with centred
+   * differences, u_nn the second derivative along grad u.  pdeopt_problem.kappa carries c (smooth_curvature),
+   * pdeopt_problem.gpe_k carries eps (smooth_epsilon); no closures */
+  PDEOPT_EQ_SHAPE_SMOOTH = 7
 } pdeopt_equation;
 
 /* which solver.step() is fused around it */

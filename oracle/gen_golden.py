@@ -60,12 +60,26 @@ def load_reference():
     class _Results:
         successful = 0
 
+    class _ODETerm:  # dfx.ODETerm(vector_field): keeps the function so that a caller can evaluate it
+        def __init__(self, vector_field=None):
+            self.vector_field = vector_field
+
+    def _capture_solve(term, solver, t0=None, t1=None, dt0=None, y0=None, **kw):
+        """stand-in for dfx.diffeqsolve: no time stepping here (diffrax is absent); records the term and returns
+        the initial state, which lets Shape.__post_init__ (shapes.py:34-37) finish and hands its RHS closure out"""
+        _capture_solve.last = types.SimpleNamespace(term=term, t0=t0, t1=t1, dt0=dt0, y0=y0, kw=kw)
+        return types.SimpleNamespace(ys=[y0])
+
     _mod(
         "diffrax",
         AbstractSolver=object,
-        ODETerm=object,
+        ODETerm=_ODETerm,
         LocalLinearInterpolation=object,
         RESULTS=_Results,
+        diffeqsolve=_capture_solve,
+        Tsit5=lambda *a, **k: None,
+        PIDController=lambda *a, **k: None,
+        SaveAt=lambda *a, **k: None,
     )
     for p in (
         "pde_opt",
@@ -103,6 +117,10 @@ def load_reference():
     )
     ns.solvers = _load("pde_opt.numerics.solvers", "pde_opt/numerics/solvers.py")
     ns.rl_utils = _load("pde_opt.rl_utils", "pde_opt/rl_utils.py")
+    # the real shapes.py last (the equations above only needed the name `Shape`); its diffeqsolve call lands in
+    # _capture_solve
+    ns.shapes = _load("pde_opt.numerics.shapes", "pde_opt/numerics/shapes.py")
+    ns.capture_solve = _capture_solve
     return ns
 
 
@@ -438,6 +456,44 @@ def round2(ref):
         c3[f"{tag}/u"] = u
         c3[f"{tag}/rhs"] = np.asarray(eq.rhs(u, 0.0))
     np.savez_compressed(os.path.join(OUT, "ch3d_fourier.npz"), **c3)
+
+    # ---- Shape (shapes.py:21-203): the smoothing right-hand side of smooth_shape (:44-64, a closure handed to
+    # dfx.diffeqsolve -- evaluated here through the capturing stand-in), the graph Laplacian of the mask
+    # (:81-143) and the eigenvalues of its lowest modes (:145-203)
+    sh = {}
+    masks = {}
+    X, Y = np.meshgrid(np.arange(48) + 0.5, np.arange(40) + 0.5, indexing="ij")
+    masks["disc48x40"] = (((X - 24.0) / 15.0) ** 2 + ((Y - 20.0) / 11.0) ** 2 < 1.0).astype(np.float64)
+    m = np.zeros((32, 32))
+    m[6:26, 9:21] = 1.0
+    m[12:18, 21:29] = 1.0
+    masks["tee32"] = m
+    for name, mask in masks.items():
+        for (dx, eps, curv) in (((1.0, 1.0), 1.0, 0.0), ((0.5, 0.8), 2.0, 0.3), ((1.0, 1.0), 0.7, 1.0)):
+            shape = ref.shapes.Shape(mask, dx=dx, smooth_epsilon=eps, smooth_curvature=curv)
+            cap = ref.capture_solve.last
+            rhs = cap.term.vector_field
+            tag = f"{name}/dx{dx[0]}_{dx[1]}_eps{eps}_c{curv}"
+            # a smeared field (the binary itself has |grad u| = 0 almost everywhere) and the raw mask
+            u = mask.copy()
+            for _ in range(3):
+                u = 0.2 * (u + np.roll(u, 1, 0) + np.roll(u, -1, 0) + np.roll(u, 1, 1) + np.roll(u, -1, 1))
+            u = u + 0.02 * rng.standard_normal(u.shape)
+            sh[f"{tag}/u"] = u
+            sh[f"{tag}/rhs"] = np.asarray(rhs(0.0, u, None))
+            sh[f"{tag}/rhs_binary"] = np.asarray(rhs(0.0, mask, None))
+            sh[f"{tag}/solve_args"] = np.array([cap.t0, cap.t1, cap.dt0])
+            sh[f"{tag}/post_init_of_y0"] = np.asarray(shape.smooth)  # the clamps of :36-37 applied to ys[-1] = binary
+        sh[f"{name}/mask"] = mask
+        for periodic in (False, True):
+            lap, ids = ref.shapes.Shape(mask).laplacian_from_mask(periodic=periodic)
+            sh[f"{name}/laplacian_{'periodic' if periodic else 'open'}"] = lap.toarray()
+            sh[f"{name}/ids"] = ids
+        shp = ref.shapes.Shape(mask)
+        shp.get_shape_modes(6)
+        sh[f"{name}/mode_evals"] = np.asarray(shp.shape_basis_evals)
+        sh[f"{name}/mode_basis_abs_sum"] = np.abs(np.asarray(shp.shape_basis)).sum(axis=(0, 1))
+    np.savez_compressed(os.path.join(OUT, "shapes.npz"), **sh)
 
 
 if __name__ == "__main__":

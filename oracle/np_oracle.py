@@ -73,6 +73,21 @@ def div_face(F, h, axis):
     return (F - nb(F, -1, axis)) / h
 
 
+def grad_c(a, h, axis):
+    """centred first difference, derivatives.py:62-74."""
+    return 0.5 * (nb(a, 1, axis) - nb(a, -1, axis)) / h
+
+
+def grad2_c(a, h, axis):
+    """centred second difference, derivatives.py:77-89."""
+    return (nb(a, 1, axis) - 2 * a + nb(a, -1, axis)) / h**2
+
+
+def grad2xy_c(a, hx, hy):
+    """centred mixed second difference, derivatives.py:92-99."""
+    return (nb(nb(a, 1, 0), 1, 1) + nb(nb(a, -1, 0), -1, 1) - nb(nb(a, 1, 0), -1, 1) - nb(nb(a, -1, 0), 1, 1)) / (4.0 * hx * hy)
+
+
 # --------------------------------------------------------------------------
 # right-hand sides
 # --------------------------------------------------------------------------
@@ -161,6 +176,20 @@ def ch_sbm_rhs(u, psi, hx, hy, kappa, f, mu_h, D, theta_t, flux_t, left_half):
     Fx = avg_face(psi, 0) * avg_face(Du, 0) * grad_face(inner, hx, 0)
     Fy = avg_face(psi, 1) * avg_face(Du, 1) * grad_face(inner, hy, 1)
     return (div_face(Fx, hx, 0) + div_face(Fy, hy, 1)) / psi + sbm_norm_grad(psi, hx, hy) * flux_t
+
+
+def shape_smooth_rhs(u, hx, hy, eps, curvature):
+    """Right-hand side of ``Shape.smooth_shape`` (shapes.py:41-64): Allen-Cahn smoothing of a mask whose diffusion
+    acts along the normal for ``curvature = 0`` (no curvature flow) and isotropically for ``curvature = 1``:
+    ``2 (c lap u + (1 - c) u_nn) - W'(u) / eps`` with ``W'(u) = 18 / eps * u (1 - u)(1 - 2u)`` and ``u_nn`` the
+    second derivative along ``grad u`` (``|grad u|^2 < 1e-7`` replaced by 1, :53)."""
+    gx, gy = grad_c(u, hx, 0), grad_c(u, hy, 1)
+    gxx, gyy, gxy = grad2_c(u, hx, 0), grad2_c(u, hy, 1), grad2xy_c(u, hx, hy)
+    g2 = gx**2 + gy**2
+    g2 = np.where(g2 < 1e-7, 1.0, g2)
+    unn = (gxx * gx**2 + 2.0 * gxy * gx * gy + gyy * gy**2) / g2
+    pot = 18.0 / eps * u * (1.0 - u) * (1.0 - 2.0 * u)
+    return 2.0 * (curvature * (gxx + gyy) + (1.0 - curvature) * unn) - pot / eps
 
 
 def fft_wavenumbers(nx, ny, hx, hy):

@@ -28,6 +28,7 @@ from .numerics.functions import (
     GaussianSpots,
     LegendrePolynomialExpansion,
 )
+from .numerics.shapes import Shape
 from .numerics.solvers import (
     RK4,
     ConstantStepSize,
@@ -45,7 +46,7 @@ __all__ = [
     "PDEModel", "PDEEnv", "VectorPDEEnv", "HipEngine", "diffeqsolve", "Solution",
     "BaseEquation", "AllenCahn2DPeriodic", "CahnHilliard2DPeriodic", "AdvectionDiffusion2D", "GPE2DTSControl",
     "AllenCahn2DSmoothedBoundary", "CahnHilliard2DSmoothedBoundary", "CahnHilliard3DPeriodic",
-    "Domain", "LegendrePolynomialExpansion", "DiffusionLegendrePolynomials", "ChemicalPotentialLegendrePolynomials",
+    "Domain", "Shape", "LegendrePolynomialExpansion", "DiffusionLegendrePolynomials", "ChemicalPotentialLegendrePolynomials",
     "GaussianSpot", "GaussianSpots",
     "SemiImplicitFourierSpectral", "StrangSplitting", "Euler", "RK4", "Tsit5",
     "ConstantStepSize", "PIDController", "SaveAt",

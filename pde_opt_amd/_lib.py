@@ -24,6 +24,7 @@ DERIVS_FD, DERIVS_FOURIER = 0, 1
 EQ_CAHN_HILLIARD, EQ_ALLEN_CAHN, EQ_ADVECTION_DIFFUSION, EQ_GPE = 0, 1, 2, 3
 EQ_ALLEN_CAHN_SBM, EQ_CAHN_HILLIARD_SBM = 4, 5
 EQ_CAHN_HILLIARD_3D = 6
+EQ_SHAPE_SMOOTH = 7  # Shape.smooth_shape (shapes.py:39-64)
 INT_EULER, INT_RK4, INT_IMEX, INT_STRANG, INT_TSIT5 = 0, 1, 2, 3, 4
 CL_POLY, CL_LEGENDRE = 0, 1
 CL_LOGIT_PRIOR, CL_EXP_WRAP = 1, 2

@@ -302,7 +302,7 @@ int pdeopt_configure(pdeopt_ctx* ctx, const pdeopt_problem* pr) {
   ctx->configured = false;
   if (pr->dtype != PDEOPT_F32 && pr->dtype != PDEOPT_F64)
     return fail(ctx, PDEOPT_EINVAL, "unknown dtype %d", pr->dtype);
-  if (pr->equation < PDEOPT_EQ_CAHN_HILLIARD || pr->equation > PDEOPT_EQ_CAHN_HILLIARD_3D)
+  if (pr->equation < PDEOPT_EQ_CAHN_HILLIARD || pr->equation > PDEOPT_EQ_SHAPE_SMOOTH)
     return fail(ctx, PDEOPT_EINVAL, "unknown equation %d", pr->equation);
   if (pr->nx < 1 || pr->ny < 1 || pr->batch < 1)
     return fail(ctx, PDEOPT_EINVAL, "bad extents nx=%d ny=%d batch=%d", pr->nx, pr->ny, pr->batch);
@@ -321,6 +321,8 @@ int pdeopt_configure(pdeopt_ctx* ctx, const pdeopt_problem* pr) {
     if ((rc = check_closure(ctx, pr->mob, "mob"))) return rc;
     if (sbm && (rc = check_closure(ctx, pr->fe, "f"))) return rc;
   }
+  if (pr->equation == PDEOPT_EQ_SHAPE_SMOOTH && !(pr->gpe_k > 0))
+    return fail(ctx, PDEOPT_EINVAL, "shape smoothing needs smooth_epsilon (gpe_k) > 0");
   if (sbm && pr->derivs != PDEOPT_DERIVS_FD)
     return fail(ctx, PDEOPT_EINVAL, "Invalid derivative type: %d", pr->derivs);
   if (pr->derivs != PDEOPT_DERIVS_FD && pr->derivs != PDEOPT_DERIVS_FOURIER)

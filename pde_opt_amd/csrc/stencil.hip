@@ -107,6 +107,11 @@ int launch_generic(pdeopt_ctx* ctx, const StageArgs<T>& s) {
                          ctx->stream, s);
       ctx->last_kernel = "stage_generic<AD>";
       break;
+    case PDEOPT_EQ_SHAPE_SMOOTH:
+      if (ctx->halo) return fail(ctx, PDEOPT_EINVAL, "shape smoothing needs the periodic layout");
+      hipLaunchKernelGGL((stage_generic_kernel<T, PDEOPT_EQ_SHAPE_SMOOTH>), grid, block, 0, ctx->stream, s);
+      ctx->last_kernel = "stage_generic<shape-smooth>";
+      break;
     case PDEOPT_EQ_ALLEN_CAHN_SBM:
     case PDEOPT_EQ_CAHN_HILLIARD_SBM:
       if (!s.psi || !s.ngp || !s.mask)

@@ -201,6 +201,19 @@ __device__ __forceinline__ T rhs_generic_point(const StageArgs<T>& a, const T* _
       const T fym = (T(0.5) * (pym + p00)) * (T(0.5) * (dym + d00)) * ((in00 - inym) * a.rhy);
       return ((fx0 - fxm) * a.rhx + (fy0 - fym) * a.rhy) / p00 + a.ngp[(int64_t)i * ny + j] * a.tsrc;
     }
+  } else if constexpr (EQ == PDEOPT_EQ_SHAPE_SMOOTH) {
+    // Shape.smooth_shape (shapes.py:44-64): centred first / second / mixed differences (derivatives.py:62-106),
+    // u_nn = (u_xx u_x^2 + 2 u_xy u_x u_y + u_yy u_y^2) / |grad u|^2 with |grad u|^2 < 1e-7 replaced by 1
+    const T upp = U(i1, j1), upm = U(i1, jm1), ump = U(im1, j1), umm = U(im1, jm1);
+    const T gx = T(0.5) * (uxp - uxm) * a.rhx, gy = T(0.5) * (uyp - uym) * a.rhy;
+    const T gxx = (uxp - T(2) * u00 + uxm) * a.rhx2, gyy = (uyp - T(2) * u00 + uym) * a.rhy2;
+    const T gxy = (upp + umm - ump - upm) * (T(0.25) * a.rhx * a.rhy);
+    T g2 = gx * gx + gy * gy;
+    if (g2 < T(1e-7)) g2 = T(1);
+    const T unn = (gxx * gx * gx + T(2) * gxy * gx * gy + gyy * gy * gy) / g2;
+    const T c = p.kappa, eps = p.gpe_k;
+    const T pot = T(18) / eps * u00 * (T(1) - u00) * (T(1) - T(2) * u00);
+    return T(2) * (c * (gxx + gyy) + (T(1) - c) * unn) - pot / eps;
   } else if constexpr (EQ == PDEOPT_EQ_ADVECTION_DIFFUSION) {
     const int64_t vb = (int64_t)b * a.vstride;
     const T vx0 = a.vx[vb + (int64_t)i * g.ny + j], vxm = a.vx[vb + (int64_t)im1 * g.ny + j];

@@ -13,6 +13,7 @@ from .functions import (
     DiffusionLegendrePolynomials,
     LegendrePolynomialExpansion,
 )
+from .shapes import Shape
 from .solvers import (
     RK4,
     ConstantStepSize,

@@ -127,8 +127,14 @@ class OracleEngine:
             Fx = O.avg_face(psi, 0) * O.avg_face(Du, 0) * O.grad_face(inner, self.hx, 0)
             Fy = O.avg_face(psi, 1) * O.avg_face(Du, 1) * O.grad_face(inner, self.hy, 1)
             return (O.div_face(Fx, self.hx, 0) + O.div_face(Fy, self.hy, 1)) / psi + ngp * fl
+        if self.eq == L.EQ_SHAPE_SMOOTH:
+            return O.shape_smooth_rhs(u, self.hx, self.hy, self.gpe_k_env[b], self.kappa_env[b])
         fn = O.ch_rhs_fd if self.eq == L.EQ_CAHN_HILLIARD else O.ac_rhs_fd
         return fn(u, self.hx, self.hy, self.kappa_env[b], self.mu, self.mob)
+
+    def rhs(self, t=0.0, fetch=True):
+        out = np.stack([self._f(t, self.y[b].astype(np.float64), b) for b in range(self.batch)]).astype(self.dtype)
+        return out if fetch else None
 
     def advance(self, integrator, dt, n, t0=0.0):
         self.calls.append(("advance", integrator, dt, n, t0))

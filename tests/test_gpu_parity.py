@@ -739,3 +739,41 @@ def test_pair_kernel_tile_heights_agree(dtype):
     np.testing.assert_allclose(outs[32], outs[16], rtol=0, atol=4 * eps)
     assert np.mean(outs[32] != outs[16]) < 0.01
     np.testing.assert_array_equal(outs[0], outs[32])
+
+
+# ------------------------------------------------------------------ the reference's convergence harness
+@pytest.mark.parametrize("kind", ["ac", "ch", "ad"])
+def test_rhs_convergence_through_check_convergence(kind):
+    """tests/test_rhs_convergence.py:14-77 as written upstream -- equation class + symbolic class + the two argument
+    dictionaries into ``check_convergence`` -- on the build's counterparts of ``numerics/utils/testing.py`` and
+    ``numerics/symbolic``; the advection-diffusion row rides the same harness."""
+    import sympy as sp
+
+    from pde_opt_amd.numerics.symbolic import (SymbolicAdvectionDiffusion2D, SymbolicAllenCahn2DPeriodic,
+                                               SymbolicCahnHilliard2DPeriodic)
+    from pde_opt_amd.numerics.utils.testing import check_convergence, convergence_slope
+
+    x, y, t = sp.symbols("x y t", real=True)
+    u_star = sp.sin(2 * x) * sp.cos(3 * y) * sp.exp(-0.7 * t)
+    mu_sym = lambda u: u**3 - u
+    R_sym = lambda u: 1 + u**2
+    Ns = [32, 64, 128, 256, 512]
+    if kind == "ac":
+        args = (P.AllenCahn2DPeriodic, SymbolicAllenCahn2DPeriodic,
+                {"kappa": 1e-2, "mu": mu_sym, "R": R_sym, "derivs": "fd"},
+                {"kappa": 1e-2, "mu_sym": mu_sym, "R_sym": R_sym, "u_star": u_star})
+    elif kind == "ch":
+        args = (P.CahnHilliard2DPeriodic, SymbolicCahnHilliard2DPeriodic,
+                {"kappa": 1e-2, "mu": mu_sym, "D": R_sym, "derivs": "fd"},
+                {"kappa": 1e-2, "mu_sym": mu_sym, "D_sym": R_sym, "u_star": u_star})
+    else:
+        vel_sym = lambda xs, ys, ts: (sp.Rational(3, 5) + sp.Rational(3, 10) * sp.sin(xs) * sp.cos(2 * ys),
+                                      -sp.Rational(2, 5) + sp.Rational(1, 5) * sp.cos(3 * xs) * sp.sin(ys))
+        vel = lambda tt, xx, yy: (0.6 + 0.3 * np.sin(xx) * np.cos(2 * yy), -0.4 + 0.2 * np.cos(3 * xx) * np.sin(yy))
+        args = (P.AdvectionDiffusion2D, SymbolicAdvectionDiffusion2D, {"velocity_fn": vel, "D": 0.05},
+                {"velocity_sym": vel_sym, "D": 0.05, "u_star": u_star})
+    numeric_args, symbolic_args = dict(args[2]), dict(args[3])
+    dxs, errors = check_convergence(args[0], args[1], numeric_args, symbolic_args, Ns, 2 * np.pi)
+    assert numeric_args == args[2] and symbolic_args == args[3]  # the caller's dictionaries are left alone
+    np.testing.assert_allclose(convergence_slope(dxs, errors), 2.0, rtol=0.1)
+    assert errors[-1] < 2e-3 and all(a > b for a, b in zip(errors, errors[1:]))

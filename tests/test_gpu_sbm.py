@@ -6,6 +6,7 @@ import pytest
 
 import pde_opt_amd as P
 from oracle import np_oracle as O
+from pde_opt_amd.numerics.shapes import _ShapeSmoothing
 from util import MOB, MU, SBM_F, SBM_FLUX, SBM_THETA, TOL, rel_l2, sbm_domain, sbm_psi
 
 pytestmark = pytest.mark.gpu
@@ -140,3 +141,45 @@ def test_two_pass_ch_sbm_equals_the_literal_one_pass_kernel(dtype):
     # the two kernels are different instantiations: hipcc contracts their FMAs differently, a few ulp of the state
     inc0, inc1 = outs[0].astype(np.float64) - y0, outs[1].astype(np.float64) - y0
     assert rel_l2(inc0, inc1) < (1e-12 if dtype is np.float64 else 2e-5), rel_l2(inc0, inc1)
+
+
+# ----------------------------------------------------------------------------- Shape (shapes.py:21-79)
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_shape_smoothing_rhs_against_reference_goldens(golden, dtype):
+    """the PDEOPT_EQ_SHAPE_SMOOTH kernel against what the reference's own ``rhs`` closure of
+    ``Shape.smooth_shape`` (shapes.py:44-64) returned for the same fields (tests/golden/shapes.npz)"""
+    z = golden("shapes.npz")
+    keys = sorted(k[: -len("/rhs")] for k in z.files if k.endswith("/rhs"))
+    assert len(keys) == 6
+    for key in keys:
+        par = key.split("/")[1].split("_")
+        dx, eps, c = (float(par[0][2:]), float(par[1])), float(par[2][3:]), float(par[3][1:])
+        u = z[key + "/u"].astype(dtype)
+        nx, ny = u.shape
+        eq = _ShapeSmoothing(P.Domain((nx, ny), ((0.0, nx * dx[0]), (0.0, ny * dx[1])), "dimensionless"), eps, c)
+        got = eq.rhs(u, 0.0)
+        assert got.dtype == dtype
+        want = z[key + "/rhs"] if dtype is np.float64 else O.shape_smooth_rhs(u.astype(np.float64), *dx, eps, c)
+        assert rel_l2(got, want) < (1e-12 if dtype is np.float64 else 2e-5), (key, rel_l2(got, want))
+    assert "shape-smooth" in P.engine.default_engine().last_kernel
+
+
+def test_shape_smooth_field_and_smoothed_boundary_equation_on_it(golden):
+    """``Shape(mask).smooth`` from the GPU solve equals the same adaptive driver run on the oracle, and feeds
+    ``Domain(geometry=shape)`` -> ``AllenCahn2DSmoothedBoundary`` like the reference's notebook does"""
+    from fake_engine import OracleEngine
+
+    z = golden("shapes.npz")
+    mask = z["disc48x40/mask"]
+    shape = P.Shape(mask, smooth_epsilon=1.5, smooth_curvature=0.2, smooth_tf=0.8)
+    ref = P.Shape(mask, smooth_epsilon=1.5, smooth_curvature=0.2, smooth_tf=0.8, engine=OracleEngine())
+    np.testing.assert_allclose(shape.smooth, ref.smooth, rtol=0, atol=1e-9)
+    assert shape.smooth.min() == 0.001 and shape.smooth.max() == 1.0
+    assert np.mean((shape.smooth > 0.01) & (shape.smooth < 0.98)) > 0.05  # a diffuse interface exists
+    nx, ny = mask.shape
+    dom = P.Domain((nx, ny), ((0.0, float(nx)), (0.0, float(ny))), "dimensionless", geometry=shape)
+    eq = _eq("ac", dom)
+    u = np.clip(0.5 + 0.1 * np.random.default_rng(0).standard_normal((nx, ny)), 0.1, 0.9)
+    got = eq.rhs(u, 0.1)
+    want = O.ac_sbm_rhs(u, shape.smooth, 1.0, 1.0, 1.5, SBM_F, MU["regsol"], MOB["c1mc"], SBM_THETA(0.1), eq.left_half)
+    assert rel_l2(got, want) < 1e-11

@@ -215,3 +215,59 @@ def test_per_environment_step_sizes_equal_solo_solves():
     shared = P.diffeqsolve(eq, P.Tsit5(), 0.0, 0.2, 1e-4, y0, saveat=P.SaveAt(ts=ts),
                            stepsize_controller=P.PIDController(**ctl), engine=OracleEngine())
     assert shared.stats["num_accepted_steps"] >= max(both.stats["num_accepted_steps"])
+
+
+def test_check_convergence_harness_on_the_oracle_engine(monkeypatch):
+    """``numerics.utils.testing.check_convergence`` + ``numerics.symbolic`` (the reference's
+    tests/test_rhs_convergence.py harness) with the oracle standing in for the GPU: second order for AC and CH."""
+    import sympy as sp
+
+    from pde_opt_amd import engine as E
+    from pde_opt_amd.numerics.symbolic import SymbolicAllenCahn2DPeriodic, SymbolicCahnHilliard2DPeriodic
+    from pde_opt_amd.numerics.utils.testing import check_convergence, convergence_slope, l2_rel_err
+
+    monkeypatch.setitem(E._default_engines, 0, OracleEngine())
+    x, y, t = sp.symbols("x y t", real=True)
+    u_star = sp.sin(2 * x) * sp.cos(3 * y) * sp.exp(-0.7 * t)
+    mu_sym = lambda u: u**3 - u
+    R_sym = lambda u: 1 + u**2
+    for numeric, symbolic, key in ((P.AllenCahn2DPeriodic, SymbolicAllenCahn2DPeriodic, "R"),
+                                   (P.CahnHilliard2DPeriodic, SymbolicCahnHilliard2DPeriodic, "D")):
+        dxs, errs = check_convergence(numeric, symbolic, {"kappa": 1e-2, "mu": mu_sym, key: R_sym, "derivs": "fd"},
+                                      {"kappa": 1e-2, "mu_sym": mu_sym, key + "_sym": R_sym, "u_star": u_star},
+                                      [32, 64, 128], 2 * np.pi)
+        assert dxs == [2 * np.pi / n for n in (32, 64, 128)]
+        np.testing.assert_allclose(convergence_slope(dxs, errs), 2.0, rtol=0.1)
+    assert l2_rel_err([1.0, 2.0], [1.0, 2.0]) == 0.0 and abs(l2_rel_err([3.0, 0.0], [0.0, 4.0]) - 1.25) < 1e-15
+
+
+def test_shape_host_side_against_reference_goldens(golden):
+    """``Shape`` (shapes.py:21-203): the clamps of __post_init__, the arguments of the smoothing solve, the mask's
+    graph Laplacian and its lowest modes -- against arrays the reference's own class produced (gen_golden.py)"""
+    z = golden("shapes.npz")
+    for name in ("disc48x40", "tee32"):
+        mask = z[name + "/mask"]
+        eng = OracleEngine()
+        shape = P.Shape(mask, dx=(0.5, 0.8), smooth_epsilon=2.0, smooth_curvature=0.3, engine=eng)
+        key = f"{name}/dx0.5_0.8_eps2.0_c0.3"
+        t0, t1, dt0 = z[key + "/solve_args"]
+        assert (t0, t1, dt0) == (0.0, shape.smooth_tf, shape.smooth_dt)
+        assert eng.eq == L.EQ_SHAPE_SMOOTH and (eng.hx, eng.hy) == (0.5, 0.8)
+        assert eng.kappa_env[0] == 0.3 and eng.gpe_k_env[0] == 2.0
+        # upstream's clamps (0.001 below, 1 above 0.99) act on whatever the solve returned; on the unsmoothed
+        # mask they give the golden, on the smoothed field they bound it
+        clamped = np.where(mask < 0.001, 0.001, np.where(mask > 0.99, 1.0, mask))
+        np.testing.assert_array_equal(clamped, z[key + "/post_init_of_y0"])
+        assert shape.smooth.min() >= 0.001 and shape.smooth.max() <= 1.0
+        assert 0.2 < np.mean(np.abs(shape.smooth - mask) > 0.02) < 0.9  # the interface did get smeared
+        assert abs(shape.smooth.sum() - mask.sum()) < 0.05 * mask.sum()
+        for periodic in (False, True):
+            lap, ids = shape.laplacian_from_mask(periodic=periodic)
+            np.testing.assert_array_equal(lap.toarray(), z[f"{name}/laplacian_{'periodic' if periodic else 'open'}"])
+            np.testing.assert_array_equal(ids, z[name + "/ids"])
+        shape.get_shape_modes(6)
+        np.testing.assert_allclose(shape.shape_basis_evals, z[name + "/mode_evals"], rtol=0, atol=1e-9)
+        np.testing.assert_allclose(np.abs(shape.shape_basis).sum(axis=(0, 1)), z[name + "/mode_basis_abs_sum"], rtol=1e-6)
+    empty = P.Shape(np.zeros((8, 8)), engine=OracleEngine())
+    lap, ids = empty.laplacian_from_mask()
+    assert lap.shape == (0, 0) and (ids == -1).all()

@@ -261,3 +261,22 @@ def test_advection_diffusion_manufactured_solution_slope():
         hs.append(h)
     slope = np.polyfit(np.log(hs), np.log(errs), 1)[0]
     np.testing.assert_allclose(slope, 2.0, rtol=0.1)
+
+
+def _shape_cases(z):
+    return sorted(k[: -len("/rhs")] for k in z.files if k.endswith("/rhs"))
+
+
+def test_shape_smoothing_rhs_matches_reference_goldens(golden):
+    """``Shape.smooth_shape``'s right-hand side (shapes.py:44-64), evaluated by the reference's own closure in
+    oracle/gen_golden.py: smeared fields and the raw masks (where |grad u|^2 < 1e-7 takes the :53 branch)"""
+    z = golden("shapes.npz")
+    keys = _shape_cases(z)
+    assert len(keys) == 6
+    for key in keys:
+        par = key.split("/")[1].split("_")
+        hx, hy, eps, c = float(par[0][2:]), float(par[1]), float(par[2][3:]), float(par[3][1:])
+        for field, out in (("u", "rhs"), (None, "rhs_binary")):
+            u = z[key + "/u"] if field else z[key.split("/")[0] + "/mask"]
+            got = O.shape_smooth_rhs(u, hx, hy, eps, c)
+            np.testing.assert_allclose(got, z[f"{key}/{out}"], rtol=0, atol=1e-13 * np.max(np.abs(z[f"{key}/{out}"])))
