@@ -14,4 +14,7 @@ for w in ac_rk4_512_f32 ch_imex_1024_f32 gpe_strang_512_c64 gpe_strang_512_c64_s
 done
 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29541 bench.py --gpus 1 \
   --workload ch_rk4_4096_decomp --decomp-grid 2048 --no-cpu-baseline --steps 5 --warmup 2 2>/dev/null | tail -1 > gpurun_out/round/bench_decomp_tile2048_native_rccl_1rank.json
+# the driver's multi-GPU launch line, on the one rank a gpurun box has: RCCL barrier + max-over-ranks path of bench.py
+python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29543 bench.py --gpus 1 \
+  --steps 5 --warmup 2 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/round/bench_headline_torchrun_1rank.json
 tail -c 600 gpurun_out/round/bench.json
