@@ -153,12 +153,19 @@ def roofline_block(workload, kernel_name, bytes_per_launch, words, avg_launch_s,
         if c.get("SQ_ACTIVE_INST_VALU") and c.get("GRBM_GUI_ACTIVE"):
             # quad-cycles summed over SIMDs vs the launch's cycles under the profiler (sum over 8 XCDs)
             r["valu_busy_frac_pmc"] = 4.0 * c["SQ_ACTIVE_INST_VALU"] / N_SIMD / (c["GRBM_GUI_ACTIVE"] / 8.0)
-        if r["frac_valu_measured_issue"] > (r.get("traffic_frac") or 0.0):
+        # which pipe is busier: the VALU's measured busy share (it prices transcendentals at their 8.5 clk; the
+        # instruction count x 3.5 clk is the conservative figure reported as `frac`) or the fabric's share of the peak
+        valu_share = r.get("valu_busy_frac_pmc", r["frac_valu_measured_issue"])
+        if valu_share > (r.get("traffic_frac") or 0.0):
             r["bound"] = "valu"
             r["unit"] = "Ginst/s"
             r["achieved"] = c["SQ_INSTS_VALU"] / avg_launch_s / 1e9
             r["peak"] = N_SIMD * SHADER_HZ / VALU_CLK_MEASURED / 1e9
             r["frac"] = r["achieved"] / r["peak"]
+    if r["bound"] == "hbm" and r.get("traffic_gbs"):
+        # memory-bound with measured traffic: price the bytes that moved, not the per-stage byte count (which fusion
+        # undercuts -- a fraction above 1 of a hardware peak would say nothing)
+        r["achieved"], r["frac"] = r["traffic_gbs"], r["traffic_frac"]
     r["pmc_source"] = os.path.relpath(PMC_FILE, ROOT) + ": " + pmc.get("source", "")
     r["note"] = ("bound = what binds the kernel.  valu: achieved = wave64 VALU instructions issued per second (SQ_INSTS_VALU per "
                  "launch, PMC profile of this command / live HIP-event launch time), peak = 1024 SIMDs x 2.4 GHz / 3.5 clk, the "

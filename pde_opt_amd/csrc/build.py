@@ -10,7 +10,9 @@ from __future__ import annotations
 
 import glob
 import hashlib
+import json
 import os
+import re
 import shutil
 import subprocess
 import sys
@@ -65,19 +67,61 @@ def _flags_tag(extra: list[str]) -> str:
     return hashlib.sha1(" ".join(CXXFLAGS + extra).encode()).hexdigest()[:10]
 
 
+_REMARK = re.compile(r"remark: (?:Function Name: (?P<name>\S+)|\s+(?P<key>VGPRs|AGPRs|TotalSGPRs|ScratchSize \[bytes/lane\]|"
+                     r"Occupancy \[waves/SIMD\]|LDS Size \[bytes/block\]): (?P<val>\d+))")
+_KEYS = {"VGPRs": "vgpr", "AGPRs": "agpr", "TotalSGPRs": "sgpr", "ScratchSize [bytes/lane]": "scratch",
+         "Occupancy [waves/SIMD]": "occupancy", "LDS Size [bytes/block]": "lds_static"}
+
+
+def _parse_resources(stderr: str):
+    """hipcc -Rpass-analysis=kernel-resource-usage remarks -> {mangled kernel name: {vgpr, sgpr, scratch, ...}}, and
+    the rest of the compiler's output when it holds a warning"""
+    res, cur, rest = {}, None, []
+    for line in stderr.splitlines():
+        m = _REMARK.search(line)
+        if m and m.group("name"):
+            cur = res.setdefault(m.group("name"), {})
+        elif m and cur is not None:
+            cur[_KEYS[m.group("key")]] = int(m.group("val"))
+        elif "remark:" not in line:
+            rest.append(line)
+    noise = not any("warning:" in ln or "error:" in ln for ln in rest)  # source excerpts under the remarks
+    return res, "" if noise else "\n".join(rest)
+
+
 def _compile(src: str, force: bool, extra: list[str]) -> str:
     obj = os.path.join(OBJ_DIR, src.replace(".hip", f".{_flags_tag(extra)}.o"))
     sp = os.path.join(HERE, src)
     stamp = max(os.path.getmtime(sp), _newest_header())
-    if not force and os.path.exists(obj) and os.path.getmtime(obj) >= stamp:
+    if not force and os.path.exists(obj) and os.path.exists(obj + ".resources.json") and os.path.getmtime(obj) >= stamp:
         return obj
-    cmd = [_hipcc(), *CXXFLAGS, *extra, "-c", sp, "-o", obj]
+    # the remarks cost nothing at run time: registers / scratch / occupancy of every kernel land next to the object,
+    # where tests/test_kernel_budgets.py holds the occupancy-critical kernels to their budgets
+    cmd = [_hipcc(), *CXXFLAGS, *extra, "-Rpass-analysis=kernel-resource-usage", "-c", sp, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed on {src}:\n{' '.join(cmd)}\n{r.stdout}\n{r.stderr}")
-    if r.stderr.strip():
-        sys.stderr.write(r.stderr)
+    res, rest = _parse_resources(r.stderr)
+    with open(obj + ".resources.json", "w") as f:
+        json.dump(res, f)
+    if rest.strip():
+        sys.stderr.write(rest + "\n")
     return obj
+
+
+def kernel_resources(extra_flags: list[str] | None = None) -> dict:
+    """{demangled kernel name: {vgpr, sgpr, scratch, occupancy, lds_static}} of the library as built with these
+    flags (builds what is stale)"""
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    extra = list(extra_flags or [])
+    merged = {}
+    for src in SOURCES:
+        with open(_compile(src, False, extra) + ".resources.json") as f:
+            merged.update(json.load(f))
+    names = list(merged)
+    out = subprocess.run(["c++filt"], input="\n".join(names), capture_output=True, text=True).stdout.splitlines()
+    clean = lambda n: re.sub(r"\(.*", "", re.sub(r"pdeopt::|\(anonymous namespace\)::|^void ", "", n))
+    return {clean(d): merged[m] for m, d in zip(names, out)}
 
 
 def build(force: bool = False, verbose: bool = True, extra_flags: list[str] | None = None) -> str:

@@ -154,6 +154,8 @@ constexpr size_t fused_lds_bytes() {
 #ifndef PDEOPT_PAIR_WAVES_ATTR
 #define PDEOPT_PAIR_WAVES_ATTR
 #endif
+// (fp64 PAIR_34 sits one register above the 80 that would let three 512-thread workgroups share a CU; compiled
+// for 6 waves per SIMD it takes 78, no scratch -- and measures 504 vs 507 env-steps/s: occupancy is not its limit)
 template <typename T, int CL, int PAIR, int RPT, bool RAGGED, int NT>
 __global__ __launch_bounds__(NT) PDEOPT_PAIR_WAVES_ATTR void stage_pair_kernel(const PairArgs<T> a, const int tiles_i,
                                                         const int tiles_j, const int nblk,

@@ -163,7 +163,7 @@ __global__ __launch_bounds__(256) void strang_row_reg_kernel(Cx<T>* __restrict__
 #define PDEOPT_COL_WL_MAX 512
 #endif
 constexpr bool col_wave_local(int n) { return PDEOPT_COL_WL && n <= PDEOPT_COL_WL_MAX; }
-template <typename T, int N, int C, int PTS, bool SCALED>
+template <typename T, int N, int C, int PTS, bool SCALED, bool PER_ENV = false>
 __global__ __launch_bounds__(C* N / PTS) void strang_col_reg_kernel(Cx<T>* __restrict__ psi,
                                                                   const Cx<T>* __restrict__ mult,
                                                                   const Cx<T>* __restrict__ tw, int ny,
@@ -217,11 +217,13 @@ __global__ __launch_bounds__(C* N / PTS) void strang_col_reg_kernel(Cx<T>* __res
   if constexpr (SCALED) scale = (T)scale_sh;
   // IMEX with a per-environment implicit operator (one environment per complex field): the stored multiplier is
   // M0 = 1 / (N (1 + A dt symbol)), real; this environment's is 1 / (N (1 + sigma (1 / (N M0) - 1)))
-  const T sigma = sigma_ep ? sigma_ep[env].imex_scale : T(1);
+  // (a template parameter: as a run-time branch its divisions cost every instantiation 4-5 VGPRs, and the 512^2
+  // Strang pass -- two 1024-thread workgroups per CU -- lives at the 64-VGPR limit: 54 -> 71 us)
+  const T sigma = PER_ENV ? sigma_ep[env].imex_scale : T(1);
 #pragma unroll
   for (int sl = 0; sl < PTS; ++sl) {
     Cx<T> m = WL ? mb[E::freq(ji, sl)] : mb[E::freq(j, sl) * ny + c];
-    if (sigma_ep) {
+    if constexpr (PER_ENV) {
       m.re = inv_n / (T(1) + sigma * (inv_n / m.re - T(1)));
       m.im = T(0);
     }
@@ -688,7 +690,7 @@ int imex_cols(pdeopt_ctx* ctx, StrangFused& sf) {
                        (const Cx<T>*)sf.tw_x, p.ny, (const double*)nullptr, 0, 1.0, ep, inv_n);
   } else {
     const size_t lds = (size_t)C * fft_lds_pitch<N>() * sizeof(Cx<T>);
-    auto kern = strang_col_reg_kernel<T, N, C, PTS, false>;
+    auto kern = ep ? strang_col_reg_kernel<T, N, C, PTS, false, true> : strang_col_reg_kernel<T, N, C, PTS, false, false>;
     int rc = allow_lds(ctx, kern, lds);
     if (rc) return rc;
     hipLaunchKernelGGL(kern, dim3(p.ny / C, npairs), dim3(C * N / PTS), lds, ctx->stream, cw,

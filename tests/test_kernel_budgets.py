@@ -1,0 +1,57 @@
+"""Register / scratch budgets of the occupancy-critical kernels, from the compiler's own report.
+
+csrc/build.py compiles with -Rpass-analysis=kernel-resource-usage and keeps what hipcc reports next to every
+object.  A few kernels sit right below a VGPR boundary at which a whole workgroup stops fitting on a CU; crossing
+it is silent (the code still runs, 20-30 % slower -- round 2 lost 54 -> 71 us on the 512^2 Strang column pass to a
+run-time branch worth four registers).  The numbers below are those boundaries, not the current counts.
+No GPU needed: hipcc cross-compiles for gfx950.
+"""
+import pytest
+
+from pde_opt_amd.csrc import build as B
+
+
+@pytest.fixture(scope="module")
+def res():
+    B.build(verbose=False)
+    r = B.kernel_resources()
+    assert len(r) > 300
+    return r
+
+
+def _pick(res, prefix):
+    hit = {k: v for k, v in res.items() if k.startswith(prefix)}
+    assert hit, prefix
+    return hit
+
+
+def test_no_kernel_spills(res):
+    spilled = {k: v["scratch"] for k, v in res.items() if v.get("scratch", 0) > 0}
+    assert not spilled, spilled
+
+
+# (kernel name prefix, VGPR budget, why)
+BUDGETS = [
+    # three 512-thread workgroups (8 waves each, 42-44 KB of LDS) per CU = 6 waves per SIMD
+    ("stage_pair_kernel<float, 3, 0, 2, false, 512>", 80, "PAIR_12 fp32: 3 workgroups per CU"),
+    ("stage_pair_kernel<float, 3, 1, 2, false, 512>", 80, "PAIR_34 fp32: 3 workgroups per CU"),
+    ("stage_pair_kernel<double, 3, 0, 2, false, 512>", 80, "PAIR_12 fp64: 3 workgroups per CU"),
+    ("stage_pair_kernel<double, 3, 1, 2, false, 512>", 96, "PAIR_34 fp64: 2 workgroups per CU (3 measured no faster)"),
+    ("stage_pair_kernel<float, 3, 2, 2, false, 512>", 64, "PAIR_K (IMEX slope): 8 waves per SIMD"),
+    # the Strang / IMEX column pass up to N = 512 runs 1024-thread workgroups, two per CU: 8 waves per SIMD
+    ("strang_col_reg_kernel<float, 512, 16, 8, ", 64, "two 1024-thread workgroups per CU"),
+    ("strang_col_reg_kernel<float, 256, 16, 8, ", 64, "two 1024-thread workgroups per CU"),
+    ("strang_row_reg_kernel<float, 512, ", 64, "8 waves per SIMD"),
+    # the 32-point engine at N = 1024: 4 waves per SIMD is what its LDS footprint was halved for
+    ("strang_col32_kernel<float, 16, ", 128, "two 512-thread workgroups per CU"),
+    ("imex_row_fwd_reg_kernel<float, 1024>", 128, "4 waves per SIMD"),
+    ("imex_row_inv_reg_kernel<float, 1024>", 128, "4 waves per SIMD"),
+    ("ac_rk4_quad_kernel<4, ", 72, "single-pass Allen-Cahn, 32-row tiles: 7 waves per SIMD"),
+]
+
+
+@pytest.mark.parametrize("prefix,budget,why", BUDGETS, ids=[b[0] for b in BUDGETS])
+def test_vgpr_budget(res, prefix, budget, why):
+    for name, v in _pick(res, prefix).items():
+        assert v["vgpr"] <= budget, f"{name}: {v['vgpr']} VGPRs > {budget} ({why})"
+        assert v["agpr"] == 0
