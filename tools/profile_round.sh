@@ -7,6 +7,9 @@ bash tools/profile_gpu.sh round/ch_rk4_1024_f32 > /dev/null 2>&1
 for w in ac_rk4_512_f32 ch_imex_1024_f32 gpe_strang_512_c64 ch_rk4_1024_f64; do
   bash tools/trace_only.sh round/$w --workload $w > gpurun_out/round/${w}_trace_summary.txt 2>&1
 done
+for w in ac_rk4_512_f32 ch_imex_1024_f32 gpe_strang_512_c64 ch_rk4_1024_f64; do
+  bash tools/pmc_traffic.sh round/pmc_$w --workload $w > /dev/null 2>&1
+done
 cd $ROOT
 python bench.py > gpurun_out/round/bench.json 2> gpurun_out/round/bench.err
 for w in ac_rk4_512_f32 ch_imex_1024_f32 gpe_strang_512_c64 gpe_strang_512_c64_spots ch_rk4_1024_f64 ch_rk4_4096_decomp; do

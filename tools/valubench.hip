@@ -14,15 +14,19 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr int kIters = 2048;
 constexpr int kChains = 8;  // independent dependency chains per lane
 
-enum { OP_FMA = 0, OP_PK_FMA = 1, OP_LOG = 2, OP_RCP = 3, OP_MUL_LO = 4, OP_MUL_HI = 5, OP_ADD = 6, OP_MIX = 7 };
+enum { OP_FMA = 0, OP_PK_FMA = 1, OP_LOG = 2, OP_RCP = 3, OP_MUL_LO = 4, OP_MUL_HI = 5, OP_ADD = 6, OP_MIX = 7,
+       OP_FMA64 = 8, OP_ADD64 = 9, OP_RCP64 = 10, OP_PK_ADD = 11 };
 
 template <int OP>
 __global__ __launch_bounds__(256) void valu_kernel(float* out, float a, float b, unsigned m) {
   float x[kChains];
   f32x2 p[kChains];
   unsigned u[kChains];
+  double d[kChains];
+  const double da = a, db = b;
 #pragma unroll
   for (int c = 0; c < kChains; ++c) {
+    d[c] = 1.0 + 0.001 * (threadIdx.x + c);
     x[c] = 1.0f + 0.001f * (threadIdx.x + c);
     p[c] = f32x2{x[c], x[c] + 0.5f};
     u[c] = threadIdx.x * 2654435761u + c;
@@ -39,6 +43,10 @@ __global__ __launch_bounds__(256) void valu_kernel(float* out, float a, float b,
       if constexpr (OP == OP_RCP) asm volatile("v_rcp_f32 %0, %0" : "+v"(x[c]));
       if constexpr (OP == OP_MUL_LO) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(u[c]) : "v"(m));
       if constexpr (OP == OP_MUL_HI) asm volatile("v_mul_hi_u32 %0, %0, %1" : "+v"(u[c]) : "v"(m));
+      if constexpr (OP == OP_FMA64) asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(d[c]) : "v"(da), "v"(db));
+      if constexpr (OP == OP_ADD64) asm volatile("v_add_f64 %0, %0, %1" : "+v"(d[c]) : "v"(db));
+      if constexpr (OP == OP_RCP64) asm volatile("v_rcp_f64 %0, %0" : "+v"(d[c]));
+      if constexpr (OP == OP_PK_ADD) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(p[c]) : "v"(pb));
       if constexpr (OP == OP_MIX) {
         if (c % 4 == 3)
           asm volatile("v_log_f32 %0, %0" : "+v"(x[c]));
@@ -49,7 +57,7 @@ __global__ __launch_bounds__(256) void valu_kernel(float* out, float a, float b,
   }
   float s = 0;
 #pragma unroll
-  for (int c = 0; c < kChains; ++c) s += x[c] + p[c][0] + p[c][1] + (float)u[c];
+  for (int c = 0; c < kChains; ++c) s += x[c] + p[c][0] + p[c][1] + (float)u[c] + (float)d[c];
   if (s == 12345.678f) out[0] = s;  // keep the chains alive
 }
 
@@ -103,5 +111,9 @@ int main() {
   if (run<OP_MUL_LO>("mul_lo_u32", out, cus, ghz)) return 1;
   if (run<OP_MUL_HI>("mul_hi_u32", out, cus, ghz)) return 1;
   if (run<OP_MIX>("3fma:1log", out, cus, ghz)) return 1;
+  if (run<OP_PK_ADD>("pk_add_f32", out, cus, ghz)) return 1;
+  if (run<OP_FMA64>("fma_f64", out, cus, ghz)) return 1;
+  if (run<OP_ADD64>("add_f64", out, cus, ghz)) return 1;
+  if (run<OP_RCP64>("rcp_f64", out, cus, ghz)) return 1;
   return 0;
 }
