@@ -152,9 +152,11 @@ __device__ __forceinline__ int fft_pos_of(int k) {
   return p;
 }
 
-// LDS address of sequence position `pos`: one pad element per 8.  A stage with lane stride 8 (or 64)
-// would otherwise put 8 (16) lanes of a half-wave on the same ds_read_b64 bank slot; with the pad
-// the stride becomes 9 (72) slots, which walks all 32 slots before repeating (conflict-free).
+// LDS address of sequence position `pos`: one pad element per 8.  The LDS serves 16 lanes of a ds_read_b64 per
+// clock from 32 four-byte banks, i.e. 16 eight-byte slots: a layout whose lanes stride 8 positions would put 16
+// lanes on 2 slots; with the pad the stride is 9 slots, which walks all 16.  (Lane stride 1 pays for it -- 16
+// consecutive positions span 17 slots, a 2-way conflict -- and lane stride 64 is not helped at all: RegFft keeps
+// its last stage off that stride, see PDEOPT_FFT_LAST_IDENTITY; tools/lds_bank_model.py evaluates a layout.)
 __device__ __forceinline__ constexpr int fft_lds_addr(int pos) { return pos + (pos >> 3); }
 // padded length of one sequence (+1 so that consecutive sequences start one slot apart: the column
 // pass loads/stores with the sequence index fastest across lanes)

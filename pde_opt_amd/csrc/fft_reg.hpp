@@ -38,6 +38,16 @@ __device__ __forceinline__ void reg_fft_sync() {
 template <int N>
 constexpr int reg_default_pts() { return N > 512 ? 16 : 8; }
 
+// Which positions a thread owns in the LAST stage.  1 (default): thread j owns positions (j + u TT) R .. + R - 1,
+// so the lanes of a wave walk the image with stride R and the one-pad-per-8 addressing puts every 16 lanes of a
+// ds_read_b64 / ds_write_b64 (the LDS serves 16 lanes x 8 bytes per clock from 32 banks) on 16 different bank
+// pairs.  0: the positions whose frequencies are j + slot TT (consecutive across lanes) -- lane stride 64 (512:
+// 8 8 8) or 128 positions, 4- to 8-way conflicts: SQ_LDS_BANK_CONFLICT was 50 % of the LDS cycles of the Strang
+// passes (profiles/pmc_r02.json), which tools/lds_bank_model.py reproduces to the digit.  The frequencies of a
+// wave stay one contiguous block either way (digit-reversed WITHIN it), so global accesses coalesce as before.
+#ifndef PDEOPT_FFT_LAST_IDENTITY
+#define PDEOPT_FFT_LAST_IDENTITY 1
+#endif
 template <typename T, int N, int PTS = reg_default_pts<N>()>
 struct RegFft {
   using P = FftPlan<N>;
@@ -57,7 +67,11 @@ struct RegFft {
     constexpr int R = P::radix(STAGE), Ns = P::sublen(STAGE), S = Ns / R;
     const int u = slot / R, m = slot % R;
     if constexpr (S == 1) {
+#if PDEOPT_FFT_LAST_IDENTITY
+      return (j + u * TT) * R + m;  // thread-major: the frequencies land digit-reversed across the lanes (freq())
+#else
       return fft_pos_of<N>(j + u * TT) + m;  // k = j + (u + m PER) TT: m is the top digit of k, the bottom digit of pos
+#endif
     } else {
       const int bf = j + u * TT;
       const int blk = bf / S, jj = bf % S;
@@ -68,8 +82,12 @@ struct RegFft {
   static __device__ __forceinline__ int natural(int j, int slot) { return pos<0>(j, slot); }
   // frequency held in `slot` after the last DIF stage / expected there before the first DIT stage
   static __device__ __forceinline__ int freq(int j, int slot) {
+#if PDEOPT_FFT_LAST_IDENTITY
+    return fft_rev<N>(pos<L - 1>(j, slot));
+#else
     constexpr int R = P::radix(L - 1), PER = PTS / R;
     return j + (slot / R + (slot % R) * PER) * TT;
+#endif
   }
 
   // LDS address of slot (u, m) = base(u) + a compile-time constant: within one butterfly the positions

@@ -79,13 +79,13 @@ __device__ __forceinline__ void dft32(Cx<T>* v) {
   }
 }
 
-template <typename T>
+template <typename T, int PITCH = 33>
 struct RegFft32x32 {
   using C = Cx<T>;
   static constexpr int N = 1024, PTS = 32, TT = 32;
   static constexpr int kPts = 32;
   static constexpr bool kWaveLocal = true;
-  static constexpr int kPitch = 33;
+  static constexpr int kPitch = PITCH;
   // the exchange moves the real and the imaginary parts in two rounds through the same scalar image: half the LDS
   // of a complex image (4.2 KB per fp32 sequence -> 4 workgroups of 8 sequences per CU instead of 2)
   using LdsT = T;

@@ -245,14 +245,26 @@ __global__ __launch_bounds__(C* N / PTS) void strang_col_reg_kernel(Cx<T>* __res
 // N = 1024 fp32 column pass on the 32 x 32 plan (fft_reg32.hpp): thread (column c, j) owns rows j + 32 m of its
 // column -- global loads / stores as above (column index fastest across lanes: 128-byte segments), but ONE
 // exchange per transform instead of two, 512-thread workgroups with 68 KB of LDS (two per CU, so one's barriers
-// overlap the other's arithmetic) instead of one of 1024 threads with 148 KB.  Sequence images are 1060 scalars
-// apart: 16 columns x 4 rows of a wave land on 64 different banks in both directions of the transpose.
+// overlap the other's arithmetic) instead of one of 1024 threads with 148 KB.
 #ifndef PDEOPT_COL32
 #define PDEOPT_COL32 1
 #endif
 template <typename T, int N>
 constexpr bool col_use32() { return PDEOPT_COL32 && sizeof(T) == 4 && N == 1024; }
-constexpr int kCol32Pitch = RegFft32x32<float>::NP + 4;
+// LDS geometry of the column pass.  The LDS has 32 banks of 4 bytes and serves 32 lanes' dwords per clock; a
+// half-wave here is 16 columns x 2 rows.  With 1060 (= 4 mod 32) floats between the columns' images -- the first
+// cut, laid out for 64 banks -- columns c and c + 8 met on one bank: SQ_LDS_BANK_CONFLICT = 50 % of the LDS cycles
+// (profiles/pmc_r02.json).  1058 = 2 mod 32 with the odd row pitch 33 puts the 32 accesses of a clock on 32 banks
+// in both directions of the transpose (writes 2c + j, reads 2c + 33j): conflicts 0.000, LDS cycles halved,
+// +1.0 % on ch_imex_1024_f32 (1438 -> 1452 env-steps/s same-box).
+#ifndef PDEOPT_COL32_ROW_PITCH
+#define PDEOPT_COL32_ROW_PITCH 33
+#endif
+#ifndef PDEOPT_COL32_SEQ_PITCH
+#define PDEOPT_COL32_SEQ_PITCH 1058
+#endif
+constexpr int kCol32Pitch = PDEOPT_COL32_SEQ_PITCH;
+static_assert(kCol32Pitch >= 32 * PDEOPT_COL32_ROW_PITCH, "a column's image must fit its slot");
 
 // complex fp32 element through a buffer descriptor: uniform descriptor + SGPR row offset + ONE per-thread VGPR
 // offset for all 32 rows (plain global loads keep a 64-bit address pair per row alive: 230 VGPRs)
@@ -274,7 +286,7 @@ __global__ __launch_bounds__(C * 32, 4) void strang_col32_kernel(Cx<T>* __restri
                                                                  double dx2, const EnvParams<T>* __restrict__ sigma_ep,
                                                                  T inv_n) {
   static_assert(sizeof(T) == 4, "fp32 only");
-  using E = RegFft32x32<T>;
+  using E = RegFft32x32<T, PDEOPT_COL32_ROW_PITCH>;
   constexpr int N = 1024, PTS = 32;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const int tid = threadIdx.x;

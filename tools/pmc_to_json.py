@@ -22,7 +22,7 @@ for d in sys.argv[4:]:
             if any(x in r["Kernel_Name"] for x in subs):
                 acc[r["Counter_Name"]] += float(r["Counter_Value"])
                 cnt[r["Counter_Name"]] += 1
-                short = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("pdeopt::", "").replace("(anonymous namespace)::", "")
+                short = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("pdeopt::", "").replace("void ", "").split("(")[0]
                 names.add(short)
                 kacc[short][r["Counter_Name"]] += float(r["Counter_Value"])
                 kcnt[short][r["Counter_Name"]] += 1
