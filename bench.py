@@ -112,7 +112,8 @@ N_SIMD, SHADER_HZ = 1024, 2.4e9  # 256 CUs x 4 SIMDs; MI355X_MICROARCH.md chip t
 # issue cost of one scalar-fp32 wave64 VALU instruction per SIMD, measured with >= 4 waves resident
 # (tools/valubench.hip -> profiles/r02_valubench.txt: v_fma_f32 3.5 clk, v_add_f32 4.1, v_pk_fma_f32 5.7 for two
 # FMAs, v_log_f32 / v_rcp_f32 8.5; costs of a mix add up).  The 157.3 TF vector peak (= 2 clk) is the PACKED rate.
-VALU_CLK_MEASURED = 3.5
+VALU_CLK_MEASURED = 3.5      # clocks per wave64 scalar-fp32 VALU instruction per SIMD (profiles/r02_valubench.txt)
+VALU_CLK_MEASURED_F64 = 5.0  # v_fma_f64 / v_add_f64: 4.9-5.2 from 4 waves per SIMD on (same file)
 
 
 def roofline_block(workload, kernel_name, bytes_per_launch, words, avg_launch_s, launches):
@@ -146,8 +147,10 @@ def roofline_block(workload, kernel_name, bytes_per_launch, words, avg_launch_s,
     if c.get("SQ_INSTS_VALU"):
         per_simd = c["SQ_INSTS_VALU"] / N_SIMD
         cycles = avg_launch_s * SHADER_HZ
+        valu_clk = VALU_CLK_MEASURED_F64 if WORKLOADS.get(workload, {}).get("dtype") is np.float64 else VALU_CLK_MEASURED
         r["valu_insts_per_launch"] = c["SQ_INSTS_VALU"]
-        r["frac_valu_measured_issue"] = per_simd * VALU_CLK_MEASURED / cycles
+        r["valu_clk_per_inst_measured"] = valu_clk
+        r["frac_valu_measured_issue"] = per_simd * valu_clk / cycles
         r["frac_valu_4clk"] = per_simd * 4.0 / cycles
         r["frac_valu_spec"] = per_simd * 2.0 / cycles  # 157.3 TF denominator: the packed-fp32 rate
         if c.get("SQ_ACTIVE_INST_VALU") and c.get("GRBM_GUI_ACTIVE"):
@@ -160,7 +163,7 @@ def roofline_block(workload, kernel_name, bytes_per_launch, words, avg_launch_s,
             r["bound"] = "valu"
             r["unit"] = "Ginst/s"
             r["achieved"] = c["SQ_INSTS_VALU"] / avg_launch_s / 1e9
-            r["peak"] = N_SIMD * SHADER_HZ / VALU_CLK_MEASURED / 1e9
+            r["peak"] = N_SIMD * SHADER_HZ / valu_clk / 1e9
             r["frac"] = r["achieved"] / r["peak"]
     if r["bound"] == "hbm" and r.get("traffic_gbs"):
         # memory-bound with measured traffic: price the bytes that moved, not the per-stage byte count (which fusion
@@ -168,8 +171,8 @@ def roofline_block(workload, kernel_name, bytes_per_launch, words, avg_launch_s,
         r["achieved"], r["frac"] = r["traffic_gbs"], r["traffic_frac"]
     r["pmc_source"] = os.path.relpath(PMC_FILE, ROOT) + ": " + pmc.get("source", "")
     r["note"] = ("bound = what binds the kernel.  valu: achieved = wave64 VALU instructions issued per second (SQ_INSTS_VALU per "
-                 "launch, PMC profile of this command / live HIP-event launch time), peak = 1024 SIMDs x 2.4 GHz / 3.5 clk, the "
-                 "measured scalar-fp32 issue rate (profiles/r02_valubench.txt; transcendentals cost 8.5 clk, so the true issue "
+                 "launch, PMC profile of this command / live HIP-event launch time), peak = 1024 SIMDs x 2.4 GHz / 3.5 clk (fp64: 5.0), "
+                 "the measured scalar issue rate (profiles/r02_valubench.txt; transcendentals cost 8.5 clk, so the true issue "
                  "share is higher: valu_busy_frac_pmc).  algorithmic_gbs is SURVEY 8(d)'s byte count over the same time: it may "
                  "exceed the HBM peak because stage-pair fusion and cache-resident environment groups remove traffic; "
                  "traffic = measured L2 fabric-side bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, Infinity-Cache hits included).")

@@ -11,6 +11,10 @@ for w in ac_rk4_512_f32 ch_imex_1024_f32 gpe_strang_512_c64 ch_rk4_1024_f64; do
   bash tools/pmc_traffic.sh round/pmc_$w --workload $w > /dev/null 2>&1
 done
 cd $ROOT
+# this run's counters -> profiles/pmc_r02.json, which the roofline blocks of the bench lines below read
+timeout 300 bash tools/pmc_busy.sh busy > gpurun_out/busy_summary.txt 2>&1
+bash tools/make_pmc_json.sh r02
+cp profiles/pmc_r02.json gpurun_out/round/pmc_r02.json
 python bench.py > gpurun_out/round/bench.json 2> gpurun_out/round/bench.err
 for w in ac_rk4_512_f32 ch_imex_1024_f32 gpe_strang_512_c64 gpe_strang_512_c64_spots ch_rk4_1024_f64 ch_rk4_4096_decomp; do
   python bench.py --workload $w --no-cpu-baseline --steps 5 --warmup 2 2>/dev/null | tail -1 > gpurun_out/round/bench_$w.json
