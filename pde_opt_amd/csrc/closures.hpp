@@ -47,6 +47,54 @@ __device__ __forceinline__ float t_logit<float>(float c) {
 // instructions: ocml's double-double log was 60 % of the fp64 pair kernel's VALU instructions.  Values outside
 // (0, 1) keep log's conventions (c = 0: -inf, c = 1: +inf, otherwise NaN) so a diverged run still reports NaNs.
 #ifndef PDEOPT_LOGIT64_OCML
+#ifndef PDEOPT_LOGIT64_TWO_DIV
+// ONE division: with c = ma 2^ea and 1 - c = mb 2^eb (hardware frexp, mantissas in [0.5, 1)) the ratio is
+// (ma / mb) 2^(ea - eb); ma is doubled / halved so that m = ma' / mb lands in [0.707, 1.414) without ever forming it,
+// and s = (m - 1) / (m + 1) = (ma' - mb) / (ma' + mb) directly -- the numerator is exact (Sterbenz), so s carries one
+// rounding of the sum and one of the quotient.  (The first form divided twice, c / (1 - c) and (m - 1) / (m + 1):
+// a v_rcp_f64 is 17 clocks, profiles/r02_valubench_raw.txt; -DPDEOPT_LOGIT64_TWO_DIV keeps it.)
+template <>
+__device__ __forceinline__ double t_logit<double>(double c) {
+  const double b = 1.0 - c;
+  int ea, eb;
+  double ma = frexp(c, &ea);
+  const double mb = frexp(b, &eb);
+  const bool lo = ma < 0.70710678118654752440 * mb;  // ratio below sqrt(1/2): double it
+  const bool hi = ma > 1.41421356237309504880 * mb;  // above sqrt(2): halve it
+  const int k = lo ? 1 : (hi ? -1 : 0);              // one 32-bit select pair instead of four 64-bit halves
+  ma = ldexp(ma, k);
+  const int e = ea - eb - k;
+  // (ma - mb) / (ma + mb) with the denominator in [1, 3): no scaling, no special cases -- reciprocal, two Newton
+  // steps, quotient, one residual correction (8 instructions against the 11-12 of the IEEE sequence with its
+  // v_div_scale / v_div_fmas / v_div_fixup; the result is within an ulp either way)
+  const double num = ma - mb, den = ma + mb;
+#ifdef PDEOPT_LOGIT64_IEEE_DIV
+  const double s = num / den;
+#else
+  double rc = __builtin_amdgcn_rcp(den);
+  rc = __builtin_fma(rc, __builtin_fma(-den, rc, 1.0), rc);
+  rc = __builtin_fma(rc, __builtin_fma(-den, rc, 1.0), rc);
+  const double q0 = num * rc;
+  const double s = __builtin_fma(__builtin_fma(-den, q0, num), rc, q0);
+#endif
+  const double z = s * s;
+  double p = 1.0 / 19.0;
+  p = p * z + 1.0 / 17.0;
+  p = p * z + 1.0 / 15.0;
+  p = p * z + 1.0 / 13.0;
+  p = p * z + 1.0 / 11.0;
+  p = p * z + 1.0 / 9.0;
+  p = p * z + 1.0 / 7.0;
+  p = p * z + 1.0 / 5.0;
+  p = p * z + 1.0 / 3.0;
+  const double two_s = s + s;
+  const double lm = two_s + two_s * (p * z);
+  const double ed = (double)e;
+  double res = ed * 6.93147180369123816490e-01 + (lm + ed * 1.90821492927058770002e-10);
+  if (!(c > 0.0 && c < 1.0)) res = (c == 0.0) ? -INFINITY : ((c == 1.0) ? INFINITY : NAN);
+  return res;
+}
+#else
 template <>
 __device__ __forceinline__ double t_logit<double>(double c) {
   const double r = c / (1.0 - c);
@@ -73,6 +121,7 @@ __device__ __forceinline__ double t_logit<double>(double c) {
   if (!(r > 0.0) || r == INFINITY) res = (r == 0.0) ? -INFINITY : ((r == INFINITY) ? INFINITY : NAN);
   return res;
 }
+#endif
 #else
 template <>
 __device__ __forceinline__ double t_logit<double>(double c) {

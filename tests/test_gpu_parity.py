@@ -777,3 +777,24 @@ def test_rhs_convergence_through_check_convergence(kind):
     assert numeric_args == args[2] and symbolic_args == args[3]  # the caller's dictionaries are left alone
     np.testing.assert_allclose(convergence_slope(dxs, errors), 2.0, rtol=0.1)
     assert errors[-1] < 2e-3 and all(a > b for a, b in zip(errors, errors[1:]))
+
+
+def test_fp64_logit_is_libm_class_on_the_gpu():
+    """The fp64 regular-solution closure log(c / (1 - c)) is hand-built (frexp of c and 1 - c, one Newton-refined
+    division, nine-term atanh series: csrc/closures.hpp).  Through the Allen-Cahn kernel with kappa = 0 and R = 1 the
+    right-hand side is -mu_h(u): compared with numpy's correctly rounded long-double log over (1e-9, 1 - 1e-9),
+    dense near 1/2 (where the logit vanishes and relative error is hardest) and near the ends."""
+    rng = np.random.default_rng(99)
+    n = 256
+    c = np.concatenate([rng.uniform(1e-9, 1 - 1e-9, n * n // 2), 0.5 + 1e-2 * rng.standard_normal(n * n // 4),
+                        10.0 ** rng.uniform(-9, -1, n * n // 8), 1.0 - 10.0 ** rng.uniform(-9, -1, n * n // 8)])
+    c = np.clip(c, 1e-9, 1 - 1e-9).reshape(n, n)
+    dom = std_domain(P, n, n)
+    eq = P.AllenCahn2DPeriodic(dom, 0.0, lambda u: np.log(u / (1 - u)), lambda u: np.ones_like(u))
+    got = -eq.rhs(c, 0.0)
+    cl = c.astype(np.longdouble)
+    want = np.log(cl / (1 - cl))  # 64-bit mantissa: the reference for a 53-bit result
+    err = np.abs(got.astype(np.longdouble) - want)
+    ulp = np.spacing(np.abs(want.astype(np.float64)))
+    assert float(np.max(err / np.maximum(ulp, 2.3e-16))) < 4.0, float(np.max(err / np.maximum(ulp, 2.3e-16)))
+    assert float(err.max()) < 4e-15
