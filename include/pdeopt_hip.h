@@ -262,6 +262,12 @@ int pdeopt_probe(pdeopt_ctx* ctx, const int32_t* cells, int n_probes, int env_fi
  * [env_count][nx][ny] bytes -- a quarter (fp32) / an eighth (fp64) of the D2H of the raw field. */
 int pdeopt_observe_u8(pdeopt_ctx* ctx, double lo, double hi, int env_first, int env_count,
                       uint8_t* host_out);
+/* The same frames left in device memory for a consumer on the same GPU (an RL policy in PyTorch-ROCm): *dev_out
+ * is a library-owned buffer of env_count * nx * ny bytes, valid until the next pdeopt_observe_u8* call or
+ * pdeopt_configure with another shape; the call returns after the ctx stream has produced it, so any stream may
+ * read it.  No reference counterpart: upstream hands observations to the host (pde_env.py:305-312). */
+int pdeopt_observe_u8_device(pdeopt_ctx* ctx, double lo, double hi, int env_first, int env_count, void** dev_out,
+                             int64_t* nbytes);
 /* rl_utils.detect_vortices (pde_opt/rl_utils.py:19-84) on the resident GPE wavefunction: integer phase
  * winding of every grid plaquette, |circulation| < tol * 2 pi and cells whose corner-averaged density
  * is below amp_thresh (if > 0) suppressed.  host_counts is [env_count][3] = {num_vortices,

@@ -127,6 +127,7 @@ _SIGNATURES = {
     "pdeopt_reduce": (C.c_int, [_VP, C.c_int, _VP]),
     "pdeopt_probe": (C.c_int, [_VP, _VP, C.c_int, C.c_int, C.c_int, _VP]),
     "pdeopt_observe_u8": (C.c_int, [_VP, C.c_double, C.c_double, C.c_int, C.c_int, _VP]),
+    "pdeopt_observe_u8_device": (C.c_int, [_VP, C.c_double, C.c_double, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]),
     "pdeopt_detect_vortices": (C.c_int, [_VP, C.c_double, C.c_double, C.c_int, C.c_int, _VP, _VP]),
     "pdeopt_tsit5_trial": (C.c_int, [_VP, C.c_double, C.c_double, C.c_double, C.c_double, _VP]),
     "pdeopt_tsit5_commit": (C.c_int, [_VP, C.c_int]),

@@ -671,6 +671,19 @@ int pdeopt_observe_u8(pdeopt_ctx* ctx, double lo, double hi, int env_first, int 
   return observe_u8(ctx, lo, hi, env_first, env_count, host_out);
 }
 
+int pdeopt_observe_u8_device(pdeopt_ctx* ctx, double lo, double hi, int env_first, int env_count, void** dev_out,
+                             int64_t* nbytes) {
+  if (!ctx || !dev_out) return PDEOPT_EINVAL;
+  int rc = check_envs(ctx, env_first, env_count);
+  if (rc) return rc;
+  if (ctx->prob.equation == PDEOPT_EQ_GPE) return fail(ctx, PDEOPT_EINVAL, "observe_u8 needs a real field");
+  PDEOPT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  if ((rc = observe_u8(ctx, lo, hi, env_first, env_count, nullptr))) return rc;
+  *dev_out = ctx->obs_dev;
+  if (nbytes) *nbytes = (int64_t)ctx->env_elems * env_count;
+  return PDEOPT_OK;
+}
+
 int pdeopt_detect_vortices(pdeopt_ctx* ctx, double amp_thresh, double tol, int env_first, int env_count,
                            int32_t* host_winding, int64_t* host_counts) {
   if (!ctx || !host_counts) return PDEOPT_EINVAL;

@@ -138,7 +138,8 @@ int observe_u8(pdeopt_ctx* ctx, double lo, double hi, int env_first, int env_cou
     hipLaunchKernelGGL(observe_u8_kernel<double>, dim3(blocks), dim3(256), 0, ctx->stream,
                        (const double*)ctx->Y + off, (uint32_t*)ctx->obs_dev, n4, lo, 255.0 / (hi - lo));
   PDEOPT_HIP_CHECK(ctx, hipGetLastError());
-  PDEOPT_HIP_CHECK(ctx, hipMemcpyAsync(host_out, ctx->obs_dev, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+  if (host_out)  // nullptr: the frames stay in ctx->obs_dev (pdeopt_observe_u8_device)
+    PDEOPT_HIP_CHECK(ctx, hipMemcpyAsync(host_out, ctx->obs_dev, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
   PDEOPT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   return PDEOPT_OK;
 }

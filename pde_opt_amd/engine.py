@@ -347,6 +347,21 @@ class HipEngine:
                                                 out.ctypes.data_as(C.c_void_p)))
         return out
 
+    def observe_u8_device(self, lo: float, hi: float, env_first: int = 0, env_count: Optional[int] = None) -> "DeviceArray":
+        """The same frames left on the GPU: a ``DeviceArray`` (``__cuda_array_interface__``; ``.torch()`` gives a
+        zero-copy ``torch.uint8`` tensor) over a library-owned buffer that the next ``observe_u8*`` call overwrites."""
+        n = self.batch - env_first if env_count is None else env_count
+        p, nbytes = C.c_void_p(), C.c_int64()
+        self._check(self._lib.pdeopt_observe_u8_device(self._h, float(lo), float(hi), int(env_first), int(n),
+                                                       C.byref(p), C.byref(nbytes)))
+        return DeviceArray(p.value, (n,) + self.state_shape, np.uint8, self.device, owner=self)
+
+    def state_device_array(self) -> "DeviceArray":
+        """The state field itself as a ``DeviceArray`` (batch,) + state_shape in the engine's dtype: valid until the
+        next ``configure`` with another shape; ``advance`` updates it in place (synchronise with ``sync()``)."""
+        ptr, _ = self.state_device_ptr()
+        return DeviceArray(ptr, (self.batch,) + self.state_shape, self.dtype, self.device, owner=self)
+
     def detect_vortices(self, amp_thresh: float = 0.0, tol: float = 0.5, env_first: int = 0,
                         env_count: Optional[int] = None, want_winding: bool = True):
         """Phase-winding census of the resident GPE state (rl_utils.detect_vortices on the GPU).
@@ -486,6 +501,23 @@ class HipEngine:
 
 
 _default_engines: dict = {}
+
+
+class DeviceArray:
+    """A typed view of library-owned device memory, exported through ``__cuda_array_interface__`` (version 2) --
+    what PyTorch-ROCm, CuPy and Numba read: the zero-copy hand-over to a consumer on the same GPU."""
+
+    def __init__(self, ptr: int, shape, dtype, device: int, owner=None):
+        self.ptr, self.shape, self.dtype, self.device, self._owner = int(ptr), tuple(int(v) for v in shape), np.dtype(dtype), int(device), owner
+
+    @property
+    def __cuda_array_interface__(self):
+        return {"shape": self.shape, "typestr": self.dtype.str, "data": (self.ptr, False), "version": 2, "strides": None}
+
+    def torch(self):
+        import torch
+
+        return torch.as_tensor(self, device=torch.device("cuda", self.device))
 
 
 def default_engine(device: int = 0) -> HipEngine:

@@ -189,7 +189,9 @@ class VectorPDEEnv:
     ``device_observation=(lo, hi)`` additionally forms the uint8 image observations of the declared
     observation space on the GPU (1 byte per cell crosses PCIe instead of 4 or 8);
     ``device_observation=("probes", cells)`` returns the state at the listed grid cells instead (sensor-style
-    observations: ``(B, n_cells)`` float64, a few numbers per environment).
+    observations: ``(B, n_cells)`` float64, a few numbers per environment).  ``observations_on_device=True``
+    leaves the uint8 frames on the GPU and returns them as a zero-copy ``torch.uint8`` CUDA tensor
+    ``(B, 1, nx, ny)`` for a policy on the same device (no PCIe at all; the tensor is overwritten by the next step).
     """
 
     def __init__(
@@ -217,8 +219,12 @@ class VectorPDEEnv:
         device_observation: Optional[tuple] = None,
         engine=None,
         reuse_observation_buffer: bool = False,
+        observations_on_device: bool = False,
     ):
         self.num_envs = int(num_envs)
+        self.observations_on_device = bool(observations_on_device)
+        if self.observations_on_device and (device_observation is None or isinstance(device_observation[0], str)):
+            raise ValueError("observations_on_device needs device_observation=(lo, hi)")
         # True: device-formed uint8 frames land in ONE page-locked host array that every step overwrites and
         # returns (copy what you keep) -- no 32 MiB allocation + page faults + pageable D2H per step
         self.reuse_observation_buffer = bool(reuse_observation_buffer)
@@ -362,6 +368,10 @@ class VectorPDEEnv:
                 obs = self._engine.probe(self.device_observation[1])  # (B, n_cells): point sensors
             else:
                 lo, hi = self.device_observation
+                if self.observations_on_device:
+                    obs = self._engine.observe_u8_device(lo, hi).torch()[:, None]  # (B, 1, nx, ny) uint8 CUDA tensor
+                    terminated = self._time >= self.end_time
+                    return obs, rewards, terminated, np.zeros(self.num_envs, dtype=bool), {}
                 if self.reuse_observation_buffer and self._obs_buffer is None and hasattr(self._engine, "pinned_empty"):
                     self._obs_buffer = self._engine.pinned_empty((self.num_envs,) + tuple(self.domain.points), np.uint8)
                 obs = self._engine.observe_u8(lo, hi, out=self._obs_buffer)[:, None]  # (B, 1, nx, ny) uint8, as the declared space

@@ -154,6 +154,39 @@ def test_device_observation_uint8():
     venv.close()
 
 
+def test_observations_and_state_stay_on_the_gpu_as_torch_tensors():
+    """zero-copy hand-over to a consumer on the same GPU: the uint8 frames and the state field as torch CUDA
+    tensors over library-owned memory (``__cuda_array_interface__``), equal to the host path bit for bit"""
+    torch = pytest.importorskip("torch")
+    dom = std_domain(P, 64, 128)
+    kw = _env_kwargs(dom)
+    host = P.VectorPDEEnv(3, **kw, device_reward="mean", device_observation=(0.0, 1.0))
+    dev = P.VectorPDEEnv(3, **kw, device_reward="mean", device_observation=(0.0, 1.0), observations_on_device=True)
+    host.reset(seed=5)
+    dev.reset(seed=5)
+    for _ in range(2):
+        obs_h, rew_h, _, _, _ = host.step([1, 0, 2])
+        obs_d, rew_d, _, _, _ = dev.step([1, 0, 2])
+        assert isinstance(obs_d, torch.Tensor) and obs_d.is_cuda and obs_d.dtype == torch.uint8
+        assert tuple(obs_d.shape) == (3, 1, 64, 128)
+        np.testing.assert_array_equal(obs_d.cpu().numpy(), obs_h)
+        np.testing.assert_array_equal(rew_d, rew_h)
+    # a torch op consumes the frames in place on the device
+    assert float(obs_d.float().mean()) == pytest.approx(float(obs_h.astype(np.float64).mean()), rel=1e-6)
+    eng = dev._engine
+    st = eng.state_device_array()
+    assert st.shape == (3, 64, 128) and st.__cuda_array_interface__["typestr"] == np.dtype(eng.dtype).str
+    t = st.torch()
+    np.testing.assert_array_equal(t.cpu().numpy(), dev.states)
+    t.mul_(0.5)  # the tensor aliases the library's state: the next get_state sees the change
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(dev.states, 0.5 * host.states)
+    with pytest.raises(ValueError):
+        P.VectorPDEEnv(3, **kw, device_reward="mean", observations_on_device=True)
+    host.close()
+    dev.close()
+
+
 def test_detect_vortices_against_reference_goldens(golden):
     """rl_utils.detect_vortices on the GPU: winding map, positions, charges and counts equal the
     reference's (pde_opt/rl_utils.py:19-84) -- integers, so exactly."""
