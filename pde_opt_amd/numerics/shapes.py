@@ -115,7 +115,7 @@ class Shape:
         lap, ids = self.laplacian_from_mask()
         n = lap.shape[0]
         if N is None:
-            N = max(n - 1, 1)
+            N = min(6, max(n - 1, 1))  # upstream passes k=None on to scipy's eigsh, whose default is 6 modes
         shift = max(float(lap.diagonal().mean()) if n else 1.0, 1.0) * 1e-8  # shift-invert just off the zero mode
         evals, evecs = scipy.sparse.linalg.eigsh(lap, k=N, which="LM", sigma=shift, tol=1e-8)
         basis = np.zeros(ids.shape + (N,))
