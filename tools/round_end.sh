@@ -9,4 +9,5 @@ timeout 900 python -m pytest tests -q -m gpu > gpurun_out/pytest_gpu.log 2>&1
 grep -E "passed|failed|error" gpurun_out/pytest_gpu.log | tail -2
 timeout 1800 bash tools/profile_round.sh
 [ -x tools/valubench.bin ] && ./tools/valubench.bin > gpurun_out/valubench.txt 2>&1
+[ -x tools/ldsbench.bin ] && ./tools/ldsbench.bin > gpurun_out/ldsbench.txt 2>&1
 tail -4 gpurun_out/busy_summary.txt | cut -c1-400
