@@ -21,6 +21,11 @@ from util import MOB, MU, rel_l2
 
 pytestmark = pytest.mark.gpu
 
+# PDEOPT_FUZZ_SCALE=k multiplies the number of seeded cases (a longer soak run; the defaults keep the suite short)
+import os  # noqa: E402
+
+_SCALE = max(1, int(os.environ.get("PDEOPT_FUZZ_SCALE", "1")))
+
 # tile-divisible, ragged (multiple of the 16-byte vector but not of the tile), vector-misaligned, tiny and 1-D
 SHAPES = [(64, 128), (32, 256), (128, 128), (48, 40), (100, 100), (36, 24), (8, 8), (33, 20), (30, 7), (17, 64),
           (96, 64), (256, 1), (1, 96), (16, 132), (72, 200)]
@@ -39,7 +44,7 @@ def _check(got, want, y0, dtype, what):
         assert rel_l2(inc_g, inc_w) < 2e-3, (what, rel_l2(inc_g, inc_w))
 
 
-@pytest.mark.parametrize("seed", range(64))
+@pytest.mark.parametrize("seed", range(64 * _SCALE))
 def test_explicit_fd_random_configuration(seed):
     rng = np.random.default_rng(1000 + seed)
     dtype = [np.float32, np.float64][int(rng.integers(2))]
@@ -120,7 +125,7 @@ def test_explicit_fd_random_configuration(seed):
         _check(got[b], ref, y0[b], dtype, what)
 
 
-@pytest.mark.parametrize("seed", range(16))
+@pytest.mark.parametrize("seed", range(16 * _SCALE))
 def test_imex_random_configuration(seed):
     """IMEX through the LDS transforms (power-of-two sizes: both radix plans, 64 .. 1024) and through rocFFT
     (other sizes), random batch / groups / per-environment implicit operators"""
@@ -171,7 +176,7 @@ def test_imex_random_configuration(seed):
         _check(got[b], ref, y0[b], dtype, what)
 
 
-@pytest.mark.parametrize("seed", range(16))
+@pytest.mark.parametrize("seed", range(16 * _SCALE))
 def test_strang_random_configuration(seed):
     """Strang split steps of the GPE: LDS transforms / rocFFT sizes, real and imaginary time, per-environment
     interaction strengths and potentials, static and moving light spots"""
