@@ -238,6 +238,37 @@ def api_throughput(P, name, rank, steps, warmup):
     return out
 
 
+def decomp_roofline(bytes_per_gpu, elapsed, substeps_total, tile_shape):
+    """The decomposed field runs the headline's stage-pair kernels on one tile per GPU (two launches per substep):
+    the same VALU-issue roofline, from the same kernel's counters scaled by the cells a launch covers, over the WALL
+    time of the substep loop -- exchange latency included, which is what this row is bound by at small tiles."""
+    alg_gbs = bytes_per_gpu / elapsed / 1e9
+    r = {"bound": "hbm", "achieved": alg_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg_gbs / HBM_PEAK_GBS, "traffic": None,
+         "algorithmic_gbs": alg_gbs, "algorithmic_frac_of_hbm_peak": alg_gbs / HBM_PEAK_GBS, "launches_timed": 2 * substeps_total,
+         "note": "per-GPU share of SURVEY 8(d)'s algorithmic bytes over the WALL time of the substep loop (exchange latency "
+                 "included: this row is latency-bound by design, DESIGN.md section 6)"}
+    try:
+        pmc = json.load(open(PMC_FILE)).get("ch_rk4_1024_f32")
+    except Exception:
+        pmc = None
+    if pmc and pmc["counters_per_launch"].get("SQ_INSTS_VALU"):
+        scale = (tile_shape[0] * tile_shape[1]) / (16.0 * 1024 * 1024)  # the profiled launch covers 16 x 1024^2 cells
+        insts = pmc["counters_per_launch"]["SQ_INSTS_VALU"] * scale
+        launch_s = elapsed / (2 * substeps_total)
+        r.update({"bound": "valu", "unit": "Ginst/s", "achieved": insts / launch_s / 1e9,
+                  "peak": N_SIMD * SHADER_HZ / VALU_CLK_MEASURED / 1e9, "valu_insts_per_launch": insts,
+                  "avg_launch_us": launch_s * 1e6})
+        r["frac"] = r["achieved"] / r["peak"]
+        if pmc.get("hbm_bytes_per_launch"):
+            r["traffic"] = pmc["hbm_bytes_per_launch"] * scale
+            r["traffic_frac"] = r["traffic"] / launch_s / 1e9 / HBM_PEAK_GBS
+        r["note"] = ("stage_pair_kernel on one tile per GPU: VALU-issue roofline as for the headline, SQ_INSTS_VALU / fabric bytes of "
+                     "that kernel (profiles/pmc_r02.json, ch_rk4_1024_f32) scaled by the cells of a launch, over the WALL time per "
+                     "launch of the substep loop -- halo exchange included; algorithmic_gbs is SURVEY 8(d)'s byte count over the "
+                     "same time (above the HBM peak because stage-pair fusion removes traffic)")
+    return r
+
+
 DECOMP_GRIDS = {1: (1, 1), 2: (2, 1), 4: (2, 2), 8: (4, 2)}
 
 
@@ -327,11 +358,7 @@ def run_decomp(args, P, world, rank, local_rank, dist):
             "achieved_gbs_whole_job": total_bytes / elapsed / 1e9,
             "nonfinite_cells": float(np.size(tile) - np.isfinite(tile).sum()),
             **(spot or {}),
-            "roofline": {"bound": "hbm", "achieved": total_bytes / elapsed / 1e9 / world, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": total_bytes / elapsed / 1e9 / world / HBM_PEAK_GBS, "traffic": None,
-                         "launches_timed": launches,
-                         "note": "per-GPU share of SURVEY 8(d)'s algorithmic bytes over the WALL time of the substep loop "
-                                 "(exchange latency included: this row is latency-bound by design, DESIGN.md section 6)"},
+            "roofline": decomp_roofline(total_bytes / world, elapsed, args.steps * substeps, sol.tile_shape),
         }
         print(json.dumps(line))
         sys.stdout.flush()
