@@ -107,6 +107,13 @@ def make_problem(P, name, batch, rank):
     return eq, y0, solver
 
 
+# Parity gates of the spot checks (relative L2 of the state INCREMENT against the fp64 oracle; observed in round 2:
+# RK4 6.4e-6, IMEX 4.1e-6, Strang 2.6e-6) and the hard bound on the largest absolute state error of an fp32 run
+# (observed 3.6e-7 on states of O(1): a few fp32 roundings of the state per 100 substeps)
+SPOT_TOL_F32 = {"rk4": 5e-5, "imex": 5e-5, "strang": 2e-5}
+SPOT_TOL_F64 = {"rk4": 1e-9, "imex": 1e-8, "strang": 1e-10}
+SPOT_ABS_TOL_F32 = 5e-7
+
 PMC_FILE = os.path.join(ROOT, "profiles", "pmc_r02.json")  # per-launch PMC averages (tools/pmc_to_json.py)
 N_SIMD, SHADER_HZ = 1024, 2.4e9  # 256 CUs x 4 SIMDs; MI355X_MICROARCH.md chip table
 # issue cost of one scalar-fp32 wave64 VALU instruction per SIMD, measured with >= 4 waves resident
@@ -272,102 +279,152 @@ def decomp_roofline(bytes_per_gpu, elapsed, substeps_total, tile_shape):
 DECOMP_GRIDS = {1: (1, 1), 2: (2, 1), 4: (2, 2), 8: (4, 2)}
 
 
-def run_decomp(args, P, world, rank, local_rank, dist):
+def run_decomp(args, P, world, rank, local_rank, dist, make_solver=None):
     """--workload ch_rk4_4096_decomp (BASELINE config 5): ONE Cahn-Hilliard field of 4096^2 cells, RK4 dt 2e-7,
-    decomposed over px x py GPUs (1x1, 2x1, 2x2, 4x2 for N = 1, 2, 4, 8) with an RCCL all-gather of packed halo
-    strips per fused stage pair (pde_opt_amd/decomp.py: the collective overlaps the interior tiles, substep pairs
-    replay from a device graph).  A step = 100 substeps of the one field; strong scaling (the field is fixed)."""
-    from pde_opt_amd.decomp import CartesianGrid, DecomposedSolver, NativeComm, TorchComm
+    decomposed over px x py ranks (1x1, 2x1, 2x2, 4x2 for N = 1, 2, 4, 8).  Default driver: the library's own substep
+    loop on its own RCCL communicator, halo-8 layout -- ONE all-gather of packed halo strips per substep, the strip
+    written by the second stage pair's edge tiles (pde_opt_amd/decomp.py, csrc/comm.hip).  --virtual-ranks R runs R
+    ranks of ONE process on ONE GPU (in-process group: the same loop, device copies instead of RCCL): every N > 1
+    code path without a second GPU.  A step = 100 substeps of the one field; strong scaling (the field is fixed).
+    ``make_solver(eq, grid)``: test hook (tests/test_dist_cpu.py drives this function's control flow -- which rank
+    runs which collective -- under gloo with an oracle-backed tile)."""
+    from pde_opt_amd.decomp import (CartesianGrid, DecomposedSolver, LocalGroupComm, NativeComm, TorchComm,
+                                    advance_group)
 
-    n, dt, substeps = args.decomp_grid, 2e-7, 100
-    if world not in DECOMP_GRIDS:
-        raise SystemExit(f"ch_rk4_4096_decomp runs on {sorted(DECOMP_GRIDS)} GPUs, not {world}")
-    px, py = DECOMP_GRIDS[world]
+    n, dt, substeps = args.decomp_grid, 2e-7, args.decomp_substeps
+    on_gpu = dist is None or dist.get_backend() == "nccl"
+    vranks = args.virtual_ranks
+    if vranks and world > 1:
+        raise SystemExit("--virtual-ranks runs in ONE process on one GPU")
+    nranks = vranks or world
+    if nranks not in DECOMP_GRIDS:
+        raise SystemExit(f"ch_rk4_4096_decomp runs on {sorted(DECOMP_GRIDS)} ranks, not {nranks}")
+    px, py = DECOMP_GRIDS[nranks]
     dom = P.Domain((n, n), ((-0.005 * n, 0.005 * n),) * 2, "dimensionless")
     eq = P.CahnHilliard2DPeriodic(dom, 0.002, REGSOL, C1MC)
-    grid = CartesianGrid(px, py, rank)
     # under torchrun: the library's own RCCL communicator and in-library substep loop (auto / native); the torch
-    # all-gather drivers stay selectable for comparison
+    # all-gather drivers stay selectable for comparison.  The overlap / graph drivers are halo-4 (one exchange per
+    # stage pair); everything else takes the halo-8 layout (one per substep).
     native = args.decomp_mode in ("auto", "native", "native-overlap")
-    comm = None if dist is None else (NativeComm() if native else TorchComm())
-    sol = DecomposedSolver(eq, grid, comm=comm, dtype=np.float32, device=local_rank)
-    sol.use_overlap = args.decomp_mode in ("native-overlap", "overlap", "graph")
-    sol.use_graph = args.decomp_mode == "graph"
+    halo = args.decomp_halo or (4 if args.decomp_mode in ("native-overlap", "overlap", "graph") else None)
     rng = np.random.default_rng(0)  # every rank draws the same global field and keeps its tile
     y0 = np.clip(0.5 + 0.01 * rng.standard_normal((n, n)), 0.05, 0.95).astype(np.float32)
-    sol.set_global_state(y0)
-    eng = sol.backend.engine
+    if make_solver is not None:
+        sols = [make_solver(eq, CartesianGrid(px, py, rank))]
+    elif vranks:
+        comms = LocalGroupComm.create(vranks)
+        sols = [DecomposedSolver(eq, CartesianGrid(px, py, r), comm=comms[r], dtype=np.float32, device=local_rank, halo=halo)
+                for r in range(vranks)]
+    else:
+        comm = None if dist is None else (NativeComm() if native else TorchComm())
+        sols = [DecomposedSolver(eq, CartesianGrid(px, py, rank), comm=comm, dtype=np.float32, device=local_rank, halo=halo)]
+    for sol in sols:
+        sol.use_overlap = args.decomp_mode in ("native-overlap", "overlap", "graph")
+        sol.use_graph = args.decomp_mode == "graph"
+        sol.set_global_state(y0)
+    sol = sols[0]
+    engines = [s_.backend.engine for s_ in sols]
+    eng = engines[0]
+
+    def advance(nsub):
+        if vranks:
+            advance_group(sols, dt, nsub)  # one host thread per virtual rank
+        else:
+            sol.advance(dt, nsub)
 
     def barrier():
-        eng.sync()
+        for e in engines:
+            e.sync()
         if dist is not None:
             import torch
 
-            torch.cuda.synchronize()
+            if on_gpu:
+                torch.cuda.synchronize()
             dist.barrier()
 
     for _ in range(args.warmup):
-        sol.advance(dt, substeps)
+        advance(substeps)
     barrier()
     launches0 = eng.stage_launches()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        sol.advance(dt, substeps)
+        advance(substeps)
     barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed = my_elapsed = time.perf_counter() - t0
     launches = eng.stage_launches() - launches0
+    per_rank = [my_elapsed]
     if dist is not None:
         import torch
 
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt[0])
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if on_gpu else "cpu")
+        allt = [torch.zeros_like(tt) for _ in range(world)]
+        dist.all_gather(allt, tt)
+        per_rank = [float(t_[0]) for t_ in allt]
+        elapsed = max(per_rank)
     tile = sol.local_state()
     spot = None
-    if rank == 0 and not args.no_parity_spot:
-        # rank 0's tile after a few fresh substeps against the C oracle run on the WHOLE periodic field
-        from oracle import c_oracle as CO
+    if not args.no_parity_spot:
+        # EVERY rank runs the spot's substeps (they contain collectives); rank 0 alone compares its tile against the
+        # C oracle run on the whole periodic field
+        nspot = 7
+        for s_ in sols:
+            s_.set_global_state(y0)
+        advance(nspot)
+        for e in engines:
+            e.sync()
+        if rank == 0:
+            from oracle import c_oracle as CO
 
-        nspot = 7  # through the same driver path as the timed loop (graph-replayed pairs + one eager substep)
-        sol.set_global_state(y0)
-        sol.advance(dt, nspot)
-        barrier_local = eng.sync()
-        got = sol.local_state().astype(np.float64)
-        _, cmu, cmob = _oracle_closures(WORKLOADS["ch_rk4_1024_f32"])
-        ref = CO.rk4(0, y0, dom.dx[0], dom.dx[1], 0.002, cmu, cmob, dt, nspot, threads=usable_cores()).astype(np.float64)
-        si, sj = grid.tile_slices(n, n)
-        base = y0[si, sj].astype(np.float64)
-        rel = float(np.linalg.norm((got - base) - (ref[si, sj] - base)) / np.linalg.norm(ref[si, sj] - base))
-        spot = {"parity_spot_rel_err": rel, "parity_spot_max_abs_err": float(np.max(np.abs(got - ref[si, sj]))),
-                "parity_spot_tol": 2e-3, "parity_spot_ok": bool(rel < 2e-3),
-                "parity_spot": f"rank 0's {got.shape[0]}x{got.shape[1]} tile after {nspot} substeps ({sol.mode}) vs oracle/c_oracle.c on the whole periodic field"}
+            _, cmu, cmob = _oracle_closures(WORKLOADS["ch_rk4_1024_f32"])
+            ref = CO.rk4(0, y0, dom.dx[0], dom.dx[1], 0.002, cmu, cmob, dt, nspot, threads=usable_cores()).astype(np.float64)
+            rel = mabs = 0.0
+            for s_ in sols:  # all virtual ranks' tiles (one tile under torchrun: this rank's)
+                got = s_.local_state().astype(np.float64)
+                si, sj = s_.grid.tile_slices(n, n)
+                base = y0[si, sj].astype(np.float64)
+                rel = max(rel, float(np.linalg.norm((got - base) - (ref[si, sj] - base)) / np.linalg.norm(ref[si, sj] - base)))
+                mabs = max(mabs, float(np.max(np.abs(got - ref[si, sj]))))
+            spot = {"parity_spot_rel_err": rel, "parity_spot_max_abs_err": mabs,
+                    "parity_spot_tol": SPOT_TOL_F32["rk4"], "parity_spot_max_abs_tol": SPOT_ABS_TOL_F32,
+                    "parity_spot_ok": bool(rel < SPOT_TOL_F32["rk4"] and mabs < SPOT_ABS_TOL_F32),
+                    "parity_spot": f"{len(sols)} tile(s) of {sol.tile_shape[0]}x{sol.tile_shape[1]} after {nspot} substeps "
+                                   f"({sol.mode}) vs oracle/c_oracle.c on the whole periodic field"}
     if dist is not None and world > 1:
         dist.barrier()
     if rank == 0:
         total_bytes = WORDS["rk4"] * 4 * n * n * substeps * args.steps
+        nex = sum(1 for f in sol.backend.phase_plan() if f >= 0)
         line = {
             "metric": "env-steps/sec (ch_rk4_4096_decomp: one 4096^2 field, 100 substeps/env-step) & achieved HBM GB/s",
             "value": args.steps / elapsed, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "ch_rk4_4096_decomp", "grid": [n, n], "tiles": [px, py], "tile": list(sol.tile_shape),
-                       "integrator": "rk4", "dt": dt, "substeps_per_env_step": substeps, "halo": 4,
-                       "exchange": "one all-gather of packed halo strips per fused stage pair (2 per substep)",
+                       "integrator": "rk4", "dt": dt, "substeps_per_env_step": substeps, "halo": getattr(sol.backend, "halo", 4),
+                       "exchange": f"one all-gather of packed halo strips per {'substep' if nex == 1 else 'fused stage pair'} ({nex} per substep)",
+                       "ranks": (f"{vranks} virtual ranks on ONE GPU (in-process group, csrc/comm.hip: the RCCL run's loop with device "
+                                 "copies as the collective)") if vranks else f"{world} process(es), one GPU each",
                        "strip_bytes": int(sol.backend.strip_elems) * 4, "driver_mode": sol.mode, "kernel": eng.last_kernel},
             "substeps_per_s": args.steps * substeps / elapsed, "us_per_substep": 1e6 * elapsed / (args.steps * substeps),
+            "per_rank_ms_per_step": [1e3 * t_ / args.steps for t_ in per_rank],
+            "comm_world_size": (dist.get_world_size() if dist is not None else (vranks or 1)),
             "achieved_gbs_whole_job": total_bytes / elapsed / 1e9,
             "nonfinite_cells": float(np.size(tile) - np.isfinite(tile).sum()),
             **(spot or {}),
-            "roofline": decomp_roofline(total_bytes / world, elapsed, args.steps * substeps, sol.tile_shape),
+            "roofline": decomp_roofline(total_bytes / max(world, 1), elapsed, args.steps * substeps,
+                                        (n, n) if vranks else sol.tile_shape),
         }
         print(json.dumps(line))
         sys.stdout.flush()
     if dist is not None:
         dist.barrier()
-        dist.destroy_process_group()
-    eng.close()
+        if make_solver is None:
+            dist.destroy_process_group()
+    for e in engines:
+        e.close()
     if spot is not None and not spot["parity_spot_ok"]:
         raise SystemExit(f"parity spot check FAILED: {spot}")
+    return spot
 
 
 def usable_cores():
@@ -433,9 +490,11 @@ def parity_spot(name, eng, eq, solver, y0, threads):
         worst_rel = max(worst_rel, float(np.linalg.norm((got - base) - (ref - base)) / (den if den > 0 else 1.0)))
         worst_abs = max(worst_abs, float(np.max(np.abs(got - ref))))
     f64 = y0.dtype == np.float64
-    tol = {"rk4": 1e-9 if f64 else 2e-3, "imex": 1e-8 if f64 else 2e-3, "strang": 1e-10 if f64 else 1e-4}[w["integ"]]
+    tol = (SPOT_TOL_F64 if f64 else SPOT_TOL_F32)[w["integ"]]
+    abs_tol = 1e-12 if f64 else SPOT_ABS_TOL_F32 * max(1.0, float(np.max(np.abs(y0))))
     return {"parity_spot_rel_err": worst_rel, "parity_spot_max_abs_err": worst_abs, "parity_spot_tol": tol,
-            "parity_spot_ok": bool(worst_rel < tol),
+            "parity_spot_max_abs_tol": abs_tol,
+            "parity_spot_ok": bool(worst_rel < tol and worst_abs < abs_tol),
             "parity_spot": f"{nsub} substeps of the timed call on fresh inputs, environments {envs} of {batch} "
                            f"(groups: {eng.last_groups()}) vs "
                            + ("oracle/c_oracle.c" if w["integ"] == "rk4" else "oracle/np_oracle.py")}
@@ -516,6 +575,11 @@ def main():
                          "loop in C; native-overlap: + collective on a second stream under the interior tiles; "
                          "plain / overlap / graph = torch all-gather drivers)")
     ap.add_argument("--decomp-grid", type=int, default=4096, help="ch_rk4_4096_decomp: cells per side of the one field")
+    ap.add_argument("--decomp-substeps", type=int, default=100, help="ch_rk4_4096_decomp: substeps per step")
+    ap.add_argument("--decomp-halo", type=int, default=0, choices=[0, 4, 8],
+                    help="ch_rk4_4096_decomp: halo layout (0 = auto: 8 = one exchange per substep, 4 for the overlap / graph drivers)")
+    ap.add_argument("--virtual-ranks", type=int, default=0,
+                    help="ch_rk4_4096_decomp: run this many ranks of ONE process on ONE GPU (in-process group)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
 
@@ -591,12 +655,15 @@ def main():
     kernel_name = eng.last_kernel
     launches = eng.stage_launches() - launches0  # fused stencil(+update) launches in the timed region
 
+    per_rank = [elapsed]
     if dist is not None:
         import torch
 
         tt = torch.tensor([elapsed, dev_ms], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed, dev_ms = float(tt[0]), float(tt[1])
+        allt = [torch.zeros_like(tt) for _ in range(world)]
+        dist.all_gather(allt, tt)  # every rank's clock: the line reports them all, value uses the slowest
+        per_rank = [float(t_[0]) for t_ in allt]
+        elapsed, dev_ms = max(per_rank), max(float(t_[1]) for t_ in allt)
 
     # sanity: the timed state is finite (a diverged run would be measuring NaN arithmetic)
     bad = float(eng.reduce(L.RED_NONFINITE).sum())
@@ -638,6 +705,8 @@ def main():
                 "kernel": kernel_name,
             },
             "substeps_per_s": args.gpus * batch * args.steps * substeps / elapsed,
+            "per_rank_ms_per_step": [1e3 * t_ / args.steps for t_ in per_rank],  # value uses the slowest rank
+            "comm_world_size": dist.get_world_size() if dist is not None else 1,  # as RCCL / torch.distributed sees it
             "achieved_gbs_whole_job": args.gpus * total_bytes / elapsed / 1e9,
             "nonfinite_cells": bad,
             **(spot or {}),

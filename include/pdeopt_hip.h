@@ -162,7 +162,11 @@ typedef enum {
                                  0 = auto (launch-bound problem sizes), 1 = always, -1 = never */
   PDEOPT_OPT_HALO_LAYOUT = 5, /* layout of the NEXT pdeopt_configure: 0 = periodic field (wrap by index),
                                  4 = rank-local tile padded by a 4-cell halo on every side, no wrap
-                                 (domain decomposition; halos filled by pdeopt_halo_unpack) */
+                                 (domain decomposition; halos filled by pdeopt_halo_unpack; one exchange per
+                                 RK4 phase: 2 per substep with fused stage pairs, 4 otherwise),
+                                 8 = 8-cell halo (+ a tail margin): ONE exchange per RK4 substep -- the first
+                                 stage pair is evaluated on the tile + 4 ring, so the second finds its input there
+                                 (fused Cahn-Hilliard stage pairs only; pdeopt_rk4_phase_plan reports {0, -1}) */
   PDEOPT_OPT_FUSE_STAGES = 4, /* RK4: temporally fused stages: 0 = auto (stage pairs 1+2 / 3+4 where a fused
                                  kernel exists; fp32 Allen-Cahn: the whole substep in one pass), 1 = stage
                                  pairs only, -1 = off (one launch per stage) */
@@ -285,7 +289,9 @@ int pdeopt_detect_vortices(pdeopt_ctx* ctx, double amp_thresh, double tol, int e
  * tile INTERIOR.  dev_send / dev_recv are DEVICE pointers (e.g. torch tensors handed to RCCL);
  * dev_recv holds the strips of all ranks, rank-major.  neighbours[8] = ranks of
  * {up, down, left, right, up-left, up-right, down-left, down-right} (up = smaller x index).
- * NULL dev_send / dev_recv selects an internal loop-back buffer (single rank, every neighbour 0). */
+ * NULL dev_send / dev_recv selects an internal loop-back buffer (single rank, every neighbour 0).
+ * Halo layout 8: h = 8 in the strip layout, and pdeopt_rk4_phase_plan reports nphases = 2 with fields = {0, -1}:
+ * only phase 0 is preceded by an exchange (of the state), phase 1 finds the ring of its input computed by phase 0. */
 int pdeopt_halo_strip_elems(pdeopt_ctx* ctx, int64_t* elems);
 int pdeopt_halo_pack(pdeopt_ctx* ctx, int field, void* dev_send);
 int pdeopt_halo_unpack(pdeopt_ctx* ctx, int field, const void* dev_recv, const int* neighbours);
@@ -314,6 +320,16 @@ int pdeopt_rk4_loopback_advance(pdeopt_ctx* ctx, double dt, int64_t n_substeps);
 int pdeopt_comm_unique_id(char out[128]);
 int pdeopt_comm_init(pdeopt_ctx* ctx, int world, int rank, const char id[128]);
 int pdeopt_comm_destroy(pdeopt_ctx* ctx);
+/* The same loop on an IN-PROCESS group of ranks instead of RCCL: the ranks are ctxs of one process -- several on one
+ * GPU ("virtual ranks": every N > 1 line of the decomposed driver runs without a second GPU) or one per GPU with a
+ * host thread each -- and the all-gather is device-to-device copies between their strip buffers, ordered by HIP
+ * events.  Every rank's thread must be inside pdeopt_rk4_decomposed_advance at the same time (they rendezvous once
+ * per exchange; a rank that does not show up within 60 s fails the call on every rank).  Destroy the members'
+ * communicators (pdeopt_comm_destroy / pdeopt_ctx_destroy) before the group. */
+typedef struct pdeopt_local_group pdeopt_local_group;
+int pdeopt_local_group_create(int world, pdeopt_local_group** out);
+int pdeopt_local_group_destroy(pdeopt_local_group* group);
+int pdeopt_comm_init_local(pdeopt_ctx* ctx, pdeopt_local_group* group, int rank);
 int pdeopt_rk4_decomposed_advance(pdeopt_ctx* ctx, double dt, int64_t n_substeps, const int* neighbours /* [8] */,
                                   int overlap);
 /* ctx whose work is ordered on a caller-owned HIP stream (e.g. torch's current stream, so RCCL

@@ -269,8 +269,8 @@ int pdeopt_set_option(pdeopt_ctx* ctx, int option, int64_t value) {
       ctx->opt_graph = value;
       return PDEOPT_OK;
     case PDEOPT_OPT_HALO_LAYOUT:
-      if (value != 0 && value != 4)
-        return fail(ctx, PDEOPT_EINVAL, "halo layout must be 0 (periodic) or 4 (padded tiles)");
+      if (value != 0 && value != 4 && value != 8)
+        return fail(ctx, PDEOPT_EINVAL, "halo layout must be 0 (periodic), 4 or 8 (padded tiles)");
       ctx->opt_halo = value;
       return PDEOPT_OK;
     case PDEOPT_OPT_FUSE_STAGES:
@@ -339,7 +339,7 @@ int pdeopt_configure(pdeopt_ctx* ctx, const pdeopt_problem* pr) {
   ctx->halo = (int)ctx->opt_halo;
   if (ctx->halo && pr->equation != PDEOPT_EQ_CAHN_HILLIARD && pr->equation != PDEOPT_EQ_ALLEN_CAHN)
     return fail(ctx, PDEOPT_EINVAL, "the padded (domain-decomposition) layout covers CH / AC only");
-  ctx->env_elems = (size_t)(pr->nx + 2 * ctx->halo) * (pr->ny + 2 * ctx->halo) * ctx->comps;
+  ctx->env_elems = (size_t)pad_rows(pr->nx, ctx->halo) * pad_ld(pr->ny, ctx->halo) * ctx->comps;
   if (pr->equation == PDEOPT_EQ_CAHN_HILLIARD_3D) ctx->env_elems *= (size_t)pr->nz;
   ctx->total_bytes = ctx->env_elems * pr->batch * ctx->esize;
   int rc;
@@ -495,7 +495,7 @@ int pdeopt_set_state(pdeopt_ctx* ctx, int env_first, int env_count, const void* 
   const size_t eb = ctx->env_elems * ctx->esize;
   if (ctx->halo) {
     // interior of each padded tile; halo cells are filled by pdeopt_halo_unpack
-    const size_t h = ctx->halo, pny = ctx->prob.ny + 2 * h, row = (size_t)ctx->prob.ny * ctx->esize;
+    const size_t h = ctx->halo, pny = pad_ld(ctx->prob.ny, ctx->halo), row = (size_t)ctx->prob.ny * ctx->esize;
     for (int e = 0; e < env_count; ++e)
       PDEOPT_HIP_CHECK(ctx, hipMemcpy2DAsync((char*)ctx->Y + eb * (env_first + e) + (h * pny + h) * ctx->esize,
                                              pny * ctx->esize, (const char*)host + (size_t)e * row * ctx->prob.nx,
@@ -517,7 +517,7 @@ int pdeopt_get_state(pdeopt_ctx* ctx, int env_first, int env_count, void* host) 
   PDEOPT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   const size_t eb = ctx->env_elems * ctx->esize;
   if (ctx->halo) {
-    const size_t h = ctx->halo, pny = ctx->prob.ny + 2 * h, row = (size_t)ctx->prob.ny * ctx->esize;
+    const size_t h = ctx->halo, pny = pad_ld(ctx->prob.ny, ctx->halo), row = (size_t)ctx->prob.ny * ctx->esize;
     for (int e = 0; e < env_count; ++e)
       PDEOPT_HIP_CHECK(ctx, hipMemcpy2DAsync((char*)host + (size_t)e * row * ctx->prob.nx, row,
                                              (const char*)ctx->Y + eb * (env_first + e) + (h * pny + h) * ctx->esize,
@@ -847,6 +847,25 @@ int pdeopt_comm_init(pdeopt_ctx* ctx, int world, int rank, const char id[128]) {
   if (world < 1 || rank < 0 || rank >= world) return fail(ctx, PDEOPT_EINVAL, "rank %d of %d", rank, world);
   PDEOPT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   return comm_init(ctx, world, rank, id);
+}
+
+int pdeopt_local_group_create(int world, pdeopt_local_group** out) {
+  if (!out) return PDEOPT_EINVAL;
+  *out = nullptr;
+  if (world < 1 || world > 1024) return fail(nullptr, PDEOPT_EINVAL, "local group of %d ranks", world);
+  *out = local_group_new(world);
+  return PDEOPT_OK;
+}
+
+int pdeopt_local_group_destroy(pdeopt_local_group* g) {
+  if (g) local_group_delete(g);
+  return PDEOPT_OK;
+}
+
+int pdeopt_comm_init_local(pdeopt_ctx* ctx, pdeopt_local_group* g, int rank) {
+  if (!ctx || !g) return PDEOPT_EINVAL;
+  PDEOPT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  return comm_init_local(ctx, g, rank);
 }
 
 int pdeopt_comm_destroy(pdeopt_ctx* ctx) {

@@ -89,12 +89,17 @@ def _parse_resources(stderr: str):
     return res, "" if noise else "\n".join(rest)
 
 
+LAST_BUILD = {"compiled": [], "reused": [], "linked": False}  # what the last build() did (printed by it)
+
+
 def _compile(src: str, force: bool, extra: list[str]) -> str:
     obj = os.path.join(OBJ_DIR, src.replace(".hip", f".{_flags_tag(extra)}.o"))
     sp = os.path.join(HERE, src)
     stamp = max(os.path.getmtime(sp), _newest_header())
     if not force and os.path.exists(obj) and os.path.exists(obj + ".resources.json") and os.path.getmtime(obj) >= stamp:
+        LAST_BUILD["reused"].append(src)
         return obj
+    LAST_BUILD["compiled"].append(src)
     # the remarks cost nothing at run time: registers / scratch / occupancy of every kernel land next to the object,
     # where tests/test_kernel_budgets.py holds the occupancy-critical kernels to their budgets
     cmd = [_hipcc(), *CXXFLAGS, *extra, "-Rpass-analysis=kernel-resource-usage", "-c", sp, "-o", obj]
@@ -127,6 +132,7 @@ def kernel_resources(extra_flags: list[str] | None = None) -> dict:
 def build(force: bool = False, verbose: bool = True, extra_flags: list[str] | None = None) -> str:
     os.makedirs(OBJ_DIR, exist_ok=True)
     extra = list(extra_flags or [])
+    LAST_BUILD.update(compiled=[], reused=[], linked=False)
     with ThreadPoolExecutor(max_workers=min(7, len(SOURCES))) as ex:
         objs = list(ex.map(lambda s: _compile(s, force, extra), SOURCES))
     # the link stamp records which objects (flag sets included) the library was made of
@@ -144,7 +150,13 @@ def build(force: bool = False, verbose: bool = True, extra_flags: list[str] | No
             raise RuntimeError(f"link failed:\n{' '.join(cmd)}\n{r.stdout}\n{r.stderr}")
         with open(stamp, "w") as f:
             f.write(want)
+        LAST_BUILD["linked"] = True
     if verbose:
+        # objects are cached by source / header mtime and flag set: say which were rebuilt and which reused, so a
+        # log shows whether the library on a box is this checkout's (tests/test_kernel_budgets.py reads the
+        # resource reports written next to the objects by THIS function)
+        print(f"[pde_opt_amd] compiled {LAST_BUILD['compiled'] or 'nothing'}, reused {len(LAST_BUILD['reused'])} cached "
+              f"object(s), {'linked' if LAST_BUILD['linked'] else 'library up to date'}")
         print(f"[pde_opt_amd] {LIB} ({os.path.getsize(LIB) / 1e6:.1f} MB)")
     return LIB
 

@@ -16,7 +16,66 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <chrono>
+#include <condition_variable>
+#include <mutex>
+
 #include "common.hpp"
+
+// An IN-PROCESS group of ranks (pdeopt_local_group_create): the ranks are ctxs of ONE process -- several engines on
+// one GPU (virtual ranks: the whole decomposed loop, neighbour tables and rank offsets into the gathered buffer run
+// without a second GPU) or one engine per GPU driven by one host thread each -- and the all-gather is device-side
+// copies between their strip buffers, ordered by HIP events:
+//
+//   rank r, exchange number q (parity p = q & 1):
+//     [pack / fused pack wrote send[p]]          stream r     (before it: wait done[p][*] of exchange q - 2)
+//     record ready[p][r]                         stream r
+//     -- host barrier over the ranks' threads: every ready[p][*] has been recorded --
+//     for every rank s:  wait ready[p][s];  copy send[p] of rank s -> recv[s] of rank r       stream r
+//     record done[p][r]                          stream r
+//
+// Two send buffers per rank (parity) so that a rank may pack exchange q + 1 while a slower neighbour still copies
+// exchange q; the wait on done[p][*] of exchange q - 2 happens-after its host-side record because this rank has
+// passed the barrier of exchange q - 1, which every rank enters after recording it.  Every rank's host thread must
+// be inside pdeopt_rk4_decomposed_advance at the same time (the barrier times out with an error otherwise).
+struct pdeopt_local_group {
+  int world = 0;
+  std::mutex m;
+  std::condition_variable cv;
+  int arrived = 0;
+  uint64_t generation = 0;
+  bool broken = false;
+  std::vector<int> attached;          // rank taken?
+  std::vector<void*> send[2];         // [parity][rank] strip buffers, published by their owners
+  std::vector<size_t> send_bytes;     // [rank]
+  std::vector<hipEvent_t> ready[2], done[2];
+  std::vector<int> done_recorded[2];  // has done[p][r] ever been recorded?
+
+  // false: timed out or another rank failed
+  bool barrier(double timeout_s) {
+    std::unique_lock<std::mutex> lk(m);
+    if (broken) return false;
+    const uint64_t gen = generation;
+    if (++arrived == world) {
+      arrived = 0;
+      ++generation;
+      cv.notify_all();
+      return true;
+    }
+    const bool ok = cv.wait_for(lk, std::chrono::duration<double>(timeout_s), [&] { return generation != gen || broken; });
+    if (!ok || broken) {
+      broken = true;  // the other ranks must not wait for this one again
+      cv.notify_all();
+      return false;
+    }
+    return true;
+  }
+  void fail_all() {
+    std::lock_guard<std::mutex> lk(m);
+    broken = true;
+    cv.notify_all();
+  }
+};
 
 namespace pdeopt {
 
@@ -34,6 +93,12 @@ struct CommState {
   void* send = nullptr;                   // strip of this rank
   void* recv = nullptr;                   // strips of all ranks, rank-major
   size_t strip_bytes = 0;
+  // in-process backend (pdeopt_comm_init_local): no RCCL, copies between the ranks' buffers
+  pdeopt_local_group* group = nullptr;
+  void* send2 = nullptr;                  // second send buffer (parity 1)
+  uint64_t seq = 0;                       // exchanges done so far
+  bool local() const { return group != nullptr; }
+  void* send_buf() const { return local() && (seq & 1) ? send2 : send; }  // where the NEXT exchange's strip goes
 };
 
 namespace {
@@ -94,12 +159,40 @@ int comm_init(pdeopt_ctx* ctx, int world, int rank, const char* id128) {
   return PDEOPT_OK;
 }
 
+int comm_init_local(pdeopt_ctx* ctx, pdeopt_local_group* g, int rank) {
+  if (ctx->comm && (ctx->comm->comm || ctx->comm->group)) return fail(ctx, PDEOPT_ESTATE, "this ctx already has a communicator");
+  {
+    std::lock_guard<std::mutex> lk(g->m);
+    if (rank < 0 || rank >= g->world) return fail(ctx, PDEOPT_EINVAL, "rank %d outside the local group of %d", rank, g->world);
+    if (g->attached[rank]) return fail(ctx, PDEOPT_EINVAL, "rank %d of the local group is taken", rank);
+    g->attached[rank] = 1;
+  }
+  if (!ctx->comm) ctx->comm = new CommState();
+  CommState& c = *ctx->comm;
+  c.group = g;
+  c.world = g->world;
+  c.rank = rank;
+  c.seq = 0;
+  for (int p = 0; p < 2; ++p) {
+    PDEOPT_HIP_CHECK(ctx, hipEventCreateWithFlags(&g->ready[p][rank], hipEventDisableTiming));
+    PDEOPT_HIP_CHECK(ctx, hipEventCreateWithFlags(&g->done[p][rank], hipEventDisableTiming));
+  }
+  return PDEOPT_OK;
+}
+
 void comm_destroy(pdeopt_ctx* ctx) {
   CommState* c = ctx->comm;
   if (!c) return;
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   if (c->cstream) (void)hipStreamSynchronize(c->cstream);
   if (c->comm) (void)c->comm_destroy(c->comm);
+  if (c->group) {
+    // the group outlives its members' buffers: un-publish them (the events stay with the group until it is destroyed)
+    std::lock_guard<std::mutex> lk(c->group->m);
+    c->group->send[0][c->rank] = c->group->send[1][c->rank] = nullptr;
+    c->group->attached[c->rank] = 0;
+  }
+  if (c->send2) (void)hipFree(c->send2);
   if (c->send) (void)hipFree(c->send);
   if (c->recv) (void)hipFree(c->recv);
   if (c->packed) (void)hipEventDestroy(c->packed);
@@ -109,10 +202,90 @@ void comm_destroy(pdeopt_ctx* ctx) {
   ctx->comm = nullptr;
 }
 
+namespace {
+
+// in-process all-gather of the strip in c.send_buf() into c.recv (header comment of this file)
+int local_all_gather(pdeopt_ctx* ctx, CommState& c) {
+  pdeopt_local_group& g = *c.group;
+  const int p = (int)(c.seq & 1);
+  PDEOPT_HIP_CHECK(ctx, hipEventRecord(g.ready[p][c.rank], ctx->stream));
+  if (!g.barrier(60.0))
+    return fail(ctx, PDEOPT_ESTATE, "local group: a rank did not reach exchange %llu (every rank's host thread must be "
+                "inside pdeopt_rk4_decomposed_advance at the same time, with the same substep count)", (unsigned long long)c.seq);
+  for (int r = 0; r < c.world; ++r) {
+    void* src;
+    size_t bytes;
+    {
+      std::lock_guard<std::mutex> lk(g.m);
+      src = g.send[p][r];
+      bytes = g.send_bytes[r];
+    }
+    if (!src || bytes != c.strip_bytes) {
+      g.fail_all();
+      return fail(ctx, PDEOPT_EINVAL, "local group: rank %d publishes a strip of %zu bytes, this rank expects %zu", r, bytes, c.strip_bytes);
+    }
+    if (r != c.rank) PDEOPT_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, g.ready[p][r], 0));
+    PDEOPT_HIP_CHECK(ctx, hipMemcpyAsync((char*)c.recv + (size_t)r * bytes, src, bytes, hipMemcpyDefault, ctx->stream));
+  }
+  PDEOPT_HIP_CHECK(ctx, hipEventRecord(g.done[p][c.rank], ctx->stream));
+  {
+    std::lock_guard<std::mutex> lk(g.m);
+    g.done_recorded[p][c.rank] = 1;
+  }
+  ++c.seq;
+  return PDEOPT_OK;
+}
+
+// before this rank overwrites c.send_buf() (parity p of exchange seq): every rank's copies of exchange seq - 2 out
+// of that buffer must have run.  Their done events were recorded before those ranks entered the barrier of exchange
+// seq - 1, which this rank has left.
+int local_wait_send_free(pdeopt_ctx* ctx, CommState& c) {
+  pdeopt_local_group& g = *c.group;
+  const int p = (int)(c.seq & 1);
+  if (c.seq < 2) return PDEOPT_OK;
+  for (int r = 0; r < c.world; ++r) {
+    if (r == c.rank) continue;  // own copies run on this stream, in order
+    bool rec;
+    {
+      std::lock_guard<std::mutex> lk(g.m);
+      rec = g.done_recorded[p][r] != 0;
+    }
+    if (rec) PDEOPT_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, g.done[p][r], 0));
+  }
+  return PDEOPT_OK;
+}
+
+}  // namespace
+
+pdeopt_local_group* local_group_new(int world) {
+  auto* g = new pdeopt_local_group();
+  g->world = world;
+  g->attached.assign((size_t)world, 0);
+  g->send_bytes.assign((size_t)world, 0);
+  for (int p = 0; p < 2; ++p) {
+    g->send[p].assign((size_t)world, nullptr);
+    g->ready[p].assign((size_t)world, nullptr);
+    g->done[p].assign((size_t)world, nullptr);
+    g->done_recorded[p].assign((size_t)world, 0);
+  }
+  return g;
+}
+
+void local_group_delete(pdeopt_local_group* g) {
+  for (int p = 0; p < 2; ++p) {
+    for (hipEvent_t e : g->ready[p])
+      if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : g->done[p])
+      if (e) (void)hipEventDestroy(e);
+  }
+  delete g;
+}
+
 // n RK4 substeps of this rank's tile; nbr[8] = ranks of {up, down, left, right, UL, UR, DL, DR}
 int rk4_decomposed_advance(pdeopt_ctx* ctx, double dt, int64_t n, const int* nbr, int overlap) {
   CommState* cp = ctx->comm;
-  if (!cp || !cp->comm) return fail(ctx, PDEOPT_ESTATE, "pdeopt_comm_init has not been called");
+  if (!cp || (!cp->comm && !cp->group))
+    return fail(ctx, PDEOPT_ESTATE, "pdeopt_comm_init / pdeopt_comm_init_local has not been called");
   CommState& c = *cp;
   for (int q = 0; q < 8; ++q)
     if (nbr[q] < 0 || nbr[q] >= c.world) return fail(ctx, PDEOPT_EINVAL, "neighbour rank %d outside 0..%d", nbr[q], c.world - 1);
@@ -121,33 +294,79 @@ int rk4_decomposed_advance(pdeopt_ctx* ctx, double dt, int64_t n, const int* nbr
   int rc;
   if (c.strip_bytes != strip_bytes) {
     PDEOPT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (c.local()) {  // nobody may still be copying out of the old buffers: the group is idle between advance calls
+      std::lock_guard<std::mutex> lk(c.group->m);
+      c.group->send[0][c.rank] = c.group->send[1][c.rank] = nullptr;
+    }
     if (c.send) (void)hipFree(c.send);
+    if (c.send2) (void)hipFree(c.send2);
     if (c.recv) (void)hipFree(c.recv);
-    c.send = c.recv = nullptr;
+    c.send = c.send2 = c.recv = nullptr;
     if ((rc = ensure_buffer(ctx, &c.send, strip_bytes))) return rc;
+    if (c.local() && (rc = ensure_buffer(ctx, &c.send2, strip_bytes))) return rc;
     if ((rc = ensure_buffer(ctx, &c.recv, strip_bytes * (size_t)c.world))) return rc;
     c.strip_bytes = strip_bytes;
+    if (c.local()) {
+      std::lock_guard<std::mutex> lk(c.group->m);
+      c.group->send[0][c.rank] = c.send;
+      c.group->send[1][c.rank] = c.send2;
+      c.group->send_bytes[c.rank] = strip_bytes;
+    }
   }
   int fields[4], nph = 0;
   rk4_phase_plan(ctx, fields, &nph);
-  const bool split = overlap && nph == 2;  // interior / edge launches exist for the fused stage pairs
   const ncclDataType_t dtype = ctx->prob.dtype == PDEOPT_F32 ? ncclFloat32 : ncclFloat64;
+  // the collective: all ranks' strips (this rank's in `send`) -> c.recv, rank-major, on `stream`
+  auto all_gather = [&](void* send, hipStream_t stream) -> int {
+    if (c.local()) return local_all_gather(ctx, c);  // (always on the compute stream)
+    PDEOPT_NCCL_CHECK(ctx, c, c.all_gather(send, c.recv, strip_elems, dtype, c.comm, stream));
+    return PDEOPT_OK;
+  };
+  auto abort_group = [&](int code) {
+    if (c.local()) c.group->fail_all();  // the other ranks' threads must not wait for this one
+    return code;
+  };
+
+  if (ctx->halo == 8) {
+    // ONE exchange per substep (halo-8 layout):
+    //   pack(Y) -> all-gather                                   prologue: the state as it stands
+    //   per substep:  unpack(Y) -> PAIR_12 on tile + 4 -> PAIR_34, its edge tiles writing the NEW state's strip
+    //                 (no pack launch) -> all-gather (not after the last substep)
+    if (n <= 0) return PDEOPT_OK;
+    if (c.local() && (rc = local_wait_send_free(ctx, c))) return abort_group(rc);
+    void* send = c.send_buf();
+    if ((rc = halo_pack(ctx, 0, send))) return abort_group(rc);
+    if ((rc = all_gather(send, ctx->stream))) return abort_group(rc);
+    for (int64_t s = 0; s < n; ++s) {
+      if ((rc = halo_unpack(ctx, 0, c.recv, nbr))) return abort_group(rc);
+      const bool more = s + 1 < n;
+      if (more && c.local() && (rc = local_wait_send_free(ctx, c))) return abort_group(rc);
+      send = c.send_buf();
+      if ((rc = rk4_substep_h8(ctx, dt, more ? send : nullptr))) return abort_group(rc);
+      if (more && (rc = all_gather(send, ctx->stream))) return abort_group(rc);
+    }
+    return PDEOPT_OK;
+  }
+
+  const bool split = overlap && nph == 2 && !c.local();  // interior / edge launches exist for the fused stage pairs
   for (int64_t s = 0; s < n; ++s) {
     for (int ph = 0; ph < nph; ++ph) {
-      if ((rc = halo_pack(ctx, fields[ph], c.send))) return rc;
+      if (c.local() && (rc = local_wait_send_free(ctx, c))) return abort_group(rc);
+      void* send = c.send_buf();
+      if ((rc = halo_pack(ctx, fields[ph], send))) return abort_group(rc);
       if (split) {
         PDEOPT_HIP_CHECK(ctx, hipEventRecord(c.packed, ctx->stream));
         PDEOPT_HIP_CHECK(ctx, hipStreamWaitEvent(c.cstream, c.packed, 0));
-        PDEOPT_NCCL_CHECK(ctx, c, c.all_gather(c.send, c.recv, strip_elems, dtype, c.comm, c.cstream));
+        if ((rc = all_gather(send, c.cstream))) return rc;
         PDEOPT_HIP_CHECK(ctx, hipEventRecord(c.gathered, c.cstream));
         if ((rc = rk4_phase(ctx, ph, dt, 1))) return rc;  // interior tiles: no halo reads
         PDEOPT_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, c.gathered, 0));
         if ((rc = halo_unpack(ctx, fields[ph], c.recv, nbr))) return rc;
         if ((rc = rk4_phase(ctx, ph, dt, 2))) return rc;  // edge tiles
       } else {
-        PDEOPT_NCCL_CHECK(ctx, c, c.all_gather(c.send, c.recv, strip_elems, dtype, c.comm, ctx->stream));
-        if ((rc = halo_unpack(ctx, fields[ph], c.recv, nbr))) return rc;
-        if ((rc = rk4_phase(ctx, ph, dt, 0))) return rc;
+        if ((rc = all_gather(send, ctx->stream))) return abort_group(rc);
+        if ((rc = halo_unpack(ctx, fields[ph], c.recv, nbr))) return abort_group(rc);
+        if ((rc = rk4_phase(ctx, ph, dt, 0))) return abort_group(rc);
       }
     }
   }

@@ -91,7 +91,7 @@ struct AuxField {
   bool loaded = false;
 };
 
-struct CommState;    // RCCL communicator + strip buffers of the decomposed driver (comm.hip)
+struct CommState;    // RCCL / in-process communicator + strip buffers of the decomposed driver (comm.hip)
 struct Spectral;     // rocFFT plans + work buffers (spectral.hip)
 struct StrangFused;  // LDS-FFT split-step state (strang_fused.hip)
 
@@ -153,8 +153,10 @@ struct pdeopt_ctx {
   int64_t opt_tile_rows = 0;  // 0 auto, 16 or 32
   int64_t opt_group_envs = 0; // explicit integrators: envs per cache-resident group (0 auto, <0 whole batch)
   int64_t n_stage_launches = 0;  // fused stencil+update launches issued so far
-  int64_t opt_halo = 0;          // requested halo width of the NEXT configure (0 periodic, 4 padded)
+  int64_t opt_halo = 0;          // requested halo width of the NEXT configure (0 periodic, 4 or 8 padded)
   int halo = 0;                  // halo width of the configured layout
+  int pair_ext = 0;              // next PAIR_12 launch covers the tile + this many ring cells (halo-8 layout: 4)
+  void* pair_strip = nullptr;    // next PAIR_34 launch also writes the tile's halo strip here (fused pack)
   void* halo_scratch = nullptr;  // single-rank loop-back buffer for pack/unpack
   size_t halo_scratch_bytes = 0;
   int64_t opt_imex_lds_fft = 0;  // IMEX transforms: 0 auto (hand-written passes where the size is covered), -1 rocFFT
@@ -186,15 +188,24 @@ struct pdeopt_ctx {
 
 namespace pdeopt {
 
+// Padded (domain-decomposition) layouts.  halo 4: the tile with 4 halo cells on every side.  halo 8: 8 halo cells
+// in front of the tile and 8 + a tail margin behind it -- the first stage pair of a substep runs on the tile + 4
+// ring in whole workgroup tiles (32 rows x 32 16-byte vectors) that start at cell (-4, -4), so its last tile row /
+// column over-runs the ring by up to a tile; the over-run cells are computed from whatever the margin holds and
+// written back into it, nobody reads them.  Rows: 8 + nx + 8 + 32; row pitch: 8 + ny + 8 + 128.
+constexpr int kTailRows = 32, kTailCols = 128;
+inline int pad_rows(int nx, int h) { return h == 8 ? nx + 2 * h + kTailRows : nx + 2 * h; }
+inline int pad_ld(int ny, int h) { return h == 8 ? ny + 2 * h + kTailCols : ny + 2 * h; }
+
 // field geometry of the configured layout: periodic, or padded by ctx->halo cells on every side
 inline Geo make_geo(const pdeopt_ctx* ctx) {
   Geo g;
   const int h = ctx->halo;
   g.nx = ctx->prob.nx;
   g.ny = ctx->prob.ny;
-  g.ld = ctx->prob.ny + 2 * h;
+  g.ld = pad_ld(ctx->prob.ny, h);
   g.off = (int64_t)h * g.ld + h;
-  g.bstride = (int64_t)(ctx->prob.nx + 2 * h) * g.ld;
+  g.bstride = (int64_t)pad_rows(ctx->prob.nx, h) * g.ld;
   g.periodic = h == 0 ? 1 : 0;
   g.nz = ctx->prob.nz > 1 ? ctx->prob.nz : 1;
   if (g.nz > 1) g.bstride *= g.nz;  // [nx][ny][nz], no halo layout in 3-D
@@ -249,11 +260,17 @@ int halo_unpack(pdeopt_ctx* ctx, int field, const void* dev_recv, const int* nbr
 size_t halo_strip_elems(const pdeopt_ctx* ctx);
 int rk4_phase(pdeopt_ctx* ctx, int phase, double dt, int part = 0);
 int rk4_loopback_advance(pdeopt_ctx* ctx, double dt, int64_t n);
+// halo-8 layout: one substep = [unpack(Y)] -> PAIR_12 on the tile + 4 ring -> PAIR_34 (+ the new state's halo strip
+// written into `strip` by the edge tiles' epilogue when strip != nullptr); Y / TA are swapped
+int rk4_substep_h8(pdeopt_ctx* ctx, double dt, void* strip);
 int rk4_phase_plan(pdeopt_ctx* ctx, int* fields, int* nphases);
 void* field_ptr(pdeopt_ctx* ctx, int field);
 // comm.hip
 int comm_unique_id(pdeopt_ctx* ctx, char* out128);
 int comm_init(pdeopt_ctx* ctx, int world, int rank, const char* id128);
+int comm_init_local(pdeopt_ctx* ctx, pdeopt_local_group* g, int rank);
+pdeopt_local_group* local_group_new(int world);
+void local_group_delete(pdeopt_local_group* g);
 void comm_destroy(pdeopt_ctx* ctx);
 int rk4_decomposed_advance(pdeopt_ctx* ctx, double dt, int64_t n, const int* nbr, int overlap);
 // reduce.hip

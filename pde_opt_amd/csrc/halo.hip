@@ -28,8 +28,8 @@ HaloGeo halo_geo(const pdeopt_ctx* ctx) {
   g.nx = ctx->prob.nx;
   g.ny = ctx->prob.ny;
   g.h = ctx->halo;
-  g.ld = g.ny + 2 * g.h;
-  g.bstride = (int64_t)(g.nx + 2 * g.h) * g.ld;
+  g.ld = pad_ld(g.ny, g.h);
+  g.bstride = (int64_t)pad_rows(g.nx, g.h) * g.ld;
   g.off = (int64_t)g.h * g.ld + g.h;
   g.per_env = 2LL * g.h * g.ny + 2LL * g.nx * g.h + 4LL * g.h * g.h;
   return g;

@@ -467,7 +467,13 @@ void graph_destroy(pdeopt_ctx* ctx) {
 int rk4_phase_plan(pdeopt_ctx* ctx, int* fields, int* nphases) {
   const bool fused = ctx->opt_kernel_path != 1 && ctx->prob.derivs == PDEOPT_DERIVS_FD &&
                      (ctx->prob.dtype == PDEOPT_F32 ? fused_supported<float>(ctx) : fused_supported<double>(ctx));
-  if (fused) {
+  if (fused && ctx->halo == 8) {
+    // halo-8 layout: ONE exchange per substep.  Pair 1+2 runs on the tile + 4 ring (it reads y on tile + 8), so
+    // pair 3+4 finds TB on its tile + 4 input region without an exchange of TB.
+    *nphases = 2;
+    fields[0] = 0;
+    fields[1] = -1;  // no exchange before phase 1
+  } else if (fused) {
     *nphases = 2;
     fields[0] = 0;  // Y  (stage pair 1+2 differentiates y)
     fields[1] = 2;  // TB (stage pair 3+4 differentiates y + dt/2 k2)
@@ -493,10 +499,17 @@ int rk4_phase(pdeopt_ctx* ctx, int phase, double dt, int part) {
   if (phase < 0 || phase >= n) return fail(ctx, PDEOPT_EINVAL, "phase %d outside 0..%d", phase, n - 1);
   ctx->win_lo = 0;
   ctx->win_n = ctx->prob.batch;
+  if (ctx->halo == 8 && n != 2)
+    return fail(ctx, PDEOPT_EINVAL, "the halo-8 layout needs the fused Cahn-Hilliard stage pairs (closure class / tile shape / "
+                                    "PDEOPT_OPT_FUSE_STAGES rule them out here): use halo layout 4");
+  if (ctx->halo == 8 && part != 0)
+    return fail(ctx, PDEOPT_EINVAL, "interior / edge launches belong to the halo-4 layout (two exchanges per substep)");
   if (n == 2) {
     ctx->launch_part = part;
     if (phase == 0) {
+      ctx->pair_ext = ctx->halo == 8 ? 4 : 0;
       rc = launch_pair_dt(ctx, PAIR_12, ctx->Y, nullptr, nullptr, ctx->TB, ctx->ACC, dt / 2, dt / 6, dt / 2, dt / 3);
+      ctx->pair_ext = 0;
     } else {
       rc = launch_pair_dt(ctx, PAIR_34, ctx->TB, ctx->Y, ctx->ACC, ctx->TA, nullptr, dt, dt / 3, 0.0, dt / 6);
       if (part != 1) std::swap(ctx->Y, ctx->TA);
@@ -522,12 +535,34 @@ int rk4_loopback_advance(pdeopt_ctx* ctx, double dt, int64_t n) {
   rk4_phase_plan(ctx, fields, &np_);
   const int nbr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   int rc = PDEOPT_OK;
+  if (ctx->halo == 8) {
+    // one exchange per substep; after the first one the strip comes out of PAIR_34's epilogue (fused pack) and the
+    // loop-back "collective" is the strip buffer itself
+    if (n <= 0) return PDEOPT_OK;
+    if ((rc = halo_pack(ctx, 0, nullptr))) return rc;
+    for (int64_t s = 0; s < n && !rc; ++s) {
+      if ((rc = halo_unpack(ctx, 0, nullptr, nbr))) break;
+      rc = rk4_substep_h8(ctx, dt, s + 1 < n ? ctx->halo_scratch : nullptr);
+    }
+    return rc;
+  }
   for (int64_t s = 0; s < n && !rc; ++s)
     for (int ph = 0; ph < np_ && !rc; ++ph) {
       if ((rc = halo_pack(ctx, fields[ph], nullptr))) break;
       if ((rc = halo_unpack(ctx, fields[ph], nullptr, nbr))) break;
       rc = rk4_phase(ctx, ph, dt, 0);
     }
+  return rc;
+}
+
+// halo-8 layout, the state's halo already unpacked: both stage pairs of one substep; the edge tiles of the second
+// write the NEW state's halo strip into `strip` (nullptr: not wanted)
+int rk4_substep_h8(pdeopt_ctx* ctx, double dt, void* strip) {
+  int rc = rk4_phase(ctx, 0, dt, 0);
+  if (rc) return rc;
+  ctx->pair_strip = strip;
+  rc = rk4_phase(ctx, 1, dt, 0);
+  ctx->pair_strip = nullptr;
   return rc;
 }
 

@@ -74,6 +74,22 @@ struct PairArgs {
   int part;  // which tiles this launch computes: 0 all, 1 interior tiles only, 2 edge tiles only (tiles in the
              // first / last tile row or column: the ones that read halo cells of a decomposed field, so the
              // interior can run while the halo exchange is in flight)
+  // PAIR_34 of a decomposed field (halo-8 layout): the edge tiles also write the cells of the new state within 8
+  // of the tile border into the rank's halo strip -- csrc/halo.hip's layout, [top 8 rows][bottom 8 rows]
+  // [left 8 cols][right 8 cols][TL][TR][BL][BR] per environment -- so no pack launch is needed (nullptr: off)
+  T* strip;
+  int64_t strip_env;  // strip elements per environment
+};
+
+// offsets of the 8 pieces of a halo strip of width H for an nx x ny tile (halo.hip: decode())
+template <int H>
+struct StripOffsets {
+  int64_t top, bottom, left, right, tl, tr, bl, br;
+  __device__ __forceinline__ StripOffsets(int nx, int ny) {
+    const int64_t rows = (int64_t)H * ny, cols = (int64_t)nx * H, cor = H * H;
+    top = 0; bottom = rows; left = 2 * rows; right = 2 * rows + cols;
+    tl = 2 * rows + 2 * cols; tr = tl + cor; bl = tr + cor; br = bl + cor;
+  }
 };
 
 // does this launch skip tile (ti, tj)?  (uniform per workgroup; evaluated before any barrier)
@@ -518,7 +534,26 @@ __global__ __launch_bounds__(NT) PDEOPT_PAIR_WAVES_ATTR void stage_pair_kernel(c
       *reinterpret_cast<Vec*>(a.out + idx) = yown[r] + a.aB * kB[r];
       *reinterpret_cast<Vec*>(a.acc_out + idx) = accp[r] + a.bB * kB[r];
     } else {
-      *reinterpret_cast<Vec*>(a.out + idx) = accp[r] + a.bB * kB[r];
+      const Vec ynew = accp[r] + a.bB * kB[r];
+      *reinterpret_cast<Vec*>(a.out + idx) = ynew;
+      // fused pack (decomposed field): wave-uniform test first, interior tiles skip everything
+      if (a.strip != nullptr && (ti == 0 || ti == tiles_i - 1 || tj == 0 || tj == tiles_j - 1)) {
+        constexpr int H = 8;
+        static_assert(H % V == 0, "a vector never straddles two strip pieces");
+        const StripOffsets<H> so(g.nx, g.ny);
+        T* const st = a.strip + (int64_t)b * a.strip_env;
+        const int gi = i0 + r0 + r, gj = j0 + lx * V;
+        const bool top = gi < H, bot = gi >= g.nx - H, lef = gj < H, rig = gj >= g.ny - H;
+        const int bi = gi - (g.nx - H), rj = gj - (g.ny - H);
+        if (top) *reinterpret_cast<Vec*>(st + so.top + (int64_t)gi * g.ny + gj) = ynew;
+        if (bot) *reinterpret_cast<Vec*>(st + so.bottom + (int64_t)bi * g.ny + gj) = ynew;
+        if (lef) *reinterpret_cast<Vec*>(st + so.left + (int64_t)gi * H + gj) = ynew;
+        if (rig) *reinterpret_cast<Vec*>(st + so.right + (int64_t)gi * H + rj) = ynew;
+        if (top && lef) *reinterpret_cast<Vec*>(st + so.tl + gi * H + gj) = ynew;
+        if (top && rig) *reinterpret_cast<Vec*>(st + so.tr + gi * H + rj) = ynew;
+        if (bot && lef) *reinterpret_cast<Vec*>(st + so.bl + bi * H + gj) = ynew;
+        if (bot && rig) *reinterpret_cast<Vec*>(st + so.br + bi * H + rj) = ynew;
+      }
     }
   }
 }
@@ -538,28 +573,31 @@ template <typename T, int CL, int PAIR, int RPT>
 int launch_pair_ac_inst(pdeopt_ctx* ctx, const PairArgs<T>& s);  // stencil_fused_ac.hpp
 
 template <typename T, int CL, int PAIR, int RPT>
-int launch_pair_ch_inst(pdeopt_ctx* ctx, const PairArgs<T>& s);
+int launch_pair_ch_inst(pdeopt_ctx* ctx, const PairArgs<T>& s, int ext);
 
 template <typename T, int CL, int PAIR, int RPT>
-int launch_pair_inst(pdeopt_ctx* ctx, const PairArgs<T>& s) {
+int launch_pair_inst(pdeopt_ctx* ctx, const PairArgs<T>& s, int ext = 0) {
   if (ctx->prob.equation == PDEOPT_EQ_ALLEN_CAHN) return launch_pair_ac_inst<T, CL, PAIR, RPT>(ctx, s);
-  return launch_pair_ch_inst<T, CL, PAIR, RPT>(ctx, s);
+  return launch_pair_ch_inst<T, CL, PAIR, RPT>(ctx, s, ext);
 }
 
 template <typename T, int CL, int PAIR, int RPT>
-int launch_pair_ch_inst(pdeopt_ctx* ctx, const PairArgs<T>& s) {
+int launch_pair_ch_inst(pdeopt_ctx* ctx, const PairArgs<T>& s, int ext) {
   // CH: 2 rows per thread always; 32-row tiles (RPT == 4 on this dispatch axis) are 512-thread blocks
   constexpr int V = VecOf<T>::V;
   constexpr int NT = RPT == 4 ? 512 : 256;
   constexpr int TX = (NT / kLanesPerRow) * 2;
   const pdeopt_problem& p = ctx->prob;
-  const int tiles_i = (p.nx + TX - 1) / TX;
-  const int tiles_j = (p.ny + kLanesPerRow * V - 1) / (kLanesPerRow * V);
+  // ext > 0 (halo-8 layout, PAIR_12): the launch covers the tile + ext ring in WHOLE workgroup tiles starting at
+  // cell (-ext, -ext) -- the caller shifted the pointers; the last tile row / column over-runs into the layout's
+  // tail margin (common.hpp: pad_rows / pad_ld), nothing is masked
+  const int tiles_i = (p.nx + 2 * ext + TX - 1) / TX;
+  const int tiles_j = (p.ny + 2 * ext + kLanesPerRow * V - 1) / (kLanesPerRow * V);
   const int64_t nblk64 = (int64_t)tiles_i * tiles_j * ctx->win_n;
   if (nblk64 > 0x7fffffffLL) return fail(ctx, PDEOPT_EINVAL, "too many tiles");
   const int nblk = (int)nblk64;
   const size_t lds = fused_lds_bytes<T, TX>();
-  const bool ragged = p.nx % TX != 0 || p.ny % (kLanesPerRow * V) != 0;
+  const bool ragged = ext == 0 && (p.nx % TX != 0 || p.ny % (kLanesPerRow * V) != 0);
   if (ragged)
     hipLaunchKernelGGL((stage_pair_kernel<T, CL, PAIR, 2, true, NT>), dim3(nblk), dim3(NT), lds, ctx->stream, s, tiles_i,
                        tiles_j, nblk, tile_flags(nblk, tiles_i, tiles_j));

@@ -27,6 +27,19 @@ int launch_pair(pdeopt_ctx* ctx, int pair, const void* in, const void* y, const 
   s.mob = ClosureSpec{p.mob.kind, p.mob.flags, p.mob.n};
   s.dbg = (int)ctx->opt_debug_ablate;
   s.part = ctx->launch_part;
+  // halo-8 layout of a decomposed field: PAIR_12 on the tile + 4 ring, PAIR_34 with the fused pack
+  int ext = 0;
+  if (ctx->halo == 8) {
+    if (p.equation != PDEOPT_EQ_CAHN_HILLIARD) return fail(ctx, PDEOPT_EINVAL, "the halo-8 layout runs the fused Cahn-Hilliard stage pairs only");
+    if (pair == PAIR_12) {
+      ext = ctx->pair_ext;
+      const int64_t shift = (int64_t)ext * s.g.ld + ext;
+      s.in -= shift; s.out -= shift; s.acc_out -= shift;
+    } else if (ctx->pair_strip) {
+      s.strip = static_cast<T*>(ctx->pair_strip);
+      s.strip_env = 2LL * 8 * p.ny + 2LL * p.nx * 8 + 4LL * 64;
+    }
+  }
   ctx->n_stage_launches++;
   const int cl = classify_closures(p.mu, p.mob);
   // tile height of the pair kernels.  CH: 32 rows (512-thread workgroups) where they divide the grid --
@@ -41,13 +54,13 @@ int launch_pair(pdeopt_ctx* ctx, int pair, const void* in, const void* y, const 
   if (cl == CL_LOGIT && p.mu.n <= 2 && p.equation == PDEOPT_EQ_CAHN_HILLIARD) {
     // linear polynomial part: the shorter closure (same bits, see closures.hpp)
     if (rpt == 2)
-      return pair == PAIR_12 ? launch_pair_ch_inst<T, CL_LOGIT1, PAIR_12, 2>(ctx, s)
-                             : launch_pair_ch_inst<T, CL_LOGIT1, PAIR_34, 2>(ctx, s);
-    return pair == PAIR_12 ? launch_pair_ch_inst<T, CL_LOGIT1, PAIR_12, 4>(ctx, s)
-                           : launch_pair_ch_inst<T, CL_LOGIT1, PAIR_34, 4>(ctx, s);
+      return pair == PAIR_12 ? launch_pair_ch_inst<T, CL_LOGIT1, PAIR_12, 2>(ctx, s, ext)
+                             : launch_pair_ch_inst<T, CL_LOGIT1, PAIR_34, 2>(ctx, s, 0);
+    return pair == PAIR_12 ? launch_pair_ch_inst<T, CL_LOGIT1, PAIR_12, 4>(ctx, s, ext)
+                           : launch_pair_ch_inst<T, CL_LOGIT1, PAIR_34, 4>(ctx, s, 0);
   }
 #define PDEOPT_PAIR_DISPATCH(CLV, PAIRV)                                             \
-  (rpt == 2 ? launch_pair_inst<T, CLV, PAIRV, 2>(ctx, s) : launch_pair_inst<T, CLV, PAIRV, 4>(ctx, s))
+  (rpt == 2 ? launch_pair_inst<T, CLV, PAIRV, 2>(ctx, s, ext) : launch_pair_inst<T, CLV, PAIRV, 4>(ctx, s, ext))
   if (cl == CL_LOGIT)
     return pair == PAIR_12 ? PDEOPT_PAIR_DISPATCH(CL_LOGIT, PAIR_12) : PDEOPT_PAIR_DISPATCH(CL_LOGIT, PAIR_34);
   return pair == PAIR_12 ? PDEOPT_PAIR_DISPATCH(CL_POLY, PAIR_12) : PDEOPT_PAIR_DISPATCH(CL_POLY, PAIR_34);
@@ -81,7 +94,7 @@ int launch_slope_pair(pdeopt_ctx* ctx, const void* in, void* out) {
   const bool rows32 = ctx->opt_tile_rows == 32 || (ctx->opt_tile_rows == 0 && p.nx % 32 == 0);
   ctx->last_kernel = rows32 ? "slope_pair<CH,rows32>" : "slope_pair<CH,rows16>";
 #define PDEOPT_SLOPE(CLV) \
-  (rows32 ? launch_pair_ch_inst<T, CLV, PAIR_K, 4>(ctx, s) : launch_pair_ch_inst<T, CLV, PAIR_K, 2>(ctx, s))
+  (rows32 ? launch_pair_ch_inst<T, CLV, PAIR_K, 4>(ctx, s, 0) : launch_pair_ch_inst<T, CLV, PAIR_K, 2>(ctx, s, 0))
   if (cl == CL_LOGIT) return p.mu.n <= 2 ? PDEOPT_SLOPE(CL_LOGIT1) : PDEOPT_SLOPE(CL_LOGIT);
   return PDEOPT_SLOPE(CL_POLY);
 #undef PDEOPT_SLOPE

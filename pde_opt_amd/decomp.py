@@ -2,13 +2,20 @@
 Cahn-Hilliard 4096^2 on 2x2 GPUs).  New relative to the reference, which has no multi-device code
 (SURVEY 2.1); semantics = the monolithic periodic solve, bit for bit for the explicit integrators.
 
-Every rank owns an (nx/px) x (ny/py) tile stored with a 4-cell halo.  Per RK4 substep::
+Every rank owns an (nx/px) x (ny/py) tile stored with a halo.  Per RK4 substep::
 
     for phase, field in enumerate(backend.phase_plan()):       # 2 phases (fused pairs) or 4
-        backend.pack(field, send)                              # 8 interior pieces -> one strip
-        comm.all_gather(send, recv)                            # RCCL over xGMI (torch.distributed)
-        backend.unpack(field, recv, grid.neighbours())         # 8 halo pieces from 8 neighbours
+        if field >= 0:                                         # halo 8: only phase 0 exchanges (the state)
+            backend.pack(field, send)                          # 8 interior pieces -> one strip
+            comm.all_gather(send, recv)                        # RCCL over xGMI (torch.distributed)
+            backend.unpack(field, recv, grid.neighbours())     # 8 halo pieces from 8 neighbours
         backend.phase(phase, dt)                               # fused stencil + RK update kernel
+
+Two layouts.  **Halo 8** (default where the fused Cahn-Hilliard stage pairs run): ONE exchange per substep -- the
+first stage pair is evaluated on the tile + 4 ring (it reads the state on tile + 8), so the second pair finds its
+input there, and in the library's own loops the second pair's edge tiles write the new state's strip themselves (no
+pack launch): a substep is unpack + 2 stencil kernels + 1 collective.  **Halo 4**: one exchange per phase (2 per
+substep with fused pairs, 4 with per-stage kernels), the layout of the interior / edge overlap and graph drivers.
 
 The exchange is ONE all-gather of packed strips per phase (edges and corners together), the pattern
 BASELINE.json names; strips are 2*h*(nx+ny)+4*h^2 elements (128 KiB at 2048^2 fp32), far below the
@@ -51,7 +58,7 @@ import numpy as np
 from . import _lib as L
 from .engine import HipEngine
 
-HALO = 4
+HALO = 4  # halo width of the per-phase exchange layout (the oracle tile backend of the CPU tests uses it)
 
 
 class CartesianGrid:
@@ -227,6 +234,59 @@ class NativeComm:
         raise RuntimeError("NativeComm exchanges inside pdeopt_rk4_decomposed_advance")
 
 
+class LocalGroupComm:
+    """One rank of an IN-PROCESS group (``pdeopt_local_group``, csrc/comm.hip): the ranks are engines of this
+    process -- several on one GPU ("virtual ranks": the library's decomposed loop, its neighbour tables and rank
+    offsets run with world > 1 on a single GPU) or one per GPU -- and the all-gather is device-side copies between
+    their strip buffers ordered by HIP events, inside the same ``pdeopt_rk4_decomposed_advance`` loop the RCCL
+    communicator runs.  Every rank's ``DecomposedSolver.advance`` must be called at the same time from its own
+    host thread: ``advance_group(solvers, dt, n)`` does that."""
+
+    def __init__(self, group, rank: int):
+        self.group, self.world, self.rank = group, group.world, int(rank)
+        self._attached = False
+
+    @staticmethod
+    def create(world: int):
+        """[LocalGroupComm(rank) for rank in range(world)] sharing one group"""
+        from .engine import LocalGroup
+
+        g = LocalGroup(world)
+        return [LocalGroupComm(g, r) for r in range(world)]
+
+    def make_buffers(self, backend):
+        if not self._attached:
+            backend.engine.comm_init_local(self.group, self.rank)
+            self._attached = True
+        return None, None  # the strip buffers live in the library
+
+    def all_gather(self, send, recv):
+        raise RuntimeError("LocalGroupComm exchanges inside pdeopt_rk4_decomposed_advance")
+
+
+def advance_group(solvers, dt: float, n_substeps: int):
+    """``advance`` on every rank of an in-process group at the same time, one host thread per rank (the ranks
+    rendezvous once per halo exchange inside the library); the first failure is re-raised after all have returned"""
+    import threading
+
+    errors = [None] * len(solvers)
+
+    def run(i):
+        try:
+            solvers[i].advance(dt, n_substeps)
+        except BaseException as e:  # noqa: BLE001
+            errors[i] = e
+
+    threads = [threading.Thread(target=run, args=(i,), name=f"pdeopt-rank{i}") for i in range(len(solvers))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for e in errors:
+        if e is not None:
+            raise e
+
+
 # ---------------------------------------------------------------------------------- HIP backend
 class HipTileBackend:
     """One rank's tile on the GPU (padded layout of libpdeopt_hip.so)."""
@@ -234,15 +294,26 @@ class HipTileBackend:
     on_device = True
 
     def __init__(self, equation, tile_shape, dtype=np.float32, device: int = 0, stream: Optional[int] = None,
-                 engine: Optional[HipEngine] = None):
+                 engine: Optional[HipEngine] = None, halo: Optional[int] = None):
+        """``halo``: 8 (one exchange per substep; fused Cahn-Hilliard stage pairs), 4 (one per phase), or None =
+        8 where the library runs the fused pairs on this problem, else 4"""
         self.engine = engine or HipEngine(device, stream=stream)
         self.device = device
         self.dtype = np.dtype(dtype)
         prob = dict(equation._engine_problem())
         prob["nx"], prob["ny"] = tile_shape  # same spacing, local extent
-        self.engine.set_halo_layout(HALO)
-        self.engine.configure(dtype=dtype, batch=1, **prob)
-        self.engine.set_halo_layout(0)  # the option only applies to the configure above
+        if halo not in (None, 4, 8):
+            raise ValueError(f"halo must be 4 or 8, got {halo}")
+        for h in ((8, 4) if halo is None else (halo,)):
+            self.engine.set_halo_layout(h)
+            self.engine.configure(dtype=dtype, batch=1, **prob)
+            self.engine.set_halo_layout(0)  # the option only applies to the configure above
+            self.halo = h
+            if h != 8 or self.engine.rk4_phase_plan() == [0, -1]:
+                break
+            if halo == 8:
+                raise ValueError("halo=8 needs the fused Cahn-Hilliard stage pairs (closure class, tile shape and "
+                                 "PDEOPT_OPT_FUSE_STAGES decide); this problem runs one kernel per stage: use halo=4")
         self.strip_elems = self.engine.halo_strip_elems()
 
     def phase_plan(self) -> List[int]:
@@ -276,7 +347,7 @@ class DecomposedSolver:
     """RK4 on one rank's tile of a decomposed periodic field."""
 
     def __init__(self, equation, grid: CartesianGrid, comm=None, dtype=np.float32, device: int = 0,
-                 backend=None, stream: Optional[int] = None):
+                 backend=None, stream: Optional[int] = None, halo: Optional[int] = None):
         self.equation = equation
         self.grid = grid
         self.comm = comm or LoopbackComm()
@@ -284,11 +355,11 @@ class DecomposedSolver:
             raise ValueError(f"communicator has {self.comm.world} ranks, process grid {grid.world}")
         nx, ny = equation.domain.points
         self.tile_shape = grid.tile_shape(nx, ny)
-        if min(self.tile_shape) < 2 * HALO:
-            raise ValueError("tiles must be at least 8 cells wide")
+        if min(self.tile_shape) < 16:
+            raise ValueError("tiles must be at least 16 cells wide")
         if stream is None:
             stream = getattr(self.comm, "stream_handle", None)
-        self.backend = backend or HipTileBackend(equation, self.tile_shape, dtype, device, stream)
+        self.backend = backend or HipTileBackend(equation, self.tile_shape, dtype, device, stream, halo=halo)
         self.send, self.recv = self.comm.make_buffers(self.backend)
         self.neighbours = grid.neighbours()
         self.exchanges = 0
@@ -308,6 +379,8 @@ class DecomposedSolver:
         self.backend.set_state(np.asarray(u_global)[si, sj])
 
     def exchange(self, field: int):
+        if field < 0:  # halo-8 layout: this phase finds its input's ring computed by the previous one
+            return
         self.backend.pack(field, self.send)
         self.comm.all_gather(self.send, self.recv)
         self.backend.unpack(field, self.recv, self.neighbours)
@@ -327,15 +400,21 @@ class DecomposedSolver:
         n = int(n_substeps)
         plan = self.backend.phase_plan()
         be, c = self.backend, self.comm
-        if isinstance(c, NativeComm):
-            self.mode = "native+overlap" if (self.use_overlap and len(plan) == 2) else "native"  # default: native
+        nex = sum(1 for f in plan if f >= 0)  # exchanges per substep
+        if (self.use_overlap or self.use_graph) and getattr(be, "halo", HALO) == 8:
+            raise ValueError("the interior / edge overlap and the graph replay belong to the halo-4 layout "
+                             "(DecomposedSolver(..., halo=4)); halo 8 exchanges once per substep")
+        if isinstance(c, (NativeComm, LocalGroupComm)):
+            self.mode = "native" if isinstance(c, NativeComm) else "local-group"
+            if self.use_overlap and len(plan) == 2 and isinstance(c, NativeComm):
+                self.mode = "native+overlap"
             be.engine.rk4_decomposed_advance(dt, n, self.neighbours, overlap=self.use_overlap)
-            self.exchanges += n * len(plan)
+            self.exchanges += n * nex
             return
         if isinstance(c, LoopbackComm) and hasattr(be, "loopback_advance"):
             self.mode = "loopback"
             be.loopback_advance(dt, n)  # the whole loop inside the library
-            self.exchanges += n * len(plan)
+            self.exchanges += n * nex
             return
         overlap = self.use_overlap and getattr(c, "can_overlap", False) and getattr(be, "on_device", False) and len(plan) == 2
         if not overlap:
@@ -366,7 +445,7 @@ class DecomposedSolver:
             self.mode = "overlap"
         for _ in range(n - done):
             self._substep_overlapped(plan, dt)
-        self.exchanges += n * len(plan)
+        self.exchanges += n * nex
 
     def local_state(self):
         return self.backend.get_state()

@@ -132,7 +132,15 @@ class HipEngine:
         old = self.problem
         if old is None or (old.equation, old.dtype, old.nx, old.ny, old.nz, old.batch) != (p.equation, p.dtype, p.nx, p.ny, p.nz, p.batch):
             self._aux_keys.clear()  # a new shape frees the library's auxiliary fields
-        self._check(self._lib.pdeopt_configure(self._h, C.byref(p)))
+        try:
+            self._check(self._lib.pdeopt_configure(self._h, C.byref(p)))
+        except Exception:
+            # a refused configure leaves the ctx unconfigured: the NEXT configure frees every auxiliary field in
+            # the library, whatever its shape -- forget what was uploaded so that it is transferred again
+            self._aux_keys.clear()
+            self._aux_thunks.clear()
+            self.problem = None
+            raise
         self.problem = p
         self.dtype = L.np_dtype(p.dtype)
         self.batch = int(batch)
@@ -413,7 +421,8 @@ class HipEngine:
 
     # -- domain decomposition (padded layout) ---------------------------------------------------
     def set_halo_layout(self, halo: int):
-        """0 = periodic field, 4 = rank-local tile padded by a 4-cell halo (takes effect at the next configure)"""
+        """0 = periodic field, 4 / 8 = rank-local tile padded by a 4- / 8-cell halo (takes effect at the next
+        configure); 8: one halo exchange per RK4 substep instead of two (fused Cahn-Hilliard stage pairs)"""
         self._check(self._lib.pdeopt_set_option(self._h, L.OPT_HALO_LAYOUT, int(halo)))
         self._aux_keys.clear()  # a layout change re-allocates on the next configure
 
@@ -458,6 +467,13 @@ class HipEngine:
             raise ValueError("the RCCL unique id is 128 bytes")
         self._check(self._lib.pdeopt_comm_init(self._h, int(world), int(rank), unique_id))
 
+    def comm_init_local(self, group: "LocalGroup", rank: int):
+        """join an in-process group of ranks (several engines of this process, on one GPU or one per GPU) instead of
+        an RCCL communicator: ``rk4_decomposed_advance`` then exchanges by device-side copies; every rank's thread
+        must call it concurrently"""
+        self._check(self._lib.pdeopt_comm_init_local(self._h, group._h, int(rank)))
+        self._group = group  # the group outlives its members
+
     def comm_destroy(self):
         self._check(self._lib.pdeopt_comm_destroy(self._h))
 
@@ -498,6 +514,24 @@ class HipEngine:
         ms = C.c_double()
         self._check(self._lib.pdeopt_timer_stop(self._h, C.byref(ms)))
         return ms.value
+
+
+class LocalGroup:
+    """``pdeopt_local_group``: an in-process group of ``world`` ranks for the decomposed driver (virtual ranks on one
+    GPU, or one engine per GPU with a host thread each).  Keep it alive as long as any member engine."""
+
+    def __init__(self, world: int):
+        self._lib = L.load_library()
+        h = C.c_void_p()
+        rc = self._lib.pdeopt_local_group_create(int(world), C.byref(h))
+        if rc != L.OK:
+            raise L.PdeoptError(rc, self._lib.pdeopt_last_error(None).decode())
+        self._h, self.world = h, int(world)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.pdeopt_local_group_destroy(self._h)
+            self._h = None
 
 
 _default_engines: dict = {}

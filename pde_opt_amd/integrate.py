@@ -203,16 +203,16 @@ def _solve_adaptive(eng, equation, solver, t0, t1, dt0, saveat, c: PIDController
     if solver.integrator != L.INT_TSIT5:
         raise ValueError("PIDController needs an embedded pair: use Tsit5")
     if c.per_environment and eng.batch > 1:
-        return _solve_adaptive_per_env(eng, t0, t1, dt0, saveat, c, max_steps, throw, take)
+        return _solve_adaptive_per_env(eng, t0, t1, dt0, saveat, c, max_steps, throw, take, equation)
     t, dt = t0, dt0
     accepted = rejected = 0
     ts_req = [float(v) for v in saveat.ts] if saveat.ts is not None else []
     ts_out, ys_out = [], []
     qi = 0
+    if saveat.t0:  # diffrax order: t0, then ts, then t1 (the constant-step driver and the per-environment one agree)
+        ts_out.append(t0); ys_out.append(take(eng.get_state()))
     while qi < len(ts_req) and ts_req[qi] <= t0:
         ts_out.append(ts_req[qi]); ys_out.append(take(eng.get_state())); qi += 1
-    if saveat.t0:
-        ts_out.append(t0); ys_out.append(take(eng.get_state()))
     prev_inv = prev_prev_inv = 1.0
     while t < t1:
         if max_steps is not None and accepted + rejected >= max_steps:
@@ -245,12 +245,17 @@ def _solve_adaptive(eng, equation, solver, t0, t1, dt0, saveat, c: PIDController
     return Solution(np.asarray(ts_out), np.stack(ys_out), stats)
 
 
-def _solve_adaptive_per_env(eng, t0, t1, dt0, saveat, c: PIDController, max_steps, throw, take):
+def _solve_adaptive_per_env(eng, t0, t1, dt0, saveat, c: PIDController, max_steps, throw, take, equation=None):
     """``PIDController(per_environment=True)``: every environment of the batch runs its own controller -- own
     time, own step size, own accept / reject -- exactly as if it were solved alone, while the stages of all
     environments still execute as one batched launch (``pdeopt_tsit5_trial_env``: slopes scaled by
     dt_b / dt_ref).  Environments that have reached ``t1`` idle with dt = 0."""
     B = eng.batch
+    if equation is not None and equation._time_dependent_rhs(t0, t1):
+        # environments sit at different times, the stage launch carries one: refuse before the first trial step
+        # (the library refuses too -- pdeopt_tsit5_trial_env -- but only from inside the loop)
+        raise ValueError("PIDController(per_environment=True) needs an autonomous right-hand side: "
+                         f"{type(equation).__name__} has time-dependent terms")
     t = np.full(B, t0)
     dt = np.full(B, dt0)
     prev_inv, prev_prev_inv = np.ones(B), np.ones(B)
@@ -286,14 +291,14 @@ def _solve_adaptive_per_env(eng, t0, t1, dt0, saveat, c: PIDController, max_step
             dt[b] = _clip_dt(c, h[b] * f)
         eng.tsit5_commit_env(keep)
     y_end = eng.get_state()
-    for b in range(B):  # save points never reached (max_steps with throw=False): the last state, like diffrax's inf padding would not
+    for b in range(B):  # save points never reached (max_steps with throw=False) are NaN-filled, never a stale state
         for q in range(len(ts_req)):
             if slots[b][q] is None:
                 slots[b][q] = np.full_like(y_end[b], np.nan)
     ts_out = list(ts_req)
     ys = [np.stack([slots[b][q] for b in range(B)]) for q in range(len(ts_req))]
-    if saveat.t0:
-        ts_out.insert(n_t0, t0); ys.insert(n_t0, y_start)
+    if saveat.t0:  # t0 first, as in the shared-step and constant-step drivers
+        ts_out.insert(0, t0); ys.insert(0, y_start)
     if saveat.t1 or saveat.ts is None:
         ts_out.append(float(t.max())); ys.append(y_end)
     stats = {"num_steps": int((accepted + rejected).max()), "num_accepted_steps": accepted.tolist(),

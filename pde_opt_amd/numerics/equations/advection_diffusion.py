@@ -65,6 +65,9 @@ class AdvectionDiffusion2D(BaseEquation):
             return bool(self.time_dependent) and t_end is not None
         return depends_on_time(lambda tt: np.stack(self.face_velocities(tt)), t, t_end)
 
+    def _time_dependent_rhs(self, t0: float = 0.0, t1=None) -> bool:
+        return self._velocity_varies(t0, t1)
+
     @staticmethod
     def _upload_faces(engine, face_fn, varies, t, per_env):
         """face_fn(t) -> (vx, vy); one evaluation serves both fields of a stage time"""

@@ -34,6 +34,10 @@ class BaseEquation(ABC):
         """``_engine_upload`` for a batch whose environment b is described by ``eqs[b]``"""
         eqs[0]._engine_upload(engine, t, t_end)
 
+    def _time_dependent_rhs(self, t0: float = 0.0, t1=None) -> bool:
+        """does F(state, t) depend on t over [t0, t1]?  (per-environment adaptive stepping needs an autonomous F)"""
+        return False
+
     _state_trailing = ()  # trailing state axes after (nx, ny); the GPE has (2,)
 
     def _run_rhs(self, state, t):

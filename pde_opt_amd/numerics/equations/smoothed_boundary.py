@@ -78,6 +78,9 @@ class _SmoothedBoundary(BaseEquation):
         engine.set_aux(L.AUX_SBM_MASK, self.left_half)
         engine.set_time_terms(self._time_terms)
 
+    def _time_dependent_rhs(self, t0: float = 0.0, t1=None) -> bool:
+        return True  # theta(t) / flux(t) are evaluated at every stage time
+
     def rhs_fd(self, state, t):
         return self._run_rhs(state, t)
 
@@ -95,6 +98,8 @@ class AllenCahn2DSmoothedBoundary(_SmoothedBoundary):
     derivs: str = "fd"
 
     _equation_code = L.EQ_ALLEN_CAHN_SBM
+    # the kernels read kappa and the closure coefficients from the per-environment table (theta is shared)
+    _per_env_controls = frozenset({"kappa", "mu", "R"})
 
     def __post_init__(self):
         self._init_geometry("AllenCahn2DSmoothedBoundary")
@@ -119,6 +124,7 @@ class CahnHilliard2DSmoothedBoundary(_SmoothedBoundary):
     derivs: str = "fd"
 
     _equation_code = L.EQ_CAHN_HILLIARD_SBM
+    _per_env_controls = frozenset({"kappa", "mu", "D"})
 
     def __post_init__(self):
         self._init_geometry("CahnHilliard2DSmoothedBoundary")

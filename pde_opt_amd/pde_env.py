@@ -27,6 +27,7 @@ from .integrate import diffeqsolve
 from .numerics import domains
 from .numerics.equations import BaseEquation
 from .numerics.solvers import SaveAt
+from .sharding import shard_envs
 from .spaces import HAVE_GYMNASIUM, Box, Discrete, EnvBase
 from .utils import check_equation_solver_compatibility, prepare_solver_params
 
@@ -168,8 +169,96 @@ class PDEEnv(EnvBase):
         self._engine.close()
 
 
+class _EnvShard:
+    """Environments [lo, hi) of a VectorPDEEnv on ONE engine (one GPU, one HIP stream).  ``step`` runs on the
+    shard's own host thread: the ~10^2..10^3 asynchronous kernel launches of an environment step are issued per
+    device in parallel (ctypes releases the GIL inside the library) and the devices compute concurrently; nothing
+    is exchanged between shards -- environments are independent units."""
+
+    def __init__(self, env: "VectorPDEEnv", engine, lo: int, hi: int):
+        self.env, self.engine, self.lo, self.hi = env, engine, lo, hi
+        self.n = hi - lo
+        self._configured_key = None
+        self._obs_buffer = None
+        self._y0 = None
+        self.state_host = None
+
+    def reset(self, y0):
+        self._y0 = y0
+        self.state_host = y0
+        self._configured_key = None
+
+    def _configure(self, eqs):
+        eng = self.engine
+        eq0 = eqs[0]
+        prob = eq0._engine_problem()
+        y0 = self._y0 if self._y0.dtype in (np.float32, np.float64) else self._y0.astype(np.float64)
+        key = (prob["equation"], y0.dtype.str, prob["nx"], prob["ny"],
+               getattr(prob.get("mu"), "kind", None), getattr(prob.get("mu"), "flags", None),
+               len(getattr(prob.get("mu"), "coef", ())), getattr(prob.get("mob"), "kind", None),
+               getattr(prob.get("mob"), "flags", None), len(getattr(prob.get("mob"), "coef", ())))
+        if key != self._configured_key:
+            eng.configure(dtype=y0.dtype, batch=self.n, **prob)
+            eng.set_state(y0)
+            self._configured_key = key
+        # per-environment parameter values
+        kappa = [e._engine_problem().get("kappa", 0.0) for e in eqs]
+        mu = [e._engine_problem()["mu"].coef for e in eqs] if prob.get("mu") is not None else None
+        mob = [e._engine_problem()["mob"].coef for e in eqs] if prob.get("mob") is not None else None
+        eng.set_env_params(0, kappa=kappa, mu_coef=mu, mob_coef=mob)
+        return eq0
+
+    def step(self, eqs):
+        """one environment step of this shard's environments: returns (obs, rewards)"""
+        from .integrate import constant_step_plan
+
+        env, eng = self.env, self.engine
+        eq0 = self._configure(eqs)
+        type(eq0)._engine_upload_batch(eng, eqs, 0.0, env.step_dt)
+        solver = env.solver_type(**prepare_solver_params(env.solver_type, env.solver_parameters, eq0))
+        solver.configure_engine(eng, eq0)
+        if solver.integrator == L.INT_IMEX:
+            eng.set_env_imex_scale(0, env._imex_scales(eqs))
+        n_full, rem = constant_step_plan(0.0, env.step_dt, env.numeric_dt)
+        if n_full:
+            eng.advance(solver.integrator, env.numeric_dt, n_full, 0.0)
+        if rem > 0:
+            eng.advance(solver.integrator, rem, 1, n_full * env.numeric_dt)
+        rewards = None
+        if isinstance(env.device_reward, tuple):
+            # ("vortices", amp_thresh, tol): rl_utils.detect_vortices' num_vortices per environment, counted on the
+            # device (pde_opt/rl_utils.py:19-84): 24 bytes per environment cross PCIe instead of the wavefunction
+            amp, tol = (tuple(env.device_reward[1:]) + (0.0, 0.5))[:2]
+            counts, _ = eng.detect_vortices(amp_thresh=float(amp), tol=float(tol), want_winding=False)
+            rewards = counts[:, 0].astype(np.float64)
+        elif env.device_reward is not None:
+            rewards = eng.reduce(env._RED[env.device_reward])
+        fetched = False
+        if env.device_observation is not None:
+            if isinstance(env.device_observation[0], str):
+                obs = eng.probe(env.device_observation[1])  # (n, n_cells): point sensors
+            else:
+                lo, hi = env.device_observation
+                if env.observations_on_device:
+                    obs = eng.observe_u8_device(lo, hi).torch()[:, None]  # (n, 1, nx, ny) uint8 tensor on this GPU
+                else:
+                    if env.reuse_observation_buffer and self._obs_buffer is None and hasattr(eng, "pinned_empty"):
+                        self._obs_buffer = eng.pinned_empty((self.n,) + tuple(env.domain.points), np.uint8)
+                    obs = eng.observe_u8(lo, hi, out=self._obs_buffer)[:, None]  # (n, 1, nx, ny), the declared space
+        elif env.fetch_observations or env.device_reward is None:
+            self.state_host, fetched = eng.get_state(), True
+            obs = np.stack([env.state_to_observation_func(s_) for s_ in self.state_host])
+        else:
+            obs = None
+        if env.device_reward is None:
+            if not fetched:  # a host reward function sees the full field, as upstream (pde_env.py:309)
+                self.state_host = eng.get_state()
+            rewards = np.asarray([env.reward_function(s_) for s_ in self.state_host])
+        return obs, rewards
+
+
 class VectorPDEEnv:
-    """B independent PDEEnv episodes advanced in lock step on one GPU (new capability).
+    """B independent PDEEnv episodes advanced in lock step on one GPU -- or sharded over several (new capability).
 
     Semantics per environment are exactly ``PDEEnv``'s.  ``step(actions)`` takes one action per
     environment and every environment integrates with ITS control parameter: numbers and closure
@@ -182,16 +271,26 @@ class VectorPDEEnv:
     ``_per_env_controls`` of the equation class) raises ``ValueError`` as soon as two environments disagree on
     it -- never a silently shared value.
 
+    ``devices=[0, 1, ...]`` (BASELINE.json north_star: "batched episodes shard naturally across the 8 GPUs of one
+    node"): the environments are split into contiguous, balanced blocks (``sharding.shard_envs``), one
+    ``HipEngine`` and one host thread per device; ``step`` launches every device's share, the devices compute
+    concurrently, and the per-environment results are concatenated in environment order.  There is no collective
+    and no data exchanged between devices; results per environment do not depend on the number of
+    devices (bitwise for the explicit integrators).  ``engines=[...]`` injects caller-owned engines instead (several
+    engines may share one GPU; the CPU test-suite passes its oracle-backed doubles).  One process per GPU with
+    ``torch.distributed`` is the other way to scale (``bench.py --gpus N``, ``sharding.gather_per_env``).
+
     ``reward`` / observations: ``reward_function`` and ``state_to_observation_func`` are applied
     per environment on host copies unless ``device_reward`` names an on-device reduction
     (``"var"``, ``"mean"``, ``"min"``, ``"max"``, or ``("vortices", amp_thresh, tol)`` = the number of quantised
     vortices of a GPE state, ``rl_utils.detect_vortices`` on the device), which avoids the D2H of full fields;
-    ``device_observation=(lo, hi)`` additionally forms the uint8 image observations of the declared
+    ``device_observation=(lo, hi)`` forms the uint8 image observations of the declared
     observation space on the GPU (1 byte per cell crosses PCIe instead of 4 or 8);
     ``device_observation=("probes", cells)`` returns the state at the listed grid cells instead (sensor-style
     observations: ``(B, n_cells)`` float64, a few numbers per environment).  ``observations_on_device=True``
     leaves the uint8 frames on the GPU and returns them as a zero-copy ``torch.uint8`` CUDA tensor
-    ``(B, 1, nx, ny)`` for a policy on the same device (no PCIe at all; the tensor is overwritten by the next step).
+    ``(B, 1, nx, ny)`` for a policy on the same device (no PCIe at all; the tensor is overwritten by the next
+    step) -- with several devices a list of such tensors, one per device, in environment order.
     """
 
     def __init__(
@@ -220,15 +319,22 @@ class VectorPDEEnv:
         engine=None,
         reuse_observation_buffer: bool = False,
         observations_on_device: bool = False,
+        devices: Optional[Sequence[int]] = None,
+        engines: Optional[Sequence] = None,
     ):
         self.num_envs = int(num_envs)
         self.observations_on_device = bool(observations_on_device)
         if self.observations_on_device and (device_observation is None or isinstance(device_observation[0], str)):
             raise ValueError("observations_on_device needs device_observation=(lo, hi)")
-        # True: device-formed uint8 frames land in ONE page-locked host array that every step overwrites and
-        # returns (copy what you keep) -- no 32 MiB allocation + page faults + pageable D2H per step
+        if device_observation is not None and isinstance(device_observation[0], str) and device_observation[0] != "probes":
+            raise ValueError(f"unknown device observation {device_observation[0]!r}")
+        if isinstance(device_reward, tuple) and device_reward[0] != "vortices":
+            raise ValueError(f"unknown device reward {device_reward[0]!r}")
+        if isinstance(device_reward, str) and device_reward not in self._RED:
+            raise ValueError(f"unknown device reward {device_reward!r} (one of {sorted(self._RED)} or (\"vortices\", amp, tol))")
+        # True: device-formed uint8 frames land in ONE page-locked host array per device that every step overwrites
+        # and returns (copy what you keep) -- no 32 MiB allocation + page faults + pageable D2H per step
         self.reuse_observation_buffer = bool(reuse_observation_buffer)
-        self._obs_buffer = None
         self.equation_type, self.domain, self.solver_type = equation_type, domain, solver_type
         check_equation_solver_compatibility(solver_type, equation_type)
         self.end_time, self.step_dt, self.numeric_dt = end_time, step_dt, numeric_dt
@@ -252,17 +358,68 @@ class VectorPDEEnv:
         else:
             self.single_action_space = Box(low=cfg.get("low", -1.0), high=cfg.get("high", 1.0), shape=cfg.get("shape", (2,)))
             self._action_to_direction = None
-        self._engine = engine if engine is not None else HipEngine(device)
-        self._configured_key = None
+        # ---- engines: one per device (raises HipUnavailableError without a GPU / the library)
+        if engines is not None and (engine is not None or devices is not None):
+            raise ValueError("pass engines=[...] or engine= / devices=, not both")
+        if engines is None:
+            if engine is not None:
+                if devices is not None:
+                    raise ValueError("pass engine= (one caller-owned engine) or devices=[...], not both")
+                engines = [engine]
+            else:
+                devs = [int(device)] if devices is None else [int(d) for d in devices]
+                if not devs:
+                    raise ValueError("devices is empty")
+                if len(set(devs)) != len(devs):
+                    raise ValueError(f"devices lists a GPU twice: {devs} (several engines on one GPU: engines=[...])")
+                engines = [HipEngine(d) for d in devs]
+        engines = list(engines)
+        if not 1 <= len(engines) <= self.num_envs:
+            raise ValueError(f"{len(engines)} engines for {self.num_envs} environments")
+        self._shards = []
+        for r, eng in enumerate(engines):
+            lo, hi = shard_envs(self.num_envs, len(engines), r)
+            self._shards.append(_EnvShard(self, eng, lo, hi))
+        self._engine = engines[0]  # the single-device handle existing callers know
+        # one DEDICATED host thread per device (a single-worker executor each): a device's launches always come
+        # from the same thread, whose HIP "current device" therefore never changes
+        self._pool = None
+        if len(self._shards) > 1:
+            from concurrent.futures import ThreadPoolExecutor
+
+            self._pool = [ThreadPoolExecutor(max_workers=1, thread_name_prefix=f"pdeopt-dev{r}") for r in range(len(self._shards))]
         self._time = np.zeros(self.num_envs)
         self._control_value = [reset_control_value] * self.num_envs
-        self._state_host = None
 
     _RED = {"mean": L.RED_MEAN, "var": L.RED_VAR, "min": L.RED_MIN, "max": L.RED_MAX}
+
+    @property
+    def num_devices(self) -> int:
+        return len(self._shards)
+
+    @property
+    def shard_bounds(self):
+        """[(lo, hi)] environment ranges, one per device"""
+        return [(s.lo, s.hi) for s in self._shards]
 
     def _equation_for(self, control_parameter):
         params = {**self.static_equation_parameters, self.control_equation_parameter_name: control_parameter}
         return self.equation_type(domain=self.domain, **params)
+
+    def _map_shards(self, fn):
+        """fn(shard) on every shard, each on its own host thread; results in shard order (exceptions re-raised)"""
+        if self._pool is None:
+            return [fn(self._shards[0])]
+        futs = [ex.submit(fn, s_) for ex, s_ in zip(self._pool, self._shards)]
+        results, first_error = [], None
+        for f in futs:  # wait for EVERY device before raising: no shard is left running behind an exception
+            try:
+                results.append(f.result())
+            except BaseException as e:  # noqa: BLE001
+                first_error = first_error or e
+        if first_error is not None:
+            raise first_error
+        return results
 
     def reset(self, seed: Optional[int] = None, options=None):
         states = []
@@ -272,35 +429,10 @@ class VectorPDEEnv:
         self._y0 = np.stack(states)
         self._time[:] = 0.0
         self._control_value = [self.reset_control_value] * self.num_envs
-        self._configured_key = None
-        self._state_host = self._y0
+        for sh in self._shards:
+            sh.reset(self._y0[sh.lo:sh.hi])
         obs = [self.state_to_observation_func(s) for s in self._y0]
         return np.stack(obs), {}
-
-    def _configure(self, eqs):
-        eq0 = eqs[0]
-        prob = eq0._engine_problem()
-        y0 = self._y0 if self._y0.dtype in (np.float32, np.float64) else self._y0.astype(np.float64)
-        key = (prob["equation"], y0.dtype.str, prob["nx"], prob["ny"],
-               getattr(prob.get("mu"), "kind", None), getattr(prob.get("mu"), "flags", None),
-               len(getattr(prob.get("mu"), "coef", ())), getattr(prob.get("mob"), "kind", None),
-               getattr(prob.get("mob"), "flags", None), len(getattr(prob.get("mob"), "coef", ())))
-        if key != self._configured_key:
-            self._engine.configure(dtype=y0.dtype, batch=self.num_envs, **prob)
-            self._engine.set_state(y0)
-            self._configured_key = key
-        # per-environment parameter values
-        kappa = [e._engine_problem().get("kappa", 0.0) for e in eqs]
-        mu = [e._engine_problem()["mu"].coef for e in eqs] if prob.get("mu") is not None else None
-        mob = [e._engine_problem()["mob"].coef for e in eqs] if prob.get("mob") is not None else None
-        for e in eqs[1:]:
-            p = e._engine_problem()
-            for name in ("mu", "mob"):
-                a, b = prob.get(name), p.get(name)
-                if (a is None) != (b is None) or (a is not None and (a.kind, a.flags, len(a.coef)) != (b.kind, b.flags, len(b.coef))):
-                    raise ValueError("all environments of a VectorPDEEnv must share the closure structure")
-        self._engine.set_env_params(0, kappa=kappa, mu_coef=mu, mob_coef=mob)
-        return eq0
 
     @staticmethod
     def _same(a, b) -> bool:
@@ -313,8 +445,17 @@ class VectorPDEEnv:
         except Exception:
             return False
 
-    def _check_controls(self, eq0, controls):
-        """environments may only disagree on parameters the batched kernels carry per environment"""
+    def _check_controls(self, eqs, controls):
+        """environments may only disagree on parameters the batched kernels carry per environment -- checked over
+        the WHOLE job, so what is accepted does not depend on how many devices the environments are spread over"""
+        eq0 = eqs[0]
+        prob = eq0._engine_problem()
+        for e in eqs[1:]:
+            p = e._engine_problem()
+            for name in ("mu", "mob"):
+                a, b = prob.get(name), p.get(name)
+                if (a is None) != (b is None) or (a is not None and (a.kind, a.flags, len(a.coef)) != (b.kind, b.flags, len(b.coef))):
+                    raise ValueError("all environments of a VectorPDEEnv must share the closure structure")
         if all(self._same(c, controls[0]) for c in controls[1:]):
             return
         name = self.control_equation_parameter_name
@@ -323,9 +464,26 @@ class VectorPDEEnv:
                 f"{type(eq0).__name__}: the control parameter {name!r} cannot differ between the environments "
                 f"of one VectorPDEEnv (per-environment controls: {sorted(type(eq0)._per_env_controls)})")
 
-    def step(self, actions: Sequence):
-        from .integrate import constant_step_plan
+    def _imex_scales(self, eqs):
+        """sigma_b of ``pdeopt_set_env_imex_scale`` for the environments ``eqs`` of one engine: fourier_symbol =
+        kappa (2 pi i k)^4 (cahn_hilliard.py:74), so with ``kappa`` as the per-environment control every environment
+        has its own implicit operator = kappa_b / kappa_0 x the engine's first environment's.  Only then: another
+        control leaves the operator shared, and a ``fourier_symbol`` passed in ``solver_parameters`` is the caller's,
+        not kappa's."""
+        ones = [1.0] * len(eqs)
+        if self.control_equation_parameter_name != "kappa" or "fourier_symbol" in (self.solver_parameters or {}):
+            return ones
+        kappas = [float(e.kappa) for e in eqs]
+        if all(k == kappas[0] for k in kappas):
+            return ones
+        if any(not k > 0.0 for k in kappas):
+            raise ValueError(f"per-environment kappa under the IMEX solver must be positive, got {kappas}")
+        if len(self.domain.points) != 2:
+            raise ValueError("per-environment kappa under the IMEX solver needs the fused 2-D FFT passes "
+                             f"({type(eqs[0]).__name__} shares one implicit operator across the batch)")
+        return [k / kappas[0] for k in kappas]
 
+    def step(self, actions: Sequence):
         if len(actions) != self.num_envs:
             raise ValueError(f"{len(actions)} actions for {self.num_envs} environments")
         eqs, controls = [], []
@@ -335,59 +493,35 @@ class VectorPDEEnv:
             self._control_value[b] = self.update_control_value(offset, old)
             controls.append(self.update_control_parameter(old, self._control_value[b]))
             eqs.append(self._equation_for(controls[-1]))
-        self._check_controls(eqs[0], controls)
-        eq0 = self._configure(eqs)
-        type(eq0)._engine_upload_batch(self._engine, eqs, 0.0, self.step_dt)
-        solver = self.solver_type(**prepare_solver_params(self.solver_type, self.solver_parameters, eq0))
-        solver.configure_engine(self._engine, eq0)
-        if solver.integrator == L.INT_IMEX:
-            # fourier_symbol = kappa (2 pi i k)^4 (cahn_hilliard.py:74): with kappa as the per-environment control
-            # every environment has its own implicit operator = sigma_b x environment 0's
-            k0 = float(getattr(eq0, "kappa", 1.0))
-            self._engine.set_env_imex_scale(0, [float(getattr(e, "kappa", k0)) / k0 for e in eqs])
-        n_full, rem = constant_step_plan(0.0, self.step_dt, self.numeric_dt)
-        if n_full:
-            self._engine.advance(solver.integrator, self.numeric_dt, n_full, 0.0)
-        if rem > 0:
-            self._engine.advance(solver.integrator, rem, 1, n_full * self.numeric_dt)
+        self._check_controls(eqs, controls)
+        # every device's share on its own host thread; no collective, nothing exchanged
+        results = self._map_shards(lambda sh: sh.step(eqs[sh.lo:sh.hi]))
         self._time += self.step_dt
-        if isinstance(self.device_reward, tuple):
-            # ("vortices", amp_thresh, tol): rl_utils.detect_vortices' num_vortices per environment, counted on the
-            # device (pde_opt/rl_utils.py:19-84): 24 bytes per environment cross PCIe instead of the wavefunction
-            if self.device_reward[0] != "vortices":
-                raise ValueError(f"unknown device reward {self.device_reward[0]!r}")
-            amp, tol = (tuple(self.device_reward[1:]) + (0.0, 0.5))[:2]
-            counts, _ = self._engine.detect_vortices(amp_thresh=float(amp), tol=float(tol), want_winding=False)
-            rewards = counts[:, 0].astype(np.float64)
-        elif self.device_reward is not None:
-            rewards = self._engine.reduce(self._RED[self.device_reward])
-        if self.device_observation is not None and self.device_reward is not None:
-            if isinstance(self.device_observation[0], str):
-                if self.device_observation[0] != "probes":
-                    raise ValueError(f"unknown device observation {self.device_observation[0]!r}")
-                obs = self._engine.probe(self.device_observation[1])  # (B, n_cells): point sensors
-            else:
-                lo, hi = self.device_observation
-                if self.observations_on_device:
-                    obs = self._engine.observe_u8_device(lo, hi).torch()[:, None]  # (B, 1, nx, ny) uint8 CUDA tensor
-                    terminated = self._time >= self.end_time
-                    return obs, rewards, terminated, np.zeros(self.num_envs, dtype=bool), {}
-                if self.reuse_observation_buffer and self._obs_buffer is None and hasattr(self._engine, "pinned_empty"):
-                    self._obs_buffer = self._engine.pinned_empty((self.num_envs,) + tuple(self.domain.points), np.uint8)
-                obs = self._engine.observe_u8(lo, hi, out=self._obs_buffer)[:, None]  # (B, 1, nx, ny) uint8, as the declared space
-        elif self.fetch_observations or self.device_reward is None:
-            self._state_host = self._engine.get_state()
-            obs = np.stack([self.state_to_observation_func(s) for s in self._state_host])
-        else:
+        rewards = np.concatenate([np.asarray(r[1], dtype=np.float64).reshape(-1) for r in results])
+        obs_parts = [r[0] for r in results]
+        if obs_parts[0] is None:
             obs = None
-        if self.device_reward is None:
-            rewards = np.asarray([self.reward_function(s) for s in self._state_host])
+        elif self.observations_on_device and self.device_observation is not None and not isinstance(self.device_observation[0], str):
+            obs = obs_parts[0] if len(obs_parts) == 1 else obs_parts  # device tensors stay on their GPUs
+        else:
+            obs = obs_parts[0] if len(obs_parts) == 1 else np.concatenate(obs_parts)
         terminated = self._time >= self.end_time
         return obs, rewards, terminated, np.zeros(self.num_envs, dtype=bool), {}
 
     @property
+    def _state_host(self):
+        parts = [sh.state_host for sh in self._shards]
+        return parts[0] if len(parts) == 1 else np.concatenate(parts)
+
+    @property
     def states(self):
-        return self._engine.get_state()
+        parts = self._map_shards(lambda sh: sh.engine.get_state())
+        return parts[0] if len(parts) == 1 else np.concatenate(parts)
 
     def close(self):
-        self._engine.close()
+        if self._pool is not None:
+            for ex in self._pool:
+                ex.shutdown(wait=True)
+            self._pool = None
+        for sh in self._shards:
+            sh.engine.close()

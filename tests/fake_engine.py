@@ -164,7 +164,26 @@ class OracleEngine:
             self.y[b] = u
 
     def close(self):
-        pass
+        self.closed = True
+
+    # -- on-device rewards / observations, by the ABI's definitions (include/pdeopt_hip.h) --------------
+    def reduce(self, op):
+        y = self.y.reshape(self.batch, -1).astype(np.float64)
+        return {L.RED_MEAN: y.mean(1), L.RED_VAR: y.var(1), L.RED_MIN: y.min(1), L.RED_MAX: y.max(1),
+                L.RED_SUMSQ: (y**2).sum(1), L.RED_NONFINITE: (~np.isfinite(y)).sum(1).astype(np.float64)}[op]
+
+    def observe_u8(self, lo, hi, env_first=0, env_count=None, out=None):
+        n = self.batch - env_first if env_count is None else env_count
+        q = np.rint(np.clip((self.y[env_first:env_first + n].astype(np.float64) - lo) / (hi - lo), 0.0, 1.0) * 255.0).astype(np.uint8)
+        if out is not None:
+            out[...] = q
+            return out
+        return q
+
+    def probe(self, cells, env_first=0, env_count=None):
+        n = self.batch - env_first if env_count is None else env_count
+        c = np.asarray(cells, dtype=int).reshape(-1, 2)
+        return np.stack([self.y[b][c[:, 0], c[:, 1]].astype(np.float64) for b in range(env_first, env_first + n)])
 
     def snapshot(self):
         self.snap = self.y.copy()

@@ -124,3 +124,67 @@ def test_shard_envs_properties():
             assert all(a[1] == b[0] for a, b in zip(parts, parts[1:]))
             sizes = [hi - lo for lo, hi in parts]
             assert max(sizes) - min(sizes) <= 1
+
+
+class _NullEngine:
+    """what bench.run_decomp asks of a tile backend's engine (the oracle tile has none)"""
+    last_kernel = "oracle tile (test double)"
+
+    def sync(self):
+        pass
+
+    def stage_launches(self):
+        return 0
+
+    def close(self):
+        pass
+
+
+def _bench_decomp_worker(rank, world, port, q):
+    try:
+        import argparse
+        import sys
+
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        import bench
+        import pde_opt_amd as P
+
+        _init(rank, world, port)
+
+        def make_solver(eq, grid):
+            nx, ny = eq.domain.points
+            be = OracleTileBackend(grid.tile_shape(nx, ny), *eq.domain.dx, 0.002, bench.REGSOL, bench.C1MC, dtype=np.float32)
+            be.engine, be.halo = _NullEngine(), 4
+            return DecomposedSolver(eq, grid, comm=TorchComm(), dtype=np.float32, backend=be)
+
+        args = argparse.Namespace(decomp_grid=32, decomp_substeps=3, virtual_ranks=0, decomp_mode="plain", decomp_halo=0,
+                                  warmup=1, steps=2, no_parity_spot=False)
+        spot = bench.run_decomp(args, P, world, rank, 0, dist, make_solver=make_solver)
+        q.put((rank, None if spot is None else spot["parity_spot_ok"], None if spot is None else spot["parity_spot_rel_err"]))
+        dist.barrier()
+        dist.destroy_process_group()
+    except BaseException as e:  # pragma: no cover
+        q.put((rank, repr(e), -1))
+        raise
+
+
+def test_bench_decomp_control_flow_gloo():
+    """bench.py --workload ch_rk4_4096_decomp under world_size 2: the post-timing parity spot runs
+    collectives, so EVERY rank must execute its substeps -- with them under `if rank == 0` the other rank sits in the
+    barrier and the job hangs (this test then times out).  Oracle-backed tiles, gloo all-gather, 32^2 field."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bench_decomp_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    try:
+        res = sorted(q.get(timeout=180) for _ in range(world))
+    finally:
+        for p in procs:
+            p.join(timeout=60)
+            if p.is_alive():
+                p.kill()
+    assert res[0][1] is True and res[0][2] < 1e-5, res  # rank 0 compared its tile with the C oracle
+    assert res[1][1] is None, res                        # rank 1 ran the collectives, did not compare

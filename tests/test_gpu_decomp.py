@@ -6,7 +6,7 @@ import pytest
 import pde_opt_amd as P
 from decomp_util import InProcessComm, gather_all
 from pde_opt_amd import _lib as L
-from pde_opt_amd.decomp import CartesianGrid, DecomposedSolver, HipTileBackend
+from pde_opt_amd.decomp import CartesianGrid, DecomposedSolver, HipTileBackend, LocalGroupComm, advance_group
 from util import MOB, MU, std_domain
 
 pytestmark = pytest.mark.gpu
@@ -22,27 +22,43 @@ def _monolithic(eq, y0, dt, n, fuse):
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
-@pytest.mark.parametrize("fuse", [0, -1])
-def test_single_rank_loopback_equals_periodic(dtype, fuse):
+@pytest.mark.parametrize("fuse,halo", [(0, 8), (0, 4), (-1, 4)])
+def test_single_rank_loopback_equals_periodic(dtype, fuse, halo):
     rng = np.random.default_rng(0)
     dom = std_domain(P, 64, 128)
     eq = P.CahnHilliard2DPeriodic(dom, 0.002, MU["regsol"], MOB["c1mc"])
     y0 = np.clip(0.5 + 0.05 * rng.standard_normal((64, 128)), 0.05, 0.95).astype(dtype)
     want, kern = _monolithic(eq, y0, 2e-7, 6, fuse)
     assert ("pair" in kern) == (fuse == 0)
-    backend = HipTileBackend(eq, (64, 128), dtype)
+    backend = HipTileBackend(eq, (64, 128), dtype, halo=halo)
     backend.engine.set_fuse_stages(fuse)
     s = DecomposedSolver(eq, CartesianGrid(1, 1, 0), dtype=dtype, backend=backend)
-    assert len(backend.phase_plan()) == (2 if fuse == 0 else 4)
+    plan = backend.phase_plan()
+    assert plan == ([0, -1] if halo == 8 else ([0, 2] if fuse == 0 else [0, 1, 2, 1]))
     s.set_global_state(y0)
     s.advance(2e-7, 6)
     np.testing.assert_array_equal(s.local_state(), want)
-    assert s.exchanges == 6 * len(backend.phase_plan())
+    assert s.exchanges == 6 * sum(1 for f in plan if f >= 0)
+
+
+def test_halo_layout_selection():
+    """halo=None picks 8 where the fused Cahn-Hilliard stage pairs run, 4 otherwise; an impossible request is loud"""
+    dom = std_domain(P, 64, 128)
+    ch = P.CahnHilliard2DPeriodic(dom, 0.002, MU["regsol"], MOB["c1mc"])
+    ac = P.AllenCahn2DPeriodic(dom, 0.002, MU["cubic"], MOB["one"])
+    assert HipTileBackend(ch, (64, 128), np.float32).halo == 8
+    assert HipTileBackend(ac, (64, 128), np.float32).halo == 4
+    with pytest.raises(ValueError, match="halo=8 needs"):
+        HipTileBackend(ac, (64, 128), np.float32, halo=8)
+    s = DecomposedSolver(ch, CartesianGrid(1, 1, 0), dtype=np.float32)
+    s.use_overlap = True
+    with pytest.raises(ValueError, match="halo-4 layout"):
+        s.advance(2e-7, 2)
 
 
 @pytest.mark.parametrize("grid", [(2, 2), (2, 1), (1, 4)])
-@pytest.mark.parametrize("fuse", [0, -1])
-def test_multi_tile_on_one_gpu_equals_monolithic(grid, fuse):
+@pytest.mark.parametrize("fuse,halo", [(0, 8), (0, 4), (-1, 4)])
+def test_multi_tile_on_one_gpu_equals_monolithic(grid, fuse, halo):
     """px x py ranks played by px*py engines on one GPU; strips cross between engines through the
     same pack / unpack kernels and neighbour tables the RCCL path uses."""
     px, py = grid
@@ -55,7 +71,7 @@ def test_multi_tile_on_one_gpu_equals_monolithic(grid, fuse):
     comm = InProcessComm(px * py)
     solvers = []
     for r in range(px * py):
-        be = HipTileBackend(eq, (64, 128), np.float32)
+        be = HipTileBackend(eq, (64, 128), np.float32, halo=halo)
         be.engine.set_fuse_stages(fuse)
         s = DecomposedSolver(eq, CartesianGrid(px, py, r), comm=comm.view(r), dtype=np.float32, backend=be)
         s.set_global_state(y0)
@@ -63,11 +79,13 @@ def test_multi_tile_on_one_gpu_equals_monolithic(grid, fuse):
     plan = solvers[0].backend.phase_plan()
     for _ in range(4):
         for phase, field in enumerate(plan):
+            if field >= 0:
+                for s in solvers:
+                    s.backend.pack(field, s.send)
+                gather_all(comm)
+                for s in solvers:
+                    s.backend.unpack(field, s.recv, s.neighbours)
             for s in solvers:
-                s.backend.pack(field, s.send)
-            gather_all(comm)
-            for s in solvers:
-                s.backend.unpack(field, s.recv, s.neighbours)
                 s.backend.phase(phase, 2e-7)
     got = np.empty_like(want)
     for s in solvers:
@@ -126,7 +144,7 @@ def test_interior_plus_edge_launches_equal_one_launch(dtype, shape):
     y0 = np.clip(0.5 + 0.05 * rng.standard_normal((nx, ny)), 0.05, 0.95).astype(dtype)
     outs = []
     for split in (False, True):
-        be = HipTileBackend(eq, (nx, ny), dtype)
+        be = HipTileBackend(eq, (nx, ny), dtype, halo=4)
         be.set_state(y0)
         plan = be.phase_plan()
         assert len(plan) == 2
@@ -145,6 +163,62 @@ def test_interior_plus_edge_launches_equal_one_launch(dtype, shape):
     np.testing.assert_array_equal(outs[1], outs[0])
     want, _ = _monolithic(eq, y0, 2e-7, 5, 0)
     np.testing.assert_array_equal(outs[0], want)
+
+
+@pytest.mark.parametrize("grid,tile,halo,fuse", [((2, 2), (64, 128), 8, 0), ((2, 2), (64, 128), 4, 0), ((2, 2), (64, 128), 4, -1),
+                                                 ((1, 2), (96, 256), 8, 0), ((4, 1), (32, 128), 8, 0), ((2, 3), (64, 128), 8, 0)])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_in_library_loop_with_virtual_ranks_equals_monolithic(grid, tile, halo, fuse, dtype):
+    """pdeopt_rk4_decomposed_advance -- the substep loop in C with its neighbour table and rank offsets into the
+    gathered strips -- on px x py VIRTUAL ranks: engines of this process on one GPU joined in an in-process group
+    (pdeopt_comm_init_local), one host thread per rank, the all-gather = event-ordered device copies between the
+    ranks' strip buffers.  Everything the RCCL run executes except the collective itself; bitwise equal to the
+    monolithic periodic solve, also across two advance calls (the exchange parity continues) and on grids where
+    a rank is its own neighbour (1 x 2, 4 x 1)."""
+    px, py = grid
+    tx, ty = tile
+    if dtype is np.float64:
+        ty //= 2  # 16-byte vectors hold 2 cells: the 32-vector tile is 64 columns wide
+    nx, ny = px * tx, py * ty
+    rng = np.random.default_rng(7)
+    dom = std_domain(P, nx, ny)
+    eq = P.CahnHilliard2DPeriodic(dom, 0.002, MU["regsol"], MOB["c1mc"])
+    y0 = np.clip(0.5 + 0.05 * rng.standard_normal((nx, ny)), 0.05, 0.95).astype(dtype)
+    want, _ = _monolithic(eq, y0, 2e-7, 7, fuse)
+    comms = LocalGroupComm.create(px * py)
+    solvers = []
+    for r in range(px * py):
+        be = HipTileBackend(eq, (tx, ty), dtype, halo=halo)
+        be.engine.set_fuse_stages(fuse)
+        s = DecomposedSolver(eq, CartesianGrid(px, py, r), comm=comms[r], dtype=dtype, backend=be)
+        s.set_global_state(y0)
+        solvers.append(s)
+    advance_group(solvers, 2e-7, 4)
+    advance_group(solvers, 2e-7, 3)
+    got = np.empty_like(want)
+    for s in solvers:
+        assert s.mode == "local-group"
+        si, sj = s.grid.tile_slices(nx, ny)
+        got[si, sj] = s.local_state()
+    np.testing.assert_array_equal(got, want)
+    for s in solvers:
+        s.backend.engine.close()
+    comms[0].group.close()
+
+
+def test_local_group_misuse_is_an_error_not_a_hang():
+    """a rank whose partners never arrive fails with a message (the rendezvous has a time-out; here a rank count
+    mismatch is detected before any waiting)"""
+    dom = std_domain(P, 64, 128)
+    eq = P.CahnHilliard2DPeriodic(dom, 0.002, MU["regsol"], MOB["c1mc"])
+    comms = LocalGroupComm.create(2)
+    s0 = DecomposedSolver(eq, CartesianGrid(2, 1, 0), comm=comms[0], dtype=np.float32)
+    with pytest.raises(ValueError, match="taken"):
+        DecomposedSolver(eq, CartesianGrid(2, 1, 0), comm=LocalGroupComm(comms[0].group, 0), dtype=np.float32)
+    with pytest.raises(ValueError, match="communicator has 2 ranks"):
+        DecomposedSolver(eq, CartesianGrid(1, 1, 0), comm=comms[1], dtype=np.float32)
+    s0.backend.engine.close()
+    comms[0].group.close()
 
 
 def test_config5_tile_size_smoke():
@@ -185,13 +259,12 @@ def test_rccl_allgather_path_single_rank():
         dom = std_domain(P, 64, 128)
         eq = P.CahnHilliard2DPeriodic(dom, 0.002, MU["regsol"], MOB["c1mc"])
         y0 = np.clip(0.5 + 0.05 * rng.standard_normal((64, 128)), 0.05, 0.95).astype(np.float32)
-        want, _ = _monolithic(eq, y0, 2e-7, 5, 0)
         comm = TorchComm()
         assert comm.stream_handle  # a real (non-null) stream shared by RCCL and the engine
         want, _ = _monolithic(eq, y0, 2e-7, 51, 0)
-        modes = {}
+        modes, errors = {}, []
         for graph, overlap in ((True, True), (False, True), (False, False)):
-            sol = DecomposedSolver(eq, CartesianGrid(1, 1, 0), comm=comm, dtype=np.float32)
+            sol = DecomposedSolver(eq, CartesianGrid(1, 1, 0), comm=comm, dtype=np.float32, halo=4)
             sol.use_graph, sol.use_overlap = graph, overlap
             sol.set_global_state(y0)
             sol.advance(2e-7, 51)  # odd: graph-replayed pairs + one eager substep
@@ -199,28 +272,39 @@ def test_rccl_allgather_path_single_rank():
             got = sol.local_state()
             bad = np.abs(got - want)
             print("mode", sol.mode, "max diff", float(bad.max()), "rows", np.where(bad.max(axis=1) > 0)[0][:8], flush=True)
-            errors = locals().setdefault("errors", [])
             if bad.max() > 0:
                 errors.append((graph, overlap, sol.mode, float(bad.max())))
             assert sol.send.is_cuda and sol.recv.numel() == sol.backend.strip_elems
             assert sol.exchanges == 2 * 51
             modes[(graph, overlap)] = sol.mode
+            sol.backend.engine.close()
             if graph and sol.mode != "graph+overlap":
                 print("device-graph capture of the exchange unavailable:", getattr(sol, "capture_error", None))
         # the library's own RCCL communicator: the whole loop in C, with and without the overlapped collective
         from pde_opt_amd.decomp import NativeComm
 
-        for overlap in (True, False):
-            sol = DecomposedSolver(eq, CartesianGrid(1, 1, 0), comm=NativeComm(), dtype=np.float32)
+        for overlap, halo in ((True, 4), (False, 4), (False, 8)):
+            sol = DecomposedSolver(eq, CartesianGrid(1, 1, 0), comm=NativeComm(), dtype=np.float32, halo=halo)
             sol.use_overlap = overlap
             sol.set_global_state(y0)
-            sol.advance(2e-7, 51)
+            sol.advance(2e-7, 30)
+            sol.advance(2e-7, 21)
             got = sol.local_state()
-            print("mode", sol.mode, "max diff", float(np.abs(got - want).max()), flush=True)
+            print("mode", sol.mode, "halo", halo, "max diff", float(np.abs(got - want).max()), flush=True)
             assert sol.mode == ("native+overlap" if overlap else "native")
+            assert sol.exchanges == (2 if halo == 4 else 1) * 51
             if not np.array_equal(got, want):
-                errors.append(("native", overlap, sol.mode, float(np.abs(got - want).max())))
+                errors.append(("native", overlap, halo, sol.mode, float(np.abs(got - want).max())))
             sol.backend.engine.close()
+        # the plain torch all-gather driver on the halo-8 layout (one exchange per substep, pack / unpack kernels)
+        sol = DecomposedSolver(eq, CartesianGrid(1, 1, 0), comm=comm, dtype=np.float32, halo=8)
+        sol.set_global_state(y0)
+        sol.advance(2e-7, 51)
+        torch.cuda.synchronize()
+        if not np.array_equal(sol.local_state(), want):
+            errors.append(("torch plain", 8, float(np.abs(sol.local_state() - want).max())))
+        assert sol.mode == "plain" and sol.exchanges == 51
+        sol.backend.engine.close()
         assert not errors, errors
         assert modes[(False, True)] == "overlap" and modes[(False, False)] == "plain"
         assert modes[(True, True)] in ("graph+overlap", "overlap")

@@ -187,6 +187,61 @@ def test_observations_and_state_stay_on_the_gpu_as_torch_tensors():
     dev.close()
 
 
+def test_vector_env_over_several_engines():
+    """VectorPDEEnv(engines=[...]) -- the multi-GPU product path (one engine + host thread per device, environments
+    split by shard_envs, no collective) with TWO engines on device 0 and an uneven 5 = 3 + 2 split: states, rewards
+    and uint8 frames equal the single-engine environment bit for bit; with observations_on_device every engine hands
+    back its own tensor.  The CPU twin with 2 and 3 oracle-backed engines is tests/test_multi_device_env.py."""
+    dom = std_domain(P, 64, 128)
+    kw = _env_kwargs(dom)
+    extra = dict(device_reward="var", device_observation=(0.0, 1.0))
+    one = P.VectorPDEEnv(5, **kw, **extra)
+    many = P.VectorPDEEnv(5, **kw, engines=[P.HipEngine(0), P.HipEngine(0)], **extra)
+    assert many.num_devices == 2 and many.shard_bounds == [(0, 3), (3, 5)]
+    one.reset(seed=40)
+    many.reset(seed=40)
+    for actions in ([0, 1, 2, 2, 0], [2, 2, 0, 1, 1], [1, 1, 1, 1, 1]):
+        o1, r1, t1, _, _ = one.step(actions)
+        o2, r2, t2, _, _ = many.step(actions)
+        np.testing.assert_array_equal(o1, o2)
+        np.testing.assert_array_equal(r1, r2)
+        np.testing.assert_array_equal(t1, t2)
+        np.testing.assert_array_equal(one.states, many.states)
+    assert [sh.engine.batch for sh in many._shards] == [3, 2]
+    assert "stage_pair" in many._shards[1].engine.last_kernel
+    one.close()
+    many.close()
+    # host reward / observation functions and the IMEX solver (per-environment kappa: sigma relative to each
+    # engine's first environment) through the same sharding
+    kw = _env_kwargs(dom, P.SemiImplicitFourierSpectral, {"A": 0.5}, step_dt=1e-5, numeric_dt=1e-6)
+    one = P.VectorPDEEnv(5, **kw)
+    many = P.VectorPDEEnv(5, **kw, engines=[P.HipEngine(0), P.HipEngine(0), P.HipEngine(0)])
+    one.reset(seed=41)
+    many.reset(seed=41)
+    y0 = one.states
+    for actions in ([0, 1, 2, 2, 0], [2, 2, 0, 1, 1]):
+        o1, r1, _, _, _ = one.step(actions)
+        o2, r2, _, _, _ = many.step(actions)
+        # paired transforms group environments differently per engine: equal to rounding, not bitwise
+        assert rel_l2(many.states - y0, one.states - y0) < 1e-9
+        np.testing.assert_allclose(r2, r1, rtol=1e-9)
+    one.close()
+    many.close()
+    torch = pytest.importorskip("torch")
+    kw = _env_kwargs(dom)
+    dev = P.VectorPDEEnv(4, **kw, engines=[P.HipEngine(0), P.HipEngine(0)], observations_on_device=True, **extra)
+    host = P.VectorPDEEnv(4, **kw, **extra)
+    dev.reset(seed=3)
+    host.reset(seed=3)
+    obs_d, rew_d, *_ = dev.step([0, 1, 2, 1])
+    obs_h, rew_h, *_ = host.step([0, 1, 2, 1])
+    assert isinstance(obs_d, list) and len(obs_d) == 2 and all(o.is_cuda and tuple(o.shape) == (2, 1, 64, 128) for o in obs_d)
+    np.testing.assert_array_equal(torch.cat(obs_d).cpu().numpy(), obs_h)
+    np.testing.assert_array_equal(rew_d, rew_h)
+    dev.close()
+    host.close()
+
+
 def test_detect_vortices_against_reference_goldens(golden):
     """rl_utils.detect_vortices on the GPU: winding map, positions, charges and counts equal the
     reference's (pde_opt/rl_utils.py:19-84) -- integers, so exactly."""

@@ -8,8 +8,9 @@ such combination from a fixed seed and compares the HIP result of every environm
 in fp64 on the same inputs.
 
 Tolerances (stated as in tests/util.py): fp64 increments to 1e-9 relative (FMA / re-association, amplified by the
-biharmonic's (1/h^2)^2 cancellation); fp32 states to 1e-6 absolute and increments to 2e-3 relative (the state is
-O(1), an increment O(1e-4..1e-2): state rounding alone bounds the increment's relative accuracy near 1e-3).
+biharmonic's (1/h^2)^2 cancellation); fp32 states to 1e-6 absolute and increments to 2e-4 relative plus the
+explicit fp32 state-rounding floor 4 eps |y| / |increment| (tests/util.py: inc_tol_f32 -- the state is O(1), an
+increment O(1e-4..1e-2), and the state is rounded to fp32 every substep).
 """
 import numpy as np
 import pytest
@@ -17,7 +18,7 @@ import pytest
 import pde_opt_amd as P
 from oracle import np_oracle as O
 from pde_opt_amd import _lib as L
-from util import MOB, MU, rel_l2
+from util import MOB, MU, inc_tol_f32, rel_l2
 
 pytestmark = pytest.mark.gpu
 
@@ -41,7 +42,7 @@ def _check(got, want, y0, dtype, what):
         assert rel_l2(inc_g, inc_w) < 1e-9, (what, rel_l2(inc_g, inc_w))
     else:
         assert np.max(np.abs(got - want)) < 1e-6 * max(1.0, np.max(np.abs(want))), (what, np.max(np.abs(got - want)))
-        assert rel_l2(inc_g, inc_w) < 2e-3, (what, rel_l2(inc_g, inc_w))
+        assert rel_l2(inc_g, inc_w) < inc_tol_f32(want, y0), (what, rel_l2(inc_g, inc_w), inc_tol_f32(want, y0))
 
 
 @pytest.mark.parametrize("seed", range(64 * _SCALE))

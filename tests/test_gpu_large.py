@@ -12,7 +12,7 @@ import pytest
 import pde_opt_amd as P
 from oracle import np_oracle as O
 from pde_opt_amd import _lib as L
-from util import MOB, MU, rel_l2, std_domain
+from util import MOB, MU, inc_tol_f32, rel_l2, std_domain
 
 pytestmark = pytest.mark.gpu
 
@@ -87,7 +87,7 @@ def test_fields_beyond_2_31_elements(case):
             ref = step(f, i * dt, ref, dt)
         last = got[PATTERNS + b].astype(np.float64)
         assert np.max(np.abs(last - ref)) < 1e-6, (case, b, np.max(np.abs(last - ref)))
-        assert rel_l2(last - pats[b], ref - pats[b]) < 2e-3, (case, b)
+        assert rel_l2(last - pats[b], ref - pats[b]) < inc_tol_f32(ref, pats[b]), (case, b, rel_l2(last - pats[b], ref - pats[b]))
 
 
 def test_strang_beyond_2_31_elements():
