@@ -170,6 +170,12 @@ typedef enum {
   PDEOPT_OPT_FUSE_STAGES = 4, /* RK4: temporally fused stages: 0 = auto (stage pairs 1+2 / 3+4 where a fused
                                  kernel exists; fp32 Allen-Cahn: the whole substep in one pass), 1 = stage
                                  pairs only, -1 = off (one launch per stage) */
+  PDEOPT_OPT_SMALL_PERSIST = 8,/* Euler / RK4 on grids whose stage input (+ chemical potential) fits one compute unit's
+                                 LDS (CH <= 128^2 fp32, 96^2 fp64): ALL n substeps of pdeopt_advance in ONE launch, one
+                                 workgroup per environment, the state in registers (the sizes of the reference's own
+                                 tests and notebooks, where a launch per stage pair is latency-bound): 0 = auto (grids
+                                 up to 4096 cells, larger ones from 192 environments on), 1 = wherever it can run,
+                                 -1 = never */
   PDEOPT_OPT_DEBUG_ABLATE = 3 /* TIMING ONLY, results are wrong: bit0 skip the mu phase, bit1 skip
                                  the flux phase of the tiled kernel (where does the time go?) */
 } pdeopt_option;

@@ -39,6 +39,7 @@ OPT_FUSE_STAGES = 4
 OPT_HALO_LAYOUT = 5
 OPT_GRAPH = 6
 OPT_IMEX_LDS_FFT = 7
+OPT_SMALL_PERSIST = 8
 CNT_STAGE_LAUNCHES = 0
 CNT_LAST_GROUPS = 1
 COPY_H2D, COPY_D2H, COPY_D2D = 0, 1, 2

@@ -239,6 +239,7 @@ int pdeopt_ctx_destroy(pdeopt_ctx* ctx) {
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
   if (ctx->stream && !ctx->stream_borrowed) (void)hipStreamDestroy(ctx->stream);
   if (ctx->halo_scratch) (void)hipFree(ctx->halo_scratch);
+  if (ctx->halo_scratch2) (void)hipFree(ctx->halo_scratch2);
   delete ctx;
   return PDEOPT_OK;
 }
@@ -281,6 +282,10 @@ int pdeopt_set_option(pdeopt_ctx* ctx, int option, int64_t value) {
       return PDEOPT_OK;
     case PDEOPT_OPT_GROUP_ENVS:
       ctx->opt_group_envs = value;
+      return PDEOPT_OK;
+    case PDEOPT_OPT_SMALL_PERSIST:
+      if (value < -1 || value > 1) return fail(ctx, PDEOPT_EINVAL, "small-persist option must be -1, 0 or 1");
+      ctx->opt_small_persist = value;
       return PDEOPT_OK;
     default:
       return fail(ctx, PDEOPT_EINVAL, "unknown option %d", option);

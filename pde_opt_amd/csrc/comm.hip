@@ -330,19 +330,20 @@ int rk4_decomposed_advance(pdeopt_ctx* ctx, double dt, int64_t n, const int* nbr
   if (ctx->halo == 8) {
     // ONE exchange per substep (halo-8 layout):
     //   pack(Y) -> all-gather                                   prologue: the state as it stands
-    //   per substep:  unpack(Y) -> PAIR_12 on tile + 4 -> PAIR_34, its edge tiles writing the NEW state's strip
-    //                 (no pack launch) -> all-gather (not after the last substep)
+    //   per substep:  PAIR_12 on tile + 4, its edge tiles reading the halo from the gathered strips (no unpack
+    //                 launch) -> PAIR_34, its edge tiles writing the NEW state's strip (no pack launch)
+    //                 -> all-gather (not after the last substep)
     if (n <= 0) return PDEOPT_OK;
     if (c.local() && (rc = local_wait_send_free(ctx, c))) return abort_group(rc);
     void* send = c.send_buf();
     if ((rc = halo_pack(ctx, 0, send))) return abort_group(rc);
     if ((rc = all_gather(send, ctx->stream))) return abort_group(rc);
     for (int64_t s = 0; s < n; ++s) {
-      if ((rc = halo_unpack(ctx, 0, c.recv, nbr))) return abort_group(rc);
       const bool more = s + 1 < n;
       if (more && c.local() && (rc = local_wait_send_free(ctx, c))) return abort_group(rc);
       send = c.send_buf();
-      if ((rc = rk4_substep_h8(ctx, dt, more ? send : nullptr))) return abort_group(rc);
+      // no unpack launch: the first pair's edge tiles read the halo from c.recv (and fill the field's frame)
+      if ((rc = rk4_substep_h8(ctx, dt, more ? send : nullptr, c.recv, nbr))) return abort_group(rc);
       if (more && (rc = all_gather(send, ctx->stream))) return abort_group(rc);
     }
     return PDEOPT_OK;

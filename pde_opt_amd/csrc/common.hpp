@@ -157,7 +157,10 @@ struct pdeopt_ctx {
   int halo = 0;                  // halo width of the configured layout
   int pair_ext = 0;              // next PAIR_12 launch covers the tile + this many ring cells (halo-8 layout: 4)
   void* pair_strip = nullptr;    // next PAIR_34 launch also writes the tile's halo strip here (fused pack)
+  const void* pair_recv = nullptr;  // next PAIR_12 launch reads the halo from these gathered strips (fused unpack)
+  int pair_nbr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   void* halo_scratch = nullptr;  // single-rank loop-back buffer for pack/unpack
+  void* halo_scratch2 = nullptr; // second loop-back strip (halo-8 loop: fused pack writes one while the next is read)
   size_t halo_scratch_bytes = 0;
   int64_t opt_imex_lds_fft = 0;  // IMEX transforms: 0 auto (hand-written passes where the size is covered), -1 rocFFT
   int64_t opt_graph = 0;         // hipGraph replay of the substep loop: 0 auto (launch-bound sizes), 1 always, -1 never
@@ -167,6 +170,7 @@ struct pdeopt_ctx {
   std::string graph_name;
   int64_t opt_fuse_stages = 0;   // RK4 stage-pair fusion: 0 auto, -1 off (one launch per stage), 1 stage pairs (AC: no single-pass kernel)
   int64_t opt_debug_ablate = 0;  // timing-only ablations, results are wrong when set
+  int64_t opt_small_persist = 0; // whole-environment-step kernel for LDS-resident grids: 0 auto, 1 wherever it can, -1 never
   // Gaussian light spots of the GPE (pdeopt_set_gpe_spots)
   int n_spots = 0;
   void* spots_dev = nullptr;
@@ -260,9 +264,11 @@ int halo_unpack(pdeopt_ctx* ctx, int field, const void* dev_recv, const int* nbr
 size_t halo_strip_elems(const pdeopt_ctx* ctx);
 int rk4_phase(pdeopt_ctx* ctx, int phase, double dt, int part = 0);
 int rk4_loopback_advance(pdeopt_ctx* ctx, double dt, int64_t n);
-// halo-8 layout: one substep = [unpack(Y)] -> PAIR_12 on the tile + 4 ring -> PAIR_34 (+ the new state's halo strip
+// halo-8 layout: one substep = [unpack(Y), or fused into the first pair] -> PAIR_12 on the tile + 4 ring -> PAIR_34 (+ the new state's halo strip
 // written into `strip` by the edge tiles' epilogue when strip != nullptr); Y / TA are swapped
-int rk4_substep_h8(pdeopt_ctx* ctx, double dt, void* strip);
+// recv != nullptr: the halo of the state is NOT in the field yet -- the first pair's edge tiles read it from the
+// gathered strips `recv` (neighbour ranks nbr[8]) and write the frame cells back (fused unpack)
+int rk4_substep_h8(pdeopt_ctx* ctx, double dt, void* strip, const void* recv = nullptr, const int* nbr = nullptr);
 int rk4_phase_plan(pdeopt_ctx* ctx, int* fields, int* nphases);
 void* field_ptr(pdeopt_ctx* ctx, int field);
 // comm.hip

@@ -14,6 +14,7 @@
 #include "stencil_fused_ac.hpp"
 #include "stencil_fused_ac4.hpp"
 #include "stencil_fused_launch.hpp"
+#include "stencil_small.hpp"
 
 namespace pdeopt {
 
@@ -282,8 +283,31 @@ GraphStructure graph_structure(const pdeopt_problem& p) {
 }
 }  // namespace
 
+// Does the whole-environment-step kernel (stencil_small.hpp) take this advance?  PDEOPT_OPT_SMALL_PERSIST: 1 = wherever
+// it can run, -1 = never, 0 = auto: grids of at most 64^2-class size (<= 4096 cells: one launch instead of 2 n
+// dependent ones, measured 2.7-4.8 x faster per environment step), and larger LDS-resident grids once enough
+// environments run side by side to fill the chip's compute units (>= 192) -- a single 128^2 environment is faster on
+// the tiled kernels, which spread it over 8+ CUs, than on one CU.
+static bool small_chosen(const pdeopt_ctx* ctx, int integrator, int64_t n) {
+  if (ctx->opt_small_persist < 0 || ctx->opt_kernel_path == 1 || ctx->opt_debug_ablate) return false;
+  if (integrator != PDEOPT_INT_EULER && integrator != PDEOPT_INT_RK4) return false;
+  const bool ok = ctx->prob.dtype == PDEOPT_F32 ? small_supported<float>(ctx) : small_supported<double>(ctx);
+  if (!ok) return false;
+  if (ctx->opt_small_persist > 0) return true;
+  if (ctx->opt_fuse_stages < 0 || ctx->opt_kernel_path == 2 || ctx->opt_graph > 0) return false;  // the caller asked for another path
+  const int64_t cells = (int64_t)ctx->prob.nx * ctx->prob.ny;
+  if (n < 2) return false;
+  return cells <= kSmallAutoCells || ctx->prob.batch >= kSmallAutoBatch;
+}
+
 int advance_explicit(pdeopt_ctx* ctx, int integrator, double t0, double dt, int64_t n) {
   int rc;
+  if (small_chosen(ctx, integrator, n)) {
+    ctx->win_lo = 0;
+    ctx->win_n = ctx->prob.batch;
+    ctx->last_groups = 1;
+    return ctx->prob.dtype == PDEOPT_F32 ? launch_small<float>(ctx, integrator, dt, n) : launch_small<double>(ctx, integrator, dt, n);
+  }
   if ((rc = ensure_buffer(ctx, &ctx->TA, ctx->total_bytes))) return rc;
   // Euler: two substeps per launch through the stage-pair kernels where they exist
   //   PAIR_12 with aA = bA = bB = dt:  w = y + dt f(y),  ACC = y + dt f(y) + dt f(w) = two Euler steps
@@ -467,13 +491,13 @@ void graph_destroy(pdeopt_ctx* ctx) {
 int rk4_phase_plan(pdeopt_ctx* ctx, int* fields, int* nphases) {
   const bool fused = ctx->opt_kernel_path != 1 && ctx->prob.derivs == PDEOPT_DERIVS_FD &&
                      (ctx->prob.dtype == PDEOPT_F32 ? fused_supported<float>(ctx) : fused_supported<double>(ctx));
-  if (fused && ctx->halo == 8) {
+  if (fused && ctx->halo == 8 && ctx->prob.equation == PDEOPT_EQ_CAHN_HILLIARD) {
     // halo-8 layout: ONE exchange per substep.  Pair 1+2 runs on the tile + 4 ring (it reads y on tile + 8), so
     // pair 3+4 finds TB on its tile + 4 input region without an exchange of TB.
     *nphases = 2;
     fields[0] = 0;
     fields[1] = -1;  // no exchange before phase 1
-  } else if (fused) {
+  } else if (fused && ctx->halo != 8) {
     *nphases = 2;
     fields[0] = 0;  // Y  (stage pair 1+2 differentiates y)
     fields[1] = 2;  // TB (stage pair 3+4 differentiates y + dt/2 k2)
@@ -540,9 +564,14 @@ int rk4_loopback_advance(pdeopt_ctx* ctx, double dt, int64_t n) {
     // loop-back "collective" is the strip buffer itself
     if (n <= 0) return PDEOPT_OK;
     if ((rc = halo_pack(ctx, 0, nullptr))) return rc;
+    // the strip written by substep s (fused pack) is read by substep s + 1 (fused unpack): two buffers
+    const size_t bytes = halo_strip_elems(ctx) * ctx->esize;
+    if ((rc = ensure_buffer(ctx, &ctx->halo_scratch2, bytes))) return rc;
+    void* cur = ctx->halo_scratch;
+    void* nxt = ctx->halo_scratch2;
     for (int64_t s = 0; s < n && !rc; ++s) {
-      if ((rc = halo_unpack(ctx, 0, nullptr, nbr))) break;
-      rc = rk4_substep_h8(ctx, dt, s + 1 < n ? ctx->halo_scratch : nullptr);
+      rc = rk4_substep_h8(ctx, dt, s + 1 < n ? nxt : nullptr, cur, nbr);
+      std::swap(cur, nxt);
     }
     return rc;
   }
@@ -557,8 +586,12 @@ int rk4_loopback_advance(pdeopt_ctx* ctx, double dt, int64_t n) {
 
 // halo-8 layout, the state's halo already unpacked: both stage pairs of one substep; the edge tiles of the second
 // write the NEW state's halo strip into `strip` (nullptr: not wanted)
-int rk4_substep_h8(pdeopt_ctx* ctx, double dt, void* strip) {
+int rk4_substep_h8(pdeopt_ctx* ctx, double dt, void* strip, const void* recv, const int* nbr) {
+  ctx->pair_recv = recv;
+  if (recv)
+    for (int q = 0; q < 8; ++q) ctx->pair_nbr[q] = nbr[q];
   int rc = rk4_phase(ctx, 0, dt, 0);
+  ctx->pair_recv = nullptr;
   if (rc) return rc;
   ctx->pair_strip = strip;
   rc = rk4_phase(ctx, 1, dt, 0);

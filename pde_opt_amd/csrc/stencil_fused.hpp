@@ -79,6 +79,15 @@ struct PairArgs {
   // [left 8 cols][right 8 cols][TL][TR][BL][BR] per environment -- so no pack launch is needed (nullptr: off)
   T* strip;
   int64_t strip_env;  // strip elements per environment
+  // PAIR_12 of a decomposed field (halo-8 layout): the launch covers the tile + `ext` ring (pointers pre-shifted by
+  // -ext rows / columns).  With recv != nullptr the edge tiles take the halo cells of their input straight from the
+  // gathered strips (recv: all ranks' strips, rank-major, strip_rank elements each; nbr: ranks of {up, down, left,
+  // right, UL, UR, DL, DR}) instead of from the field's halo frame, and write the frame cells they own back into
+  // the field (the second stage pair reads y there): no unpack launch.
+  const T* recv;
+  int64_t strip_rank;
+  int nbr[8];
+  int ext;
 };
 
 // offsets of the 8 pieces of a halo strip of width H for an nx x ny tile (halo.hip: decode())
@@ -108,9 +117,36 @@ __device__ __forceinline__ bool tile_skipped(int part, int ti, int tj, int tiles
 // the 1/h of the face gradient join the 1/h of the divergence in ONE factor 0.5/h^2 per axis
 // (PairArgs::rhx / rhy), applied to the difference of two face values: 2 multiplies per face less
 // than the literal form, ~5 % of this VALU-bound kernel.
+//
+// Rounding must not depend on WHERE in a workgroup tile a cell falls: a decomposed field tiles the plane differently
+// from the monolithic run (and the halo-8 layout shifts the tiling by 4 cells), and both must give the same bits.
+// Under -ffp-contract=fast-honor-pragmas (hipcc's default) the difference of two face fluxes, a*b - c*d, may be
+// contracted either way round -- fma(a, b, -(c*d)) or fma(-c, d, a*b) -- and the backend picks by use counts, which
+// differ between the marching form (a face flux is shared by two rows) and the ring form (it is not): seen as 1 ulp
+// on 0.02-0.06 % of the cells.  PDEOPT_FLUX_PIN: 0 nothing pinned; 1 the FMA of k = dFx rhx + dFy rhy spelled out;
+// 2 = 1 + every face-flux product rounded (contraction off inside face_flux), so the differences are plain
+// subtractions; 3 (default) = the face-flux products AND the product dFy rhy rounded, k left to the compiler --
+// its only contraction is then fma(dFx, rhx, .).  Same-box A/B on the headline (tools/ab_pin.sh, interleaved x 3) and
+// the decomposed == monolithic tests of tests/test_gpu_decomp.py on 27 layouts:
+//     0: 1763 env-steps/s, 8 layouts differ   1: 1684, 4 differ   2: 1660, bitwise   3: 1743 (-1.1 %), bitwise
+#ifndef PDEOPT_FLUX_PIN
+#define PDEOPT_FLUX_PIN 3
+#endif
 template <typename T>
 __device__ __forceinline__ T face_flux(T d_a, T d_b, T m_a, T m_b, T /*unused*/) {
+#if PDEOPT_FLUX_PIN >= 2
+#pragma clang fp contract(off)
+#endif
   return (d_a + d_b) * (m_b - m_a);
+}
+// k = dfx * rhx + dy with dy = dFy * rhy already formed: one FMA, the x term fused
+template <typename T>
+__device__ __forceinline__ T div_sum(T dfx, T rhx, T dy) {
+#if PDEOPT_FLUX_PIN == 1 || PDEOPT_FLUX_PIN == 2
+  return __builtin_fma(dfx, rhx, dy);
+#else
+  return dfx * rhx + dy;
+#endif
 }
 
 // y-divergence of the face fluxes of one vector of cells (needs the scalar neighbours left / right)
@@ -122,8 +158,13 @@ __device__ __forceinline__ Vec div_y(Vec m_c, Vec d_c, T ml, T mr, T dl, T dr, T
   for (int e = 1; e < V; ++e) fy[e] = face_flux<T>(d_c[e - 1], d_c[e], m_c[e - 1], m_c[e], rhy);
   fy[V] = face_flux<T>(d_c[V - 1], dr, m_c[V - 1], mr, rhy);
   Vec r;
+  {
+#if PDEOPT_FLUX_PIN >= 3
+#pragma clang fp contract(off)  // the product stays a product: k = dfx rhx + r then has ONE contraction (div_sum)
+#endif
 #pragma unroll
-  for (int e = 0; e < V; ++e) r[e] = (fy[e + 1] - fy[e]) * rhy;
+    for (int e = 0; e < V; ++e) r[e] = (fy[e + 1] - fy[e]) * rhy;
+  }
   return r;
 }
 
@@ -151,7 +192,7 @@ __device__ __forceinline__ Vec flux_divergence(const ClosureSpec& ms, const T* _
   for (int e = 0; e < V; ++e) {
     const T fx_hi = face_flux<T>(d_c[e], d_up[e], m_c[e], m_up[e], rhx);
     const T fx_lo = face_flux<T>(d_dn[e], d_c[e], m_dn[e], m_c[e], rhx);
-    k[e] = (fx_hi - fx_lo) * rhx + dy[e];
+    k[e] = div_sum<T>(fx_hi - fx_lo, rhx, dy[e]);
   }
   return k;
 }
@@ -264,7 +305,69 @@ __global__ __launch_bounds__(NT) PDEOPT_PAIR_WAVES_ATTR void stage_pair_kernel(c
   // LDS store; the column wrap and the column offset are formed once per thread.  (The flat "vector idx = tid +
   // it NT" mapping needed a division by PV, two wraps and a 64-bit address per vector: ~100 of the ~700 VALU
   // instructions a thread executes per tile.)  A wave reads 34 (36) contiguous vectors of one row.
-  {
+  bool halo_from_strips = false;  // wave-uniform
+  if constexpr (PAIR == PAIR_12 && !RAGGED)
+    halo_from_strips = a.recv != nullptr && (ti == 0 || ti == tiles_i - 1 || tj == 0 || tj == tiles_j - 1);
+  if (halo_from_strips) {
+    // Fused unpack (decomposed field, edge tiles of the extended launch).  True coordinates (tile interior = [0, nx)
+    // x [0, ny)) of a loaded vector: gi = i0 - 4 + row - ext, gj = j0 - HV V + lane V - ext.  Interior cells come
+    // from the field, cells of the 8-wide halo from the strip piece of the neighbour they belong to (halo.hip:
+    // my halo piece q <- piece FROM[q] of neighbour q), cells beyond the halo (the over-run of the last tile row /
+    // column) from the layout's margin -- computed on, never read back.  A vector never straddles two sources (all
+    // boundaries are multiples of V).  Per thread: one source pointer + pitch for each row class, chosen by its
+    // column class; per trip: the wave-uniform row picks the class.
+    constexpr int NW = NT / 64;
+    constexpr int H = 8;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    if (lane < PV) {
+      const int nx = g.nx, ny = g.ny, ext = a.ext;
+      const StripOffsets<H> so(nx, ny);
+      const T* const mem = in + (int64_t)ext * ld + ext;  // cell (0, 0) of the tile interior
+      const T* const rb = a.recv + (int64_t)b * a.strip_env;
+      const int64_t S = a.strip_rank;
+      const int gj = j0 - HV * V + lane * V - ext;
+      const T *pT, *pM, *pB;
+      int64_t qT, qM, qB;  // pitches
+      if (gj >= 0 && gj < ny) {
+        pT = rb + a.nbr[0] * S + so.bottom + gj; qT = ny;   // up's bottom rows
+        pM = mem + gj; qM = ld;
+        pB = rb + a.nbr[1] * S + so.top + gj; qB = ny;      // down's top rows
+      } else if (gj < 0) {
+        const int c = gj + H;
+        pT = rb + a.nbr[4] * S + so.br + c; pM = rb + a.nbr[2] * S + so.right + c; pB = rb + a.nbr[6] * S + so.tr + c;
+        qT = qM = qB = H;
+      } else if (gj < ny + H) {
+        const int c = gj - ny;
+        pT = rb + a.nbr[5] * S + so.bl + c; pM = rb + a.nbr[3] * S + so.left + c; pB = rb + a.nbr[7] * S + so.tl + c;
+        qT = qM = qB = H;
+      } else {  // beyond the halo: the margin
+        pT = mem + gj - (int64_t)H * ld; pM = mem + gj; pB = mem + gj + (int64_t)nx * ld;
+        qT = qM = qB = ld;
+      }
+      const T* const pO = mem + gj;
+      T* const lds = sU + lane * V;
+      constexpr int kRows = TX + 8, kTrips = (kRows + NW - 1) / NW;
+      Vec f[kTrips];
+#pragma unroll
+      for (int k = 0; k < kTrips; ++k) {
+        int row = wave + k * NW;
+        if constexpr (kRows % NW != 0) row = row < kRows ? row : kRows - 1;
+        const int gi = i0 - 4 + row - ext;  // wave-uniform
+        const T* src;
+        if (gi < 0) src = pT + (int64_t)(gi + H) * qT;
+        else if (gi < nx) src = pM + (int64_t)gi * qM;
+        else if (gi < nx + H) src = pB + (int64_t)(gi - nx) * qB;
+        else src = pO + (int64_t)gi * ld;
+        f[k] = *reinterpret_cast<const Vec*>(src);
+      }
+#pragma unroll
+      for (int k = 0; k < kTrips; ++k) {
+        const int row = wave + k * NW;
+        if (kRows % NW == 0 || k + 1 < kTrips || row < kRows) *reinterpret_cast<Vec*>(lds + row * P) = f[k];
+      }
+    }
+  } else {
     constexpr int NW = NT / 64;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
@@ -446,7 +549,7 @@ __global__ __launch_bounds__(NT) PDEOPT_PAIR_WAVES_ATTR void stage_pair_kernel(c
 #pragma unroll
       for (int e = 0; e < V; ++e) {
         fx_hi[e] = face_flux<T>(d_c[e], d_hi[e], m_c[e], m_hi[e], a.rhx);
-        k[e] = (fx_hi[e] - fx_lo[e]) * a.rhx + dy[e];
+        k[e] = div_sum<T>(fx_hi[e] - fx_lo[e], a.rhx, dy[e]);  // same contraction as flux_divergence()
       }
       kout[r] = k;
       if (centre) centre[r] = u_c;
@@ -533,6 +636,12 @@ __global__ __launch_bounds__(NT) PDEOPT_PAIR_WAVES_ATTR void stage_pair_kernel(c
     } else if constexpr (PAIR == PAIR_12) {
       *reinterpret_cast<Vec*>(a.out + idx) = yown[r] + a.aB * kB[r];
       *reinterpret_cast<Vec*>(a.acc_out + idx) = accp[r] + a.bB * kB[r];
+      if (halo_from_strips) {
+        // the unpack's other half: own cells outside the tile interior go back into the field's halo frame, where
+        // the second stage pair reads y (pointwise, tile + 2)
+        const int gi = i0 + r0 + r - a.ext, gj = j0 + lx * V - a.ext;
+        if (gi < 0 || gi >= g.nx || gj < 0 || gj >= g.ny) *reinterpret_cast<Vec*>(const_cast<T*>(a.in) + idx) = yown[r];
+      }
     } else {
       const Vec ynew = accp[r] + a.bB * kB[r];
       *reinterpret_cast<Vec*>(a.out + idx) = ynew;

@@ -99,6 +99,10 @@ class HipEngine:
     def set_fuse_stages(self, v: int):
         self._check(self._lib.pdeopt_set_option(self._h, L.OPT_FUSE_STAGES, int(v)))
 
+    def set_small_persist(self, v: int):
+        """whole-environment-step kernel for LDS-resident grids (Euler / RK4): 0 auto, 1 wherever it can run, -1 never"""
+        self._check(self._lib.pdeopt_set_option(self._h, L.OPT_SMALL_PERSIST, int(v)))
+
     def set_group_envs(self, n: int):
         self._check(self._lib.pdeopt_set_option(self._h, L.OPT_GROUP_ENVS, int(n)))
 

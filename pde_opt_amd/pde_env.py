@@ -208,6 +208,12 @@ class _EnvShard:
         eng.set_env_params(0, kappa=kappa, mu_coef=mu, mob_coef=mob)
         return eq0
 
+    def get_states(self):
+        """current states of this shard's environments (the reset states until the first step configures the engine)"""
+        if self._configured_key is None:
+            return np.array(self._y0, copy=True)
+        return self.engine.get_state()
+
     def step(self, eqs):
         """one environment step of this shard's environments: returns (obs, rewards)"""
         from .integrate import constant_step_plan
@@ -515,7 +521,7 @@ class VectorPDEEnv:
 
     @property
     def states(self):
-        parts = self._map_shards(lambda sh: sh.engine.get_state())
+        parts = self._map_shards(lambda sh: sh.get_states())
         return parts[0] if len(parts) == 1 else np.concatenate(parts)
 
     def close(self):
