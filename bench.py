@@ -50,7 +50,8 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
 
 # algorithmic words per cell per substep; a word is one real scalar
-WORDS = {"rk4": 16, "euler": 2, "imex": 9, "strang": 22}  # strang: 88 B / 4 B at c64
+WORDS = {"rk4": 16, "euler": 2, "imex": 9, "strang": 22,  # strang: 88 B / 4 B at c64
+         "rk4_sbm": 28}  # smoothed boundary: + psi, |grad psi|/psi and the mask per stage ("+8 B/cell/stage" + mask)
 
 METRIC = "env-steps/sec (Cahn-Hilliard 1024^2 RK4, 100 substeps/env-step) & achieved HBM GB/s"
 WORKLOADS = {
@@ -59,6 +60,15 @@ WORKLOADS = {
     "ch_rk4_1024_f32_cubic": dict(eq="ch", n=1024, dtype=np.float32, integ="rk4", dt=2e-7, substeps=100, batch=32,
                                   closures="cubic"),
     "ch_rk4_1024_f64": dict(eq="ch", n=1024, dtype=np.float64, integ="rk4", dt=2e-7, substeps=100, batch=16),
+    # the reference's own grid sizes (tests/test_solvers.py:25,68,145; notebooks: 32^2 ... 128^2): the whole-environment-
+    # step kernel (csrc/stencil_small.hpp), one launch per environment step, one compute unit per environment
+    "ch_rk4_64_f32_small": dict(eq="ch", n=64, dtype=np.float32, integ="rk4", dt=2e-7, substeps=100, batch=256),
+    "ch_rk4_128_f32_small": dict(eq="ch", n=128, dtype=np.float32, integ="rk4", dt=2e-7, substeps=100, batch=256),
+    "ac_rk4_64_f32_small": dict(eq="ac", n=64, dtype=np.float32, integ="rk4", dt=5e-5, substeps=100, batch=256),
+    # smoothed-boundary Cahn-Hilliard (cahn_hilliard.py:204-289) on the LDS-tiled kernel: a disc-shaped
+    # level set, regular-solution free energy, contact angle and boundary flux varying in time (notebooks/smooth_boundary.ipynb)
+    "ch_sbm_1024_f32": dict(eq="ch_sbm", n=1024, dtype=np.float32, integ="rk4", dt=2e-3, substeps=100, batch=8, words="rk4_sbm",
+                            abs_tol=2e-6),  # dt = 2e-3: the state moves 10x as far per substep as in the periodic workloads
     "ac_rk4_512_f32": dict(eq="ac", n=512, dtype=np.float32, integ="rk4", dt=5e-5, substeps=100, batch=64),
     "ch_imex_1024_f32": dict(eq="ch", n=1024, dtype=np.float32, integ="imex", dt=1e-6, substeps=100, batch=32),
     "gpe_strang_512_c64": dict(eq="gpe", n=512, dtype=np.float32, integ="strang", dt=1e-3, substeps=100, batch=128),
@@ -70,6 +80,18 @@ WORKLOADS = {
 
 REGSOL = lambda c: np.log(c / (1 - c)) + 3 * (1 - 2 * c)  # noqa: E731
 C1MC = lambda c: c * (1 - c)  # noqa: E731
+# smoothed-boundary workload: free energy, contact-angle ramp and boundary flux (the closures of tests/util.py)
+SBM_F = lambda c: c * np.log(c) + (1.0 - c) * np.log(1.0 - c) + 3.0 * c * (1.0 - c) + 0.059  # noqa: E731
+SBM_THETA = lambda t: 34.9065850398866 * t**2 - 10.4719755119660 * t + np.pi / 2  # noqa: E731
+SBM_FLUX = lambda t: 0.02 * (1.0 + 3.0 * t)  # noqa: E731
+
+
+def sbm_psi(nx, ny, floor=0.05):
+    """disc-shaped level set in (floor, 1] on a unit-spacing grid"""
+    x, y = np.arange(nx) + 0.5, np.arange(ny) + 0.5
+    X, Y = np.meshgrid(x, y, indexing="ij")
+    r = np.sqrt((X - 0.5 * nx) ** 2 + (Y - 0.5 * ny) ** 2)
+    return floor + (1.0 - floor) * 0.5 * (1.0 + np.tanh((0.3 * min(nx, ny) - r) / 2.5))
 
 
 def make_problem(P, name, batch, rank):
@@ -88,6 +110,16 @@ def make_problem(P, name, batch, rank):
             y0[b, ..., 0], y0[b, ..., 1] = psi, 0.0
         solver = P.StrangSplitting(eq.A_term, eq.dx, eq.fft, eq.ifft, 1.0)
         return eq, y0, solver
+    if w["eq"] == "ch_sbm":
+        import types
+
+        psi = sbm_psi(n, n)
+        dom = P.Domain((n, n), ((0.0, float(n)), (0.0, float(n))), "dimensionless", geometry=types.SimpleNamespace(smooth=psi))
+        eq = P.CahnHilliard2DSmoothedBoundary(dom, 1.5, SBM_F, REGSOL, C1MC, SBM_THETA, SBM_FLUX)
+        y0 = np.empty((batch, n, n), dtype=dtype)
+        for b in range(batch):
+            y0[b] = np.clip(0.5 + 0.1 * np.random.default_rng(rank * batch + b).standard_normal((n, n)), 0.1, 0.9)
+        return eq, y0, P.RK4()
     L_ = 0.01 * n
     dom = P.Domain((n, n), ((-L_ / 2, L_ / 2), (-L_ / 2, L_ / 2)), "dimensionless")
     y0 = np.empty((batch, n, n), dtype=dtype)
@@ -114,13 +146,21 @@ SPOT_TOL_F32 = {"rk4": 5e-5, "imex": 5e-5, "strang": 2e-5}
 SPOT_TOL_F64 = {"rk4": 1e-9, "imex": 1e-8, "strang": 1e-10}
 SPOT_ABS_TOL_F32 = 5e-7
 
-PMC_FILE = os.path.join(ROOT, "profiles", "pmc_r02.json")  # per-launch PMC averages (tools/pmc_to_json.py)
+# per-launch PMC averages of this round's build (tools/pmc_to_json.py); the previous round's while none is committed yet
+PMC_FILE = next((f for f in (os.path.join(ROOT, "profiles", n) for n in ("pmc_r03.json", "pmc_r02.json")) if os.path.exists(f)),
+                os.path.join(ROOT, "profiles", "pmc_r03.json"))
 N_SIMD, SHADER_HZ = 1024, 2.4e9  # 256 CUs x 4 SIMDs; MI355X_MICROARCH.md chip table
-# issue cost of one scalar-fp32 wave64 VALU instruction per SIMD, measured with >= 4 waves resident
-# (tools/valubench.hip -> profiles/r02_valubench.txt: v_fma_f32 3.5 clk, v_add_f32 4.1, v_pk_fma_f32 5.7 for two
-# FMAs, v_log_f32 / v_rcp_f32 8.5; costs of a mix add up).  The 157.3 TF vector peak (= 2 clk) is the PACKED rate.
-VALU_CLK_MEASURED = 3.5      # clocks per wave64 scalar-fp32 VALU instruction per SIMD (profiles/r02_valubench.txt)
-VALU_CLK_MEASURED_F64 = 5.0  # v_fma_f64 / v_add_f64: 4.9-5.2 from 4 waves per SIMD on (same file)
+# What the VALU can do, measured IN the kernel (tools/valubench.hip: s_memtime / s_memrealtime stamps around >= 1 ms bodies,
+# profiles/r03_valubench_raw.txt): a SIMD issues one wave64 fp32 VALU instruction per ~2 shader cycles once >= 3 waves are
+# resident (a lone wave: 5.5), v_log / v_rcp per ~4-6, v_pk_fma_f32 per ~2.2 per FMA -- as MI355X_MICROARCH.md says --
+# while the chip holds 1.9-2.0 GHz under an FMA stream, not 2.4 (round 2 divided wall times by 2.4 GHz and read 3.5 "clk").
+VALU_CLK_MEASURED = 2.0      # shader cycles per wave64 scalar-fp32 VALU instruction per SIMD, >= 3 resident waves
+VALU_CLK_MEASURED_F64 = 2.5  # v_fma_f64 at 8 waves per SIMD (3.4 at 4)
+# ... and what the counters read for it (tools/valu_pmc_calib.sh, profiles/r03_valu_pmc_calibration.txt): SQ_ACTIVE_INST_VALU
+# books exactly 4 cycles per instruction, so "4 x SQ_ACTIVE_INST_VALU / SIMDs over GRBM_GUI_ACTIVE / 8" reads 1.40 (2-4
+# waves per SIMD) to 1.62-1.65 (8 waves) for a kernel that issues NOTHING but independent v_fma_f32 / v_add_f32 / v_mov --
+# not 1.0.  The VALU utilisation of a kernel is its reading over that saturated reading.
+VALU_BUSY_SATURATED = 1.62
 
 
 def roofline_block(workload, kernel_name, bytes_per_launch, words, avg_launch_s, launches):
@@ -158,31 +198,35 @@ def roofline_block(workload, kernel_name, bytes_per_launch, words, avg_launch_s,
         r["valu_insts_per_launch"] = c["SQ_INSTS_VALU"]
         r["valu_clk_per_inst_measured"] = valu_clk
         r["frac_valu_measured_issue"] = per_simd * valu_clk / cycles
-        r["frac_valu_4clk"] = per_simd * 4.0 / cycles
-        r["frac_valu_spec"] = per_simd * 2.0 / cycles  # 157.3 TF denominator: the packed-fp32 rate
         if c.get("SQ_ACTIVE_INST_VALU") and c.get("GRBM_GUI_ACTIVE"):
             # quad-cycles summed over SIMDs vs the launch's cycles under the profiler (sum over 8 XCDs)
             r["valu_busy_frac_pmc"] = 4.0 * c["SQ_ACTIVE_INST_VALU"] / N_SIMD / (c["GRBM_GUI_ACTIVE"] / 8.0)
-        # which pipe is busier: the VALU's measured busy share (it prices transcendentals at their 8.5 clk; the
-        # instruction count x 3.5 clk is the conservative figure reported as `frac`) or the fabric's share of the peak
-        valu_share = r.get("valu_busy_frac_pmc", r["frac_valu_measured_issue"])
+            r["valu_busy_saturated_pmc"] = VALU_BUSY_SATURATED
+            r["valu_util"] = r["valu_busy_frac_pmc"] / VALU_BUSY_SATURATED
+        # which pipe is busier: the VALU (its counter reading over the reading of an all-VALU kernel) or the fabric (measured
+        # traffic over the HBM peak)?
+        valu_share = r.get("valu_util", r["frac_valu_measured_issue"])
         if valu_share > (r.get("traffic_frac") or 0.0):
             r["bound"] = "valu"
-            r["unit"] = "Ginst/s"
-            r["achieved"] = c["SQ_INSTS_VALU"] / avg_launch_s / 1e9
-            r["peak"] = N_SIMD * SHADER_HZ / valu_clk / 1e9
-            r["frac"] = r["achieved"] / r["peak"]
+            r["unit"] = "VALU utilisation (SQ_ACTIVE_INST_VALU share of SIMD cycles / the 1.62 an all-VALU kernel reads)"
+            r["achieved"] = valu_share
+            r["peak"] = 1.0
+            r["frac"] = valu_share
+        r["valu_ginst_per_s"] = c["SQ_INSTS_VALU"] / avg_launch_s / 1e9
+        r["valu_ginst_per_s_at_measured_issue_cost"] = N_SIMD * SHADER_HZ / valu_clk / 1e9
     if r["bound"] == "hbm" and r.get("traffic_gbs"):
         # memory-bound with measured traffic: price the bytes that moved, not the per-stage byte count (which fusion
         # undercuts -- a fraction above 1 of a hardware peak would say nothing)
         r["achieved"], r["frac"] = r["traffic_gbs"], r["traffic_frac"]
     r["pmc_source"] = os.path.relpath(PMC_FILE, ROOT) + ": " + pmc.get("source", "")
-    r["note"] = ("bound = what binds the kernel.  valu: achieved = wave64 VALU instructions issued per second (SQ_INSTS_VALU per "
-                 "launch, PMC profile of this command / live HIP-event launch time), peak = 1024 SIMDs x 2.4 GHz / 3.5 clk (fp64: 5.0), "
-                 "the measured scalar issue rate (profiles/r02_valubench.txt; transcendentals cost 8.5 clk, so the true issue "
-                 "share is higher: valu_busy_frac_pmc).  algorithmic_gbs is SURVEY 8(d)'s byte count over the same time: it may "
-                 "exceed the HBM peak because stage-pair fusion and cache-resident environment groups remove traffic; "
-                 "traffic = measured L2 fabric-side bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, Infinity-Cache hits included).")
+    r["note"] = ("bound = the busier of two pipes: fabric traffic (measured bytes per launch / live launch time, against the 8 TB/s HBM peak; "
+                 "Infinity-Cache hits included) and the VALU (valu_util = its counter reading over the reading of an all-VALU kernel, "
+                 "profiles/r03_valu_pmc_calibration.txt).  valu_insts_per_launch, valu_busy_frac_pmc and traffic come from the COMMITTED "
+                 "rocprofv3 --pmc profile of this command (" + os.path.relpath(PMC_FILE, ROOT) + ": counters need rocprofv3, the driver's run has "
+                 "none); the launch time and algorithmic_gbs are measured live in this run with HIP events.  frac_valu_measured_issue = "
+                 "SQ_INSTS_VALU x the in-kernel-measured 2.0 cycles per instruction (tools/valubench.hip) over the live launch cycles at 2.4 GHz.  "
+                 "algorithmic_gbs is SURVEY 8(d)'s byte count over the same time: it may exceed the HBM peak because stage-pair fusion and "
+                 "cache-resident environment groups remove traffic (7 instead of 16 words per cell and substep).")
     return r
 
 
@@ -462,7 +506,7 @@ def parity_spot(name, eng, eq, solver, y0, threads):
 
     w = WORKLOADS[name]
     dt, batch = w["dt"], y0.shape[0]
-    nsub = w["substeps"] if w["integ"] == "rk4" else 8
+    nsub = w["substeps"] if (w["integ"] == "rk4" and w["eq"] != "ch_sbm") else 8
     eng.set_state(y0)
     eng.advance(solver.integrator, dt, nsub, 0.0)
     envs = sorted({0, batch // 2 - 1, batch // 2, batch - 1} & set(range(batch)))
@@ -470,7 +514,12 @@ def parity_spot(name, eng, eq, solver, y0, threads):
     worst_rel = worst_abs = 0.0
     for b in envs:
         got = eng.get_state(b, 1)[0].astype(np.float64)
-        if w["integ"] == "rk4":
+        if w["eq"] == "ch_sbm":
+            frhs = lambda t, u: O.ch_sbm_rhs(u, eq.psi, hx, hy, 1.5, SBM_F, REGSOL, C1MC, SBM_THETA(t), SBM_FLUX(t), eq.left_half)
+            ref = y0[b].astype(np.float64)
+            for i in range(nsub):
+                ref = O.rk4_step(frhs, i * dt, ref, dt)
+        elif w["integ"] == "rk4":
             code, cmu, cmob = _oracle_closures(w)
             ref = CO.rk4(code, y0[b], hx, hy, 0.002, cmu, cmob, dt, nsub, threads=threads).astype(np.float64)
         elif w["integ"] == "imex":
@@ -491,13 +540,13 @@ def parity_spot(name, eng, eq, solver, y0, threads):
         worst_abs = max(worst_abs, float(np.max(np.abs(got - ref))))
     f64 = y0.dtype == np.float64
     tol = (SPOT_TOL_F64 if f64 else SPOT_TOL_F32)[w["integ"]]
-    abs_tol = 1e-12 if f64 else SPOT_ABS_TOL_F32 * max(1.0, float(np.max(np.abs(y0))))
+    abs_tol = 1e-12 if f64 else w.get("abs_tol", SPOT_ABS_TOL_F32) * max(1.0, float(np.max(np.abs(y0))))
     return {"parity_spot_rel_err": worst_rel, "parity_spot_max_abs_err": worst_abs, "parity_spot_tol": tol,
             "parity_spot_max_abs_tol": abs_tol,
             "parity_spot_ok": bool(worst_rel < tol and worst_abs < abs_tol),
             "parity_spot": f"{nsub} substeps of the timed call on fresh inputs, environments {envs} of {batch} "
                            f"(groups: {eng.last_groups()}) vs "
-                           + ("oracle/c_oracle.c" if w["integ"] == "rk4" else "oracle/np_oracle.py")}
+                           + ("oracle/c_oracle.c" if (w["integ"] == "rk4" and w["eq"] != "ch_sbm") else "oracle/np_oracle.py")}
 
 
 def cpu_baseline(name, budget_s=15.0):
@@ -513,7 +562,7 @@ def cpu_baseline(name, budget_s=15.0):
     from oracle import np_oracle as O
 
     w = WORKLOADS[name]
-    if w["integ"] != "rk4":
+    if w["integ"] != "rk4" or w["eq"] not in ("ch", "ac"):
         return None
     n, dtype, dt, substeps = w["n"], w["dtype"], w["dt"], w["substeps"]
     hx = hy = 0.01
@@ -674,7 +723,8 @@ def main():
     if rank == 0:
         nx, ny = eq.domain.points
         esize = y0.dtype.itemsize
-        total_bytes = WORDS[w["integ"]] * esize * nx * ny * batch * substeps * args.steps
+        words = WORDS[w.get("words", w["integ"])]
+        total_bytes = words * esize * nx * ny * batch * substeps * args.steps
         launches = max(launches, 1)
         bytes_per_launch = total_bytes / launches
         avg_launch_s = (dev_ms * 1e-3) / launches
@@ -710,7 +760,7 @@ def main():
             "achieved_gbs_whole_job": args.gpus * total_bytes / elapsed / 1e9,
             "nonfinite_cells": bad,
             **(spot or {}),
-            "roofline": roofline_block(args.workload, kernel_name, bytes_per_launch, WORDS[w["integ"]], avg_launch_s, launches),
+            "roofline": roofline_block(args.workload, kernel_name, bytes_per_launch, words, avg_launch_s, launches),
         }
         if args.gpus == 1 and not args.no_api and not args.ablate:
             line.update(api_throughput(P, args.workload, rank, args.steps, args.warmup) or {})

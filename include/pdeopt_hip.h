@@ -252,6 +252,12 @@ int pdeopt_advance(pdeopt_ctx* ctx, int integrator, double t0, double dt, int64_
 /* Smoothed-boundary equations: fn is called on the calling thread, once per RHS evaluation, from
  * inside pdeopt_rhs / pdeopt_advance / pdeopt_tsit5_trial; fn == NULL uses constant[3] instead.  */
 int pdeopt_set_time_terms(pdeopt_ctx* ctx, pdeopt_time_fn fn, void* user, const double constant[3]);
+/* The same scalars for a LIST of evaluation times, handed over before pdeopt_advance: terms is [n][3] = out[0..2] of
+ * pdeopt_time_fn at times[0..n-1].  A right-hand side evaluated at a listed time (compared exactly: form the stage
+ * times as the library does -- t0 + s dt, + dt/2, + dt for RK4) takes its scalars from the table, so a fixed-step
+ * advance of n substeps makes no host callback at all (one per stage otherwise: 400 Python calls per 100 RK4
+ * substeps); other times still go to fn / constant.  n = 0 clears it; pdeopt_set_time_terms clears it too. */
+int pdeopt_set_time_table(pdeopt_ctx* ctx, int n, const double* times, const double* terms);
 /* integrator parameters: IMEX A (solvers.py:43); Strang time_scale re/im and dx (solvers.py:86-89) */
 int pdeopt_set_integrator_params(pdeopt_ctx* ctx, double imex_A, double time_scale_re,
                                  double time_scale_im, double strang_dx);

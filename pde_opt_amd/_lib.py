@@ -123,6 +123,7 @@ _SIGNATURES = {
     "pdeopt_advance": (C.c_int, [_VP, C.c_int, C.c_double, C.c_double, C.c_int64]),
     "pdeopt_set_integrator_params": (C.c_int, [_VP, C.c_double, C.c_double, C.c_double, C.c_double]),
     "pdeopt_set_time_terms": (C.c_int, [_VP, TIME_FN, _VP, C.POINTER(C.c_double)]),
+    "pdeopt_set_time_table": (C.c_int, [_VP, C.c_int, _VP, _VP]),
     "pdeopt_snapshot": (C.c_int, [_VP]),
     "pdeopt_get_interpolated": (C.c_int, [_VP, C.c_double, C.c_int, C.c_int, _VP]),
     "pdeopt_reduce": (C.c_int, [_VP, C.c_int, _VP]),

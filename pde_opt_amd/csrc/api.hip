@@ -566,6 +566,17 @@ int pdeopt_set_time_terms(pdeopt_ctx* ctx, pdeopt_time_fn fn, void* user, const 
   ctx->time_fn = fn;
   ctx->time_user = user;
   for (int i = 0; i < 3; ++i) ctx->time_const[i] = constant ? constant[i] : 0.0;
+  ctx->tt_times.clear();  // a table belongs to the source it was sampled from
+  ctx->tt_terms.clear();
+  ctx->tsit5_fsal_valid = false;
+  return PDEOPT_OK;
+}
+
+int pdeopt_set_time_table(pdeopt_ctx* ctx, int n, const double* times, const double* terms) {
+  if (!ctx || n < 0 || (n > 0 && (!times || !terms))) return PDEOPT_EINVAL;
+  ctx->tt_times.assign(times, times + n);
+  ctx->tt_terms.assign(terms, terms + 3 * (size_t)n);
+  ctx->tt_cursor = 0;
   ctx->tsit5_fsal_valid = false;
   return PDEOPT_OK;
 }

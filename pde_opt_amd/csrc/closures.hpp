@@ -11,9 +11,12 @@ namespace pdeopt {
 
 template <typename T>
 __device__ __forceinline__ T t_log(T x);
+// fp32: the hardware log2 (v_log_f32, 1 ulp) instead of ocml's logf (~40 VALU instructions with its range fix-ups), as
+// for t_logit below: the only user is the mixing-entropy term c ln c + (1 - c) ln(1 - c) of the smoothed-boundary free
+// energy, whose ~1e-7 absolute error is below the fp32 noise of the stencil it feeds.  fp64 stays libm's.
 template <>
 __device__ __forceinline__ float t_log<float>(float x) {
-  return logf(x);
+  return 0.6931471805599453f * __builtin_amdgcn_logf(x);
 }
 template <>
 __device__ __forceinline__ double t_log<double>(double x) {
@@ -29,6 +32,22 @@ template <>
 __device__ __forceinline__ double t_exp<double>(double x) {
   return exp(x);
 }
+
+// 1 / x and sqrt(x) of the smoothed-boundary kernels (kappa / psi, ... / psi, sqrt(2 f)): fp32 on the hardware
+// approximations (v_rcp_f32 / v_sqrt_f32, 1 ulp; the IEEE division and square root expand to ~10 instructions each with
+// their scaling and fix-up sequences), fp64 exact
+template <typename T>
+__device__ __forceinline__ T t_rcp(T x);
+template <>
+__device__ __forceinline__ float t_rcp<float>(float x) { return __builtin_amdgcn_rcpf(x); }
+template <>
+__device__ __forceinline__ double t_rcp<double>(double x) { return 1.0 / x; }
+template <typename T>
+__device__ __forceinline__ T t_sqrt(T x);
+template <>
+__device__ __forceinline__ float t_sqrt<float>(float x) { return __builtin_amdgcn_sqrtf(x); }
+template <>
+__device__ __forceinline__ double t_sqrt<double>(double x) { return sqrt(x); }
 
 // log(c / (1 - c)).  fp32: hardware reciprocal and log2 (v_rcp_f32 / v_log_f32, 1 ulp each) instead of
 // the correctly rounded division + ocml logf (~40 VALU instructions with their range fix-ups): the

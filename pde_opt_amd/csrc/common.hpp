@@ -146,6 +146,9 @@ struct pdeopt_ctx {
   pdeopt_time_fn time_fn = nullptr;
   void* time_user = nullptr;
   double time_const[3] = {0.0, 0.0, 0.0};
+  // pdeopt_set_time_table: the three scalars at a list of evaluation times, looked up before the callback is asked
+  std::vector<double> tt_times, tt_terms;
+  size_t tt_cursor = 0;
   void* env_params_dev = nullptr;
   std::vector<char> env_params_host;
   pdeopt::AuxField aux[pdeopt::kNumAux];

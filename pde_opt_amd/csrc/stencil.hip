@@ -15,6 +15,7 @@
 #include "stencil_fused_ac4.hpp"
 #include "stencil_fused_launch.hpp"
 #include "stencil_small.hpp"
+#include "stencil_sbm_tiled.hpp"
 
 namespace pdeopt {
 
@@ -55,7 +56,19 @@ StageArgs<T> make_args(pdeopt_ctx* ctx, const void* in, const void* y, void* out
   s.fe = ClosureSpec{p.fe.kind, p.fe.flags, p.fe.n};
   if (p.equation == PDEOPT_EQ_ALLEN_CAHN_SBM || p.equation == PDEOPT_EQ_CAHN_HILLIARD_SBM) {
     double tv[3] = {ctx->time_const[0], ctx->time_const[1], ctx->time_const[2]};
-    if (ctx->time_fn) ctx->time_fn(ctx->cur_t, tv, ctx->time_user);
+    // the table of pdeopt_set_time_table first (stage times arrive in order: resume at the cursor), the host callback
+    // for times it does not hold
+    bool found = false;
+    const size_t nt = ctx->tt_times.size();
+    for (size_t q = 0; q < nt && !found; ++q) {
+      const size_t i = (ctx->tt_cursor + q) % nt;
+      if (ctx->tt_times[i] == ctx->cur_t) {
+        for (int c = 0; c < 3; ++c) tv[c] = ctx->tt_terms[3 * i + c];
+        ctx->tt_cursor = i;
+        found = true;
+      }
+    }
+    if (!found && ctx->time_fn) ctx->time_fn(ctx->cur_t, tv, ctx->time_user);
     s.tw_a = T(tv[0]);
     s.tw_b = T(tv[1]);
     s.tsrc = T(tv[2]);
@@ -118,6 +131,11 @@ int launch_generic(pdeopt_ctx* ctx, const StageArgs<T>& s) {
       if (!s.psi || !s.ngp || !s.mask)
         return fail(ctx, PDEOPT_ESTATE, "smoothed-boundary equations need the SBM_PSI, SBM_NORM_GRAD and SBM_MASK aux fields");
       if (ctx->halo) return fail(ctx, PDEOPT_EINVAL, "smoothed-boundary equations need the periodic layout");
+      if (sbm_tiled_supported<T>(ctx)) {
+        const int rc_t = launch_sbm_tiled<T>(ctx, s);
+        if (rc_t) return rc_t;
+        break;
+      }
       if (p.equation == PDEOPT_EQ_ALLEN_CAHN_SBM) {
         hipLaunchKernelGGL((stage_generic_kernel<T, PDEOPT_EQ_ALLEN_CAHN_SBM>), grid, block, 0, ctx->stream, s);
         ctx->last_kernel = "stage_generic<AC-SBM>";
@@ -294,7 +312,9 @@ static bool small_chosen(const pdeopt_ctx* ctx, int integrator, int64_t n) {
   const bool ok = ctx->prob.dtype == PDEOPT_F32 ? small_supported<float>(ctx) : small_supported<double>(ctx);
   if (!ok) return false;
   if (ctx->opt_small_persist > 0) return true;
-  if (ctx->opt_fuse_stages < 0 || ctx->opt_kernel_path == 2 || ctx->opt_graph > 0) return false;  // the caller asked for another path
+  // a caller who turned one of the tiled path's knobs is asking for that path
+  if (ctx->opt_fuse_stages != 0 || ctx->opt_kernel_path != 0 || ctx->opt_graph != 0 || ctx->opt_group_envs != 0 || ctx->opt_tile_rows != 0)
+    return false;
   const int64_t cells = (int64_t)ctx->prob.nx * ctx->prob.ny;
   if (n < 2) return false;
   return cells <= kSmallAutoCells || ctx->prob.batch >= kSmallAutoBatch;

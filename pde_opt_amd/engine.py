@@ -262,6 +262,7 @@ class HipEngine:
         cos off the mask, flux)`` is called by the library at every stage; ``fn=None`` uses
         ``constant``.  The ctypes thunk is kept alive on the engine."""
         const = (C.c_double * 3)(*[float(v) for v in constant])
+        self._time_terms_fn = fn
         if fn is None:
             self._time_thunk = None
             self._check(self._lib.pdeopt_set_time_terms(self._h, L.TIME_FN(0), None, const))
@@ -304,7 +305,22 @@ class HipEngine:
         self._check(self._lib.pdeopt_rhs(self._h, float(t), ptr))
         return out
 
+    def _upload_time_table(self, integrator: int, dt: float, n: int, t0: float):
+        """Fixed-step Euler / RK4 with time-dependent scalar terms (smoothed-boundary theta(t), flux(t)): sample them
+        at every stage time of the call up front -- the times formed exactly as the library forms them -- so the
+        substep loop runs without a host callback per stage (``pdeopt_set_time_table``)."""
+        fn = getattr(self, "_time_terms_fn", None)
+        if fn is None or integrator not in (L.INT_EULER, L.INT_RK4) or n <= 0 or n > 100000:
+            return
+        ts = float(t0) + np.arange(int(n), dtype=np.float64) * float(dt)  # t0 + (double) step * dt
+        if integrator == L.INT_RK4:
+            ts = np.unique(np.concatenate([ts, ts + float(dt) / 2, ts + float(dt)]))
+        terms = np.ascontiguousarray(np.asarray([fn(float(t)) for t in ts], dtype=np.float64).reshape(-1, 3))
+        ts = np.ascontiguousarray(ts)
+        self._check(self._lib.pdeopt_set_time_table(self._h, len(ts), ts.ctypes.data_as(C.c_void_p), terms.ctypes.data_as(C.c_void_p)))
+
     def advance(self, integrator: int, dt: float, n_substeps: int, t0: float = 0.0):
+        self._upload_time_table(int(integrator), dt, int(n_substeps), t0)
         self._check(self._lib.pdeopt_advance(self._h, int(integrator), float(t0), float(dt), int(n_substeps)))
 
     def snapshot(self):

@@ -617,6 +617,7 @@ def test_hipgraph_replay_equals_eager(case):
     for mode in (-1, 1, 0):
         eng = P.HipEngine()
         eng.set_graph(mode)
+        eng.set_small_persist(-1)  # this test is about the per-substep launches (the whole-step kernel has none to capture)
         outs.append(P.diffeqsolve(eq, solver, 0.0, n * dt, dt, y0, engine=eng).ys[-1])
         names.append(eng.last_kernel)
         # a second solve on the same engine reuses the cached graph
@@ -635,6 +636,16 @@ def test_ragged_tiles_match_generic_and_oracle(engine, dtype, shape):
     rng = np.random.default_rng(31)
     nx, ny = shape
     dom = std_domain(P, nx, ny)
+    hx, hy = dom.dx
+    engine.set_small_persist(-1)  # the tiled kernels are the subject (small grids would take the whole-step kernel)
+    try:
+        _ragged_body(engine, dtype, shape, rng, dom)
+    finally:
+        engine.set_small_persist(0)
+
+
+def _ragged_body(engine, dtype, shape, rng, dom):
+    nx, ny = shape
     hx, hy = dom.dx
     for cls, fn, kind in ((P.CahnHilliard2DPeriodic, O.ch_rhs_fd, "c"), (P.AllenCahn2DPeriodic, O.ac_rhs_fd, "sym")):
         mu_fn, mob_fn = (MU["regsol"], MOB["c1mc"]) if kind == "c" else (MU["cubic"], MOB["one_plus_sq"])
@@ -698,6 +709,7 @@ def test_allen_cahn_single_pass_rk4_equals_stage_pairs(shape, batch, mob):
     for fuse in (0, 1, -1):  # auto (single pass), stage pairs, one launch per stage
         eng = P.HipEngine()
         eng.set_fuse_stages(fuse)
+        eng.set_small_persist(-1)
         eng.configure(dtype=np.float32, batch=batch, **eq._engine_problem())
         eng.set_env_params(0, kappa=0.002 * (1.0 + 0.1 * np.arange(batch)))
         eng.set_state(u)

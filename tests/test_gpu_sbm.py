@@ -131,6 +131,7 @@ def test_two_pass_ch_sbm_equals_the_literal_one_pass_kernel(dtype):
     outs, kernels = [], []
     for literal in (False, True):
         eng = P.HipEngine()
+        eng.set_kernel_path(L.PATH_GENERIC)        # the one-thread-per-cell forms (the LDS-tiled kernel is the default)
         eng.set_fuse_stages(-1 if literal else 1)  # auto picks by size: two passes from 2^18 cells on
         sol = P.diffeqsolve(eq, P.RK4(), 0.02, 0.02 + 5 * 2e-3, 2e-3, y0, engine=eng)
         outs.append(sol.ys[-1])
@@ -141,6 +142,69 @@ def test_two_pass_ch_sbm_equals_the_literal_one_pass_kernel(dtype):
     # the two kernels are different instantiations: hipcc contracts their FMAs differently, a few ulp of the state
     inc0, inc1 = outs[0].astype(np.float64) - y0, outs[1].astype(np.float64) - y0
     assert rel_l2(inc0, inc1) < (1e-12 if dtype is np.float64 else 2e-5), rel_l2(inc0, inc1)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("kind", ["ac", "ch"])
+@pytest.mark.parametrize("shape", [(64, 128), (100, 100), (80, 72), (8, 16), (144, 264)])
+def test_lds_tiled_sbm_kernel_vs_oracle_and_generic(kind, shape, dtype):
+    """csrc/stencil_sbm_tiled.hpp: u and psi tiles in LDS, `inner` once per point, every integrator
+    through it (Euler, RK4, Tsit5's fused next-stage form) -- against the numpy oracle and the one-thread-per-cell
+    kernels it restates term for term; tile-divisible and ragged grids, a batch of 3"""
+    from pde_opt_amd import _lib as L
+
+    rng = np.random.default_rng(31)
+    psi = sbm_psi(*shape)
+    eq = _eq(kind, sbm_domain(P, psi))
+    y0 = np.clip(0.5 + 0.1 * rng.standard_normal((3,) + psi.shape), 0.1, 0.9).astype(dtype)
+    f = _oracle_rhs(kind, psi, eq.left_half)
+    dt, n, t0 = (2e-3 if kind == "ch" else 2e-2), 3, 0.03
+    for solver, step in ((P.RK4(), O.rk4_step), (P.Euler(), O.euler_step), (P.Tsit5(), lambda ff, t, y, h: O.tsit5_step(ff, t, y, h)[0])):
+        outs = {}
+        for path in (L.PATH_AUTO, L.PATH_GENERIC):
+            eng = P.HipEngine()
+            eng.set_kernel_path(path)
+            outs[path] = P.diffeqsolve(eq, solver, t0, t0 + n * dt, dt, y0, engine=eng).ys[-1]
+            assert ("sbm_tiled" in eng.last_kernel) == (path == L.PATH_AUTO), eng.last_kernel
+            eng.close()
+        ref = y0[1].astype(np.float64)
+        for i in range(n):
+            ref = step(f, t0 + i * dt, ref, dt)
+        tol = 1e-10 if dtype is np.float64 else 5e-4
+        assert rel_l2(outs[L.PATH_AUTO][1] - y0[1], ref - y0[1]) < tol, (kind, shape, type(solver).__name__)
+        d = rel_l2(outs[L.PATH_AUTO].astype(np.float64) - y0, outs[L.PATH_GENERIC].astype(np.float64) - y0)
+        assert d < (1e-12 if dtype is np.float64 else 2e-5), (kind, shape, d)
+    # the right-hand side alone, against the oracle
+    got = eq.rhs(y0, 0.17)
+    assert "sbm_tiled" in P.engine.default_engine().last_kernel
+    for b in range(3):
+        assert rel_l2(got[b], f(0.17, y0[b].astype(np.float64))) < TOL[np.dtype(dtype)]
+
+
+def test_time_terms_are_sampled_once_per_advance_not_per_stage():
+    """fixed-step Euler / RK4: theta(t), flux(t) at every stage time of the call go to the library as ONE table
+    (pdeopt_set_time_table) -- the substep loop makes no host callback; the result equals the per-stage callback's"""
+    from pde_opt_amd import _lib as L
+
+    rng = np.random.default_rng(5)
+    psi = sbm_psi(64, 128)
+    calls = []
+    theta = lambda t: (calls.append(t), SBM_THETA(t))[1]  # noqa: E731
+    eq = _eq("ch", sbm_domain(P, psi), theta=theta)
+    y0 = np.clip(0.5 + 0.1 * rng.standard_normal(psi.shape), 0.1, 0.9)
+    eng = P.HipEngine()
+    sol = P.diffeqsolve(eq, P.RK4(), 0.03, 0.03 + 50 * 2e-3, 2e-3, y0, engine=eng)
+    n_table = len(calls)
+    assert n_table <= 151  # 50 substeps x {t, t + dt/2, t + dt}, duplicates merged -- sampled before the launch loop
+    calls.clear()
+    # the callback path (table cleared by hand): 4 calls per substep, same bits
+    eng2 = P.HipEngine()
+    eng2._upload_time_table = lambda *a, **k: None
+    sol2 = P.diffeqsolve(eq, P.RK4(), 0.03, 0.03 + 50 * 2e-3, 2e-3, y0, engine=eng2)
+    assert len(calls) == 200
+    np.testing.assert_array_equal(sol.ys[-1], sol2.ys[-1])
+    eng.close()
+    eng2.close()
 
 
 # ----------------------------------------------------------------------------- Shape (shapes.py:21-79)

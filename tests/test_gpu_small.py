@@ -78,12 +78,19 @@ def test_whole_step_kernel_vs_oracle_and_tiled_path(shape, dtype, kind, closures
             else:
                 assert np.max(np.abs(got[b] - ref)) < 1e-6, (kern, b)
                 assert rel_l2(inc_g, inc_w) < inc_tol_f32(ref, y0[b]), (kern, b, rel_l2(inc_g, inc_w))
-        # the tiled stage-pair path (where it covers the shape): the same expressions -> at most an ulp apart
+        # the tiled stage-pair path (where it covers the shape) evaluates the same expressions.  Cahn-Hilliard: every
+        # ambiguous contraction of the flux arithmetic is pinned (stencil_fused.hpp), the two agree to an ulp of the
+        # state and on > 99 % of the cells bitwise.  Allen-Cahn: lap = dxx / hx^2 + dyy / hy^2 is a sum of two products
+        # the compiler may contract either way round per kernel, and kappa lap cancels against mu_h: rounding-level
+        # differences of the INCREMENT.
         tiled, kern_t = _run(eq, y0, integ, dt, n, False, kappas)
-        if "pair" in kern_t:
+        if "pair" in kern_t and kind == "ch":
             ulp = np.spacing(np.abs(tiled).astype(dtype))
             assert np.max(np.abs(got - tiled) / ulp) <= 1.0, (kern, kern_t, float(np.max(np.abs(got - tiled) / ulp)))
             assert np.mean(got != tiled) < 0.01, (kern, kern_t, float(np.mean(got != tiled)))
+        elif "pair" in kern_t:
+            d = rel_l2(got.astype(np.float64) - y0, tiled.astype(np.float64) - y0)
+            assert d < (1e-12 if dtype is np.float64 else 1e-5), (kern, kern_t, d)
 
 
 def test_auto_policy_and_api_path():

@@ -5,8 +5,8 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_INSTS_VALU SQ_INST_CYCLES_SALU --output-format csv -d $OUT/pmc_busy -- python3 $ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-parity-spot --no-api "$@" > $OUT/pmc_busy.log 2>&1
-rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_TRANS --output-format csv -d $OUT/pmc_busy2 -- python3 $ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-parity-spot --no-api "$@" > $OUT/pmc_busy2.log 2>&1
+timeout 400 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_INSTS_VALU SQ_INST_CYCLES_SALU --output-format csv -d $OUT/pmc_busy -- python3 $ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-parity-spot --no-api "$@" > $OUT/pmc_busy.log 2>&1
+timeout 400 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_TRANS --output-format csv -d $OUT/pmc_busy2 -- python3 $ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-parity-spot --no-api "$@" > $OUT/pmc_busy2.log 2>&1
 cd $ROOT
 python3 - <<PY
 import csv, glob, collections
