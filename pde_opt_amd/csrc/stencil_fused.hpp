@@ -46,6 +46,35 @@ __device__ __forceinline__ double uniform_f(double x) {
 
 enum { PAIR_12 = 0, PAIR_34 = 1, PAIR_K = 2 };  // PAIR_K: one stage, out = f(in) (the IMEX slope)
 
+// The scalar neighbours left / right of a thread's 16-byte vector.  Read as ds_read_b32 their lane stride is 4 dwords:
+// the 32 lanes of an access group fall on 8 banks, a 4-way conflict = 8 LDS cycles per wave-instruction, and they are
+// a third of this kernel's LDS cycles (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.36).  PDEOPT_WIDE_NEIGHBOURS reads
+// the whole neighbouring VECTOR instead (ds_read_b128: 4 cycles, conflict-free) and keeps one element; the empty asm
+// stops the compiler from narrowing the load back to the one dword that is used.
+#ifndef PDEOPT_WIDE_NEIGHBOURS
+#define PDEOPT_WIDE_NEIGHBOURS 0
+#endif
+template <typename T, typename Vec, int V>
+__device__ __forceinline__ T nb_left(const T* c_) {
+#if PDEOPT_WIDE_NEIGHBOURS
+  Vec t = *reinterpret_cast<const Vec*>(c_ - V);
+  asm volatile("" : "+v"(t));
+  return t[V - 1];
+#else
+  return c_[-1];
+#endif
+}
+template <typename T, typename Vec, int V>
+__device__ __forceinline__ T nb_right(const T* c_) {
+#if PDEOPT_WIDE_NEIGHBOURS
+  Vec t = *reinterpret_cast<const Vec*>(c_ + V);
+  asm volatile("" : "+v"(t));
+  return t[0];
+#else
+  return c_[V];
+#endif
+}
+
 // Phase-ablation hooks (TIMING ONLY, tools/ablate_pair.sh) are compiled in with -DPDEOPT_PAIR_ABLATE
 // (tools/mkvariant.sh): even as never-taken uniform branches they change hipcc's schedule of the
 // product kernel (96 -> 80 VGPRs, 3 % slower), so the shipped build does not carry them.
@@ -474,7 +503,7 @@ __global__ __launch_bounds__(NT) PDEOPT_PAIR_WAVES_ATTR void stage_pair_kernel(c
       if (lane == 0) left = c_[-1];
       if (lane == 63) right = c_[V];
 #else
-      const T left = c_[-1], right = c_[V];
+      const T left = nb_left<T, Vec, V>(c_), right = nb_right<T, Vec, V>(c_);
       (void)lane;
 #endif
       Vec m;
@@ -504,7 +533,8 @@ __global__ __launch_bounds__(NT) PDEOPT_PAIR_WAVES_ATTR void stage_pair_kernel(c
     return flux_divergence<T, CL, Vec, V>(
         a.mob, p.mob, *reinterpret_cast<const Vec*>(mp - P), *reinterpret_cast<const Vec*>(mp),
         *reinterpret_cast<const Vec*>(mp + P), *reinterpret_cast<const Vec*>(up - P), u_c,
-        *reinterpret_cast<const Vec*>(up + P), mp[-1], mp[V], up[-1], up[V], a.rhx, a.rhy);
+        *reinterpret_cast<const Vec*>(up + P), nb_left<T, Vec, V>(mp), nb_right<T, Vec, V>(mp), nb_left<T, Vec, V>(up),
+        nb_right<T, Vec, V>(up), a.rhx, a.rhy);
   };
 
   // k on the own micro-tile (RPT rows x 1 vector), marching down the rows so every mu / u row is
@@ -541,8 +571,8 @@ __global__ __launch_bounds__(NT) PDEOPT_PAIR_WAVES_ATTR void stage_pair_kernel(c
         dr = eval_mob<T, CL>(a.mob, p.mob, up[V]);
       }
 #else
-      const T ml = mp[-1], mr = mp[V];
-      const T dl = eval_mob<T, CL>(a.mob, p.mob, up[-1]), dr = eval_mob<T, CL>(a.mob, p.mob, up[V]);
+      const T ml = nb_left<T, Vec, V>(mp), mr = nb_right<T, Vec, V>(mp);
+      const T dl = eval_mob<T, CL>(a.mob, p.mob, nb_left<T, Vec, V>(up)), dr = eval_mob<T, CL>(a.mob, p.mob, nb_right<T, Vec, V>(up));
 #endif
       const Vec dy = div_y<T, Vec, V>(m_c, d_c, ml, mr, dl, dr, a.rhy);
       Vec fx_hi, k;

@@ -32,7 +32,39 @@ constexpr size_t sbm_tiled_lds_bytes() {
   return n * sizeof(T);
 }
 
-template <typename T, int EQ>
+// The closures of the smoothed-boundary runs in their fixed forms (FAST): mu_h = cubic [+ logit], mobility = quadratic,
+// f = cubic [+ c ln c + (1 - c) ln(1 - c)] -- the regular-solution model of notebooks/smooth_boundary.ipynb and every
+// reference test; coefficients past n are stored as zeros, so the Horner chains have a fixed length and no loop.
+// closure_generic walks a run-time loop and run-time flag branches per evaluation: 288 lane-instructions per cell and
+// stage against ~140 (SQ_INSTS_VALU, profiles/pmc_r03.json), in a kernel the VALU bounds.
+template <typename T, bool FAST>
+__device__ __forceinline__ T sbm_mu(const StageArgs<T>& a, const EnvParams<T>& p, T c) {
+  if constexpr (!FAST) return closure_generic<T>(a.mu, p.mu, c);
+  T r = ((p.mu[3] * c + p.mu[2]) * c + p.mu[1]) * c + p.mu[0];
+  if (a.mu.flags & PDEOPT_CL_LOGIT_PRIOR) r += t_logit<T>(c);
+  return r;
+}
+template <typename T, bool FAST>
+__device__ __forceinline__ T sbm_fe(const StageArgs<T>& a, const EnvParams<T>& p, T c) {
+  if constexpr (!FAST) return closure_generic<T>(a.fe, p.fe, c);
+  T r = ((p.fe[3] * c + p.fe[2]) * c + p.fe[1]) * c + p.fe[0];
+  if (a.fe.flags & PDEOPT_CL_MIX_ENTROPY) r += c * t_log<T>(c) + (T(1) - c) * t_log<T>(T(1) - c);
+  return r;
+}
+template <typename T, bool FAST>
+__device__ __forceinline__ T sbm_mob(const StageArgs<T>& a, const EnvParams<T>& p, T c) {
+  if constexpr (!FAST) return closure_generic<T>(a.mob, p.mob, c);
+  return (p.mob[2] * c + p.mob[1]) * c + p.mob[0];
+}
+// host: do the three closures have the fixed forms?
+inline bool sbm_fast_closures(const pdeopt_problem& p) {
+  const bool mu = p.mu.kind == PDEOPT_CL_POLY && p.mu.n <= 4 && (p.mu.flags & ~PDEOPT_CL_LOGIT_PRIOR) == 0;
+  const bool mob = p.mob.kind == PDEOPT_CL_POLY && p.mob.n <= 3 && p.mob.flags == 0;
+  const bool fe = p.fe.kind == PDEOPT_CL_POLY && p.fe.n <= 4 && (p.fe.flags & ~PDEOPT_CL_MIX_ENTROPY) == 0;
+  return mu && mob && fe;
+}
+
+template <typename T, int EQ, bool FAST>
 __global__ __launch_bounds__(256) void sbm_tiled_kernel(const StageArgs<T> a, const int tiles_i, const int tiles_j,
                                                         const int nblk, const int xcd_remap) {
   using Vec = typename VecOf<T>::type;
@@ -90,8 +122,8 @@ __global__ __launch_bounds__(256) void sbm_tiled_kernel(const StageArgs<T> a, co
       const T dy_hi = (T(0.5) * (pc[e] + pyp)) * ((yp - c[e]) * a.rhy), dy_lo = (T(0.5) * (pym + pc[e])) * ((c[e] - ym) * a.rhy);
       const T lap = (dx_hi - dx_lo) * a.rhx + (dy_hi - dy_lo) * a.rhy;
       // (fp32: kappa / psi and the square root on the hardware approximations, closures.hpp: t_rcp / t_sqrt)
-      T rr = closure_generic<T>(a.mu, p.mu, c[e]) - (p.kappa * t_rcp<T>(pc[e])) * lap;
-      rr -= w * t_sqrt<T>(T(2) * closure_generic<T>(a.fe, p.fe, c[e]));
+      T rr = sbm_mu<T, FAST>(a, p, c[e]) - (p.kappa * t_rcp<T>(pc[e])) * lap;
+      rr -= w * t_sqrt<T>(T(2) * sbm_fe<T, FAST>(a, p, c[e]));
       out[e] = rr;
     }
     return out;
@@ -132,7 +164,7 @@ __global__ __launch_bounds__(256) void sbm_tiled_kernel(const StageArgs<T> a, co
     if constexpr (!kIsCH) {
       const Vec in00 = inner_vec(tr + HR, cv, ngp, msk);
 #pragma unroll
-      for (int e = 0; e < V; ++e) k[e] = -closure_generic<T>(a.mob, p.mob, c[e]) * in00[e];
+      for (int e = 0; e < V; ++e) k[e] = -sbm_mob<T, FAST>(a, p, c[e]) * in00[e];
     } else {
       const T* q_ = sp + (tr + HR) * P + cv * V;
       const T* n_ = sin + (tr + 1) * P + cv * V;
@@ -142,11 +174,11 @@ __global__ __launch_bounds__(256) void sbm_tiled_kernel(const StageArgs<T> a, co
       const T ul = c_[-1], ur = c_[V], pl = q_[-1], pr = q_[V], il = n_[-1], ir = n_[V];
       Vec d;
 #pragma unroll
-      for (int e = 0; e < V; ++e) d[e] = closure_generic<T>(a.mob, p.mob, c[e]);
-      const T dl = closure_generic<T>(a.mob, p.mob, ul), dr = closure_generic<T>(a.mob, p.mob, ur);
+      for (int e = 0; e < V; ++e) d[e] = sbm_mob<T, FAST>(a, p, c[e]);
+      const T dl = sbm_mob<T, FAST>(a, p, ul), dr = sbm_mob<T, FAST>(a, p, ur);
 #pragma unroll
       for (int e = 0; e < V; ++e) {
-        const T dxp = closure_generic<T>(a.mob, p.mob, uxp[e]), dxm = closure_generic<T>(a.mob, p.mob, uxm[e]);
+        const T dxp = sbm_mob<T, FAST>(a, p, uxp[e]), dxm = sbm_mob<T, FAST>(a, p, uxm[e]);
         const T dyp = (e == V - 1) ? dr : d[e + 1], dym = (e == 0) ? dl : d[e - 1];
         const T pyp = (e == V - 1) ? pr : p00[e + 1], pym = (e == 0) ? pl : p00[e - 1];
         const T inyp = (e == V - 1) ? ir : in00[e + 1], inym = (e == 0) ? il : in00[e - 1];
@@ -202,8 +234,11 @@ int launch_sbm_tiled_eq(pdeopt_ctx* ctx, const StageArgs<T>& s) {
   if (nblk64 > 0x7fffffffLL) return fail(ctx, PDEOPT_EINVAL, "too many tiles");
   const int nblk = (int)nblk64;
   const size_t lds = sbm_tiled_lds_bytes<T, EQ>();
-  hipLaunchKernelGGL((sbm_tiled_kernel<T, EQ>), dim3(nblk), dim3(256), lds, ctx->stream, s, tiles_i, tiles_j, nblk,
-                     tile_flags(nblk, tiles_i, tiles_j));
+  const int flags = tile_flags(nblk, tiles_i, tiles_j);
+  if (sbm_fast_closures(p))
+    hipLaunchKernelGGL((sbm_tiled_kernel<T, EQ, true>), dim3(nblk), dim3(256), lds, ctx->stream, s, tiles_i, tiles_j, nblk, flags);
+  else
+    hipLaunchKernelGGL((sbm_tiled_kernel<T, EQ, false>), dim3(nblk), dim3(256), lds, ctx->stream, s, tiles_i, tiles_j, nblk, flags);
   PDEOPT_HIP_CHECK(ctx, hipGetLastError());
   return PDEOPT_OK;
 }

@@ -1,13 +1,14 @@
 #!/bin/bash
 # Everything the round's evidence comes from, in one gpurun call:
-#   gpurun --timeout 2400 -- 'bash tools/round_end.sh 2>&1 | tail -12'
+#   gpurun --timeout 3000 -- 'timeout 2900 bash tools/round_end.sh 2>&1 | tail -12'
 # GPU test suite -> tools/profile_round.sh (bench lines, kernel traces, PMC traffic) -> tools/pmc_busy.sh (pipe
-# occupancy of the headline kernel) -> tools/valubench.  Afterwards, here: tools/install_profiles.sh <tag>.
+# occupancy of the headline kernel) -> tools/valubench + its PMC calibration.  Afterwards, here: tools/install_profiles.sh <tag>.
 cd ${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p gpurun_out
 timeout 900 python -m pytest tests -q -m gpu > gpurun_out/pytest_gpu.log 2>&1
 grep -E "passed|failed|error" gpurun_out/pytest_gpu.log | tail -2
-timeout 1800 bash tools/profile_round.sh
-[ -x tools/valubench.bin ] && ./tools/valubench.bin > gpurun_out/valubench.txt 2>&1
-[ -x tools/ldsbench.bin ] && ./tools/ldsbench.bin > gpurun_out/ldsbench.txt 2>&1
+timeout 2400 bash tools/profile_round.sh
+[ -x tools/valubench.bin ] && timeout 200 ./tools/valubench.bin > gpurun_out/valubench.txt 2>&1
+[ -x tools/ldsbench.bin ] && timeout 200 ./tools/ldsbench.bin > gpurun_out/ldsbench.txt 2>&1
+timeout 300 python tools/small_grid_bench.py ch > gpurun_out/small_grid_ch.txt 2>&1
 tail -4 gpurun_out/busy_summary.txt | cut -c1-400
