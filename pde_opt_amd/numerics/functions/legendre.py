@@ -61,14 +61,33 @@ class ChemicalPotentialLegendrePolynomials:
         return out
 
     def closure_desc(self) -> ClosureDesc:
+        """The in-kernel form.  The reference accepts ANY callable as ``prior_fn`` (legendre.py:56-74); the kernels
+        carry one non-polynomial prior, ``log(c / (1 - c))``, and a polynomial prior of any degree is folded exactly
+        into the series itself: ``p(c) = sum_k a_k c^k`` with ``c = (x + 1) / 2`` is a polynomial in ``x = 2c - 1``,
+        i.e. a Legendre series (basis change by ``numpy.polynomial.legendre.poly2leg``), added coefficient by
+        coefficient.  So ``prior_fn = lambda c: 2 c``, ``c**3 - c``, ``log(c/(1-c)) + 3 (1 - 2c)`` ... all run
+        in-kernel; priors outside that (sin, exp, a CNN ...) raise ``UnsupportedClosureError``."""
+        from numpy.polynomial import legendre as Lg
+        from numpy.polynomial import polynomial as Pn
+
+        from ..closures import POLY
+
+        params = np.array(self.expansion.params, dtype=np.float64)
         flags = 0
         if self.prior_fn is not None:
             prior = as_closure(self.prior_fn)
-            # the in-kernel family carries exactly one prior: log(c / (1 - c))
-            if not (prior.flags == LOGIT_PRIOR and all(v == 0.0 for v in prior.coef)):
+            if prior.kind != POLY or (prior.flags & ~LOGIT_PRIOR):
                 raise UnsupportedClosureError(
-                    "only the logit prior log(c/(1-c)) can be combined with a Legendre chemical "
-                    "potential in-kernel"
-                )
-            flags = LOGIT_PRIOR
-        return ClosureDesc(LEGENDRE, flags, tuple(float(v) for v in self.expansion.params))
+                    "a Legendre chemical potential can carry a polynomial prior, the logit prior log(c/(1-c)), or "
+                    "their sum in-kernel; this prior_fn is neither")
+            flags = prior.flags & LOGIT_PRIOR
+            a = np.asarray(prior.coef, dtype=np.float64)
+            if np.any(a != 0.0):
+                in_x = np.zeros(1)
+                half_x_plus_1 = np.array([0.5, 0.5])  # c as a polynomial in x
+                for k in range(len(a) - 1, -1, -1):  # Horner in the polynomial ring: p = p * c + a_k
+                    in_x = Pn.polyadd(Pn.polymul(in_x, half_x_plus_1), [a[k]])
+                leg = Lg.poly2leg(in_x)
+                n = max(len(params), len(leg))
+                params = np.pad(params, (0, n - len(params))) + np.pad(leg, (0, n - len(leg)))
+        return ClosureDesc(LEGENDRE, flags, tuple(float(v) for v in params))

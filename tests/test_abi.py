@@ -95,8 +95,15 @@ def test_legendre_closures_match_numpy_legval():
     np.testing.assert_allclose(P.ChemicalPotentialLegendrePolynomials(params)(c), legval(2 * c - 1, params), rtol=1e-5, atol=1e-7)
     chem = P.ChemicalPotentialLegendrePolynomials(np.array([0.3, 0.1, -0.2]), prior_fn=lambda v: 2.0 * v)
     np.testing.assert_allclose(chem(c), legval(2 * c - 1, [0.3, 0.1, -0.2]) + 2.0 * c, rtol=1e-5, atol=1e-7)
+    # the reference takes any callable as prior_fn (legendre.py:56-74): polynomial priors fold exactly into the series,
+    # the logit prior is a flag, their sum is both; anything else is refused loudly
+    cc = np.linspace(0.05, 0.95, 19)
+    np.testing.assert_allclose(chem.closure_desc()(cc), chem(cc), rtol=1e-13)
+    for prior in (lambda v: v**3 - v, lambda v: np.log(v / (1 - v)) + 3 * (1 - 2 * v), lambda v: np.log(v / (1 - v))):
+        ch = P.ChemicalPotentialLegendrePolynomials(np.array([0.3, 0.1, -0.2, 0.05]), prior_fn=prior)
+        np.testing.assert_allclose(ch.closure_desc()(cc), ch(cc), rtol=1e-12, atol=1e-13)
     with pytest.raises(P.UnsupportedClosureError):
-        chem.closure_desc()  # only the logit prior is in the in-kernel family
+        P.ChemicalPotentialLegendrePolynomials(np.array([0.3, 0.1]), prior_fn=lambda v: np.sin(v)).closure_desc()
 
 
 def test_domain_matches_reference_golden(golden):

@@ -14,4 +14,6 @@ python tools/pmc_to_json.py ch_imex_1024_f32 ${TAG} "stage_pair_kernel|imex_row_
 python tools/pmc_to_json.py gpe_strang_512_c64 ${TAG} "strang_row_reg_kernel|strang_col_reg_kernel" $R/pmc_gpe_strang_512_c64/pmc_fetch $R/pmc_gpe_strang_512_c64/pmc_write $R/pmc_gpe_strang_512_c64/pmc_valu > /dev/null 2>&1
 python tools/pmc_to_json.py ch_rk4_1024_f64 ${TAG} "stage_pair_kernel" $R/pmc_ch_rk4_1024_f64/pmc_fetch $R/pmc_ch_rk4_1024_f64/pmc_write $R/pmc_ch_rk4_1024_f64/pmc_valu > /dev/null 2>&1
 python tools/pmc_to_json.py ch_rk4_64_f32_small ${TAG} "small_persist_kernel" $R/pmc_ch_rk4_64_f32_small/pmc_fetch $R/pmc_ch_rk4_64_f32_small/pmc_write $R/pmc_ch_rk4_64_f32_small/pmc_valu > /dev/null 2>&1
+python tools/pmc_to_json.py ch_rk4_128_f32_small ${TAG} "small_persist_kernel" $R/pmc_ch_rk4_128_f32_small/pmc_fetch $R/pmc_ch_rk4_128_f32_small/pmc_write $R/pmc_ch_rk4_128_f32_small/pmc_valu > /dev/null 2>&1
+python tools/pmc_to_json.py ac_rk4_64_f32_small ${TAG} "small_persist_kernel" $R/pmc_ac_rk4_64_f32_small/pmc_fetch $R/pmc_ac_rk4_64_f32_small/pmc_write $R/pmc_ac_rk4_64_f32_small/pmc_valu > /dev/null 2>&1
 python tools/pmc_to_json.py ch_sbm_1024_f32 ${TAG} "sbm_tiled_kernel" $R/pmc_ch_sbm_1024_f32/pmc_fetch $R/pmc_ch_sbm_1024_f32/pmc_write $R/pmc_ch_sbm_1024_f32/pmc_valu > /dev/null 2>&1
