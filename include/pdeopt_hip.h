@@ -381,6 +381,36 @@ int pdeopt_tsit5_commit_env(pdeopt_ctx* ctx, const uint8_t* accept);
  * evaluates for SaveAt(ts=...) points that fall inside a step (tests/test_solvers.py:86-96 saves 200 of them). */
 int pdeopt_tsit5_dense(pdeopt_ctx* ctx, double theta, double dt, int env_first, int env_count, void* host_out);
 
+/* The whole adaptive solve t0 -> t1 in ONE launch, controller included, for grids that fit a compute unit's LDS
+ * (Cahn-Hilliard / Allen-Cahn, FD, analytic closure classes; up to 2048 vectors of 16 bytes per environment: 64 x 128
+ * in fp32, 64 x 64 in fp64).  Replaces, for those grids, the host loop the reference runs through
+ * diffrax.diffeqsolve(..., Tsit5(), stepsize_controller=PIDController(rtol, atol, ...)) (pde_opt/pde_model.py:100-118;
+ * tests/test_solvers.py:81,263): trial step, scaled RMS error norm, PID factor, accept / reject and dense output all
+ * happen inside the kernel, one workgroup per environment.  EVERY ENVIRONMENT RUNS ITS OWN CONTROLLER -- what batch == 1
+ * and PIDController(per_environment=True) mean; a step size shared by several environments is the caller's loop over
+ * pdeopt_tsit5_trial / pdeopt_tsit5_commit.
+ *   pid        diffrax.PIDController's fields; dtmin = -HUGE_VAL / dtmax = HUGE_VAL for "none"
+ *   max_steps  trial steps (accepted + rejected) per environment; an environment that reaches it stops where it is
+ *              (status PDEOPT_TSIT5_MAX_STEPS), as does one whose step can no longer advance t (PDEOPT_TSIT5_STALLED)
+ *   save_ts    n_save ascending times in (t0, t1]; host_save [n_save][batch][nx][ny] receives the 4th-order dense
+ *              output there (slots an environment never reached are NaN)
+ *   stats      [batch]
+ * Returns PDEOPT_EINVAL, leaving the state untouched, when the configured problem is not one the kernel takes
+ * (ask pdeopt_tsit5_solve_small_supported first). */
+typedef struct {
+  double rtol, atol, pcoeff, icoeff, dcoeff, dtmin, dtmax, factormin, factormax, safety;
+} pdeopt_pid;
+typedef enum { PDEOPT_TSIT5_DONE = 0, PDEOPT_TSIT5_MAX_STEPS = 1, PDEOPT_TSIT5_STALLED = 2 } pdeopt_tsit5_status;
+typedef struct {
+  double t, dt;               /* where the environment stopped; the step size the controller would try next */
+  int64_t accepted, rejected; /* trial steps */
+  int32_t status;             /* pdeopt_tsit5_status */
+  int32_t saved;              /* save points written */
+} pdeopt_tsit5_stats;
+int pdeopt_tsit5_solve_small_supported(pdeopt_ctx* ctx);
+int pdeopt_tsit5_solve_small(pdeopt_ctx* ctx, double t0, double t1, double dt0, const pdeopt_pid* pid, int64_t max_steps,
+                             int n_save, const double* save_ts, void* host_save, pdeopt_tsit5_stats* stats);
+
 /* ---- timing / sync ------------------------------------------------------------------------- */
 int pdeopt_sync(pdeopt_ctx* ctx);
 int pdeopt_timer_start(pdeopt_ctx* ctx);           /* hipEventRecord on the ctx stream */

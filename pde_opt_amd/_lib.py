@@ -102,6 +102,19 @@ _VP = C.c_void_p
 TIME_FN = C.CFUNCTYPE(None, C.c_double, C.POINTER(C.c_double), C.c_void_p)
 # pdeopt_aux_fn: int (*)(double t, int which, void* host_out, void* user)
 AUX_FN = C.CFUNCTYPE(C.c_int, C.c_double, C.c_int, C.c_void_p, C.c_void_p)
+class Pid(C.Structure):
+    """pdeopt_pid (include/pdeopt_hip.h)"""
+    _fields_ = [(n, C.c_double) for n in ("rtol", "atol", "pcoeff", "icoeff", "dcoeff", "dtmin", "dtmax", "factormin", "factormax", "safety")]
+
+
+class Tsit5Stats(C.Structure):
+    """pdeopt_tsit5_stats (include/pdeopt_hip.h)"""
+    _fields_ = [("t", C.c_double), ("dt", C.c_double), ("accepted", C.c_int64), ("rejected", C.c_int64), ("status", C.c_int32),
+                ("saved", C.c_int32)]
+
+
+TSIT5_DONE, TSIT5_MAX_STEPS, TSIT5_STALLED = 0, 1, 2
+
 _SIGNATURES = {
     "pdeopt_abi_version": (C.c_int, []),
     "pdeopt_device_count": (C.c_int, [C.POINTER(C.c_int)]),
@@ -136,6 +149,8 @@ _SIGNATURES = {
     "pdeopt_tsit5_trial_env": (C.c_int, [_VP, C.c_double, _VP, C.c_double, C.c_double, C.POINTER(C.c_double), _VP]),
     "pdeopt_tsit5_commit_env": (C.c_int, [_VP, _VP]),
     "pdeopt_tsit5_dense": (C.c_int, [_VP, C.c_double, C.c_double, C.c_int, C.c_int, _VP]),
+    "pdeopt_tsit5_solve_small_supported": (C.c_int, [_VP]),
+    "pdeopt_tsit5_solve_small": (C.c_int, [_VP, C.c_double, C.c_double, C.c_double, _VP, C.c_int64, C.c_int, _VP, _VP, _VP]),
     "pdeopt_halo_strip_elems": (C.c_int, [_VP, C.POINTER(C.c_int64)]),
     "pdeopt_halo_pack": (C.c_int, [_VP, C.c_int, _VP]),
     "pdeopt_halo_unpack": (C.c_int, [_VP, C.c_int, _VP, C.POINTER(C.c_int)]),

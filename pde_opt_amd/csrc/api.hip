@@ -728,6 +728,30 @@ int pdeopt_tsit5_trial(pdeopt_ctx* ctx, double t, double dt, double rtol, double
   return tsit5_trial(ctx, t, dt, rtol, atol, err_norm);
 }
 
+int pdeopt_tsit5_solve_small_supported(pdeopt_ctx* ctx) {
+  return ctx && ctx->configured && ctx->prob.equation != PDEOPT_EQ_GPE && tsit5_solve_small_supported(ctx) ? 1 : 0;
+}
+
+int pdeopt_tsit5_solve_small(pdeopt_ctx* ctx, double t0, double t1, double dt0, const pdeopt_pid* pid, int64_t max_steps,
+                             int n_save, const double* save_ts, void* host_save, pdeopt_tsit5_stats* stats) {
+  if (!ctx) return PDEOPT_EINVAL;
+  if (!ctx->configured) return fail(ctx, PDEOPT_ESTATE, "pdeopt_configure has not been called");
+  if (!pid || !stats || n_save < 0 || (n_save > 0 && (!save_ts || !host_save)))
+    return fail(ctx, PDEOPT_EINVAL, "pdeopt_tsit5_solve_small: null argument");
+  if (!(max_steps > 0)) return fail(ctx, PDEOPT_EINVAL, "max_steps must be positive");
+  if (!(dt0 > 0) || !(t1 >= t0)) return fail(ctx, PDEOPT_EINVAL, "need dt0 > 0 and t1 >= t0");
+  if (!(pid->rtol >= 0) || !(pid->atol >= 0) || !(pid->rtol + pid->atol > 0))
+    return fail(ctx, PDEOPT_EINVAL, "need rtol, atol >= 0, not both zero");
+  if (!(pid->factormin > 0) || !(pid->factormax >= pid->factormin) || !(pid->safety > 0))
+    return fail(ctx, PDEOPT_EINVAL, "need 0 < factormin <= factormax and safety > 0");
+  for (int q = 0; q < n_save; ++q)
+    if (!(save_ts[q] > t0) || (q && !(save_ts[q] >= save_ts[q - 1])))
+      return fail(ctx, PDEOPT_EINVAL, "save_ts must be ascending and > t0");
+  PDEOPT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  ctx->kscale_prev.clear();
+  return tsit5_solve_small(ctx, t0, t1, dt0, pid, max_steps, n_save, save_ts, host_save, stats);
+}
+
 int pdeopt_tsit5_trial_env(pdeopt_ctx* ctx, double t, const double* dt, double rtol, double atol, double* dt_ref,
                            double* err_norm) {
   if (!ctx || !dt || !dt_ref) return PDEOPT_EINVAL;

@@ -258,6 +258,9 @@ int tsit5_commit(pdeopt_ctx* ctx, int accept);
 int tsit5_dense(pdeopt_ctx* ctx, double theta, double dt, int env_first, int env_count, void* dev_out);
 int tsit5_commit_env(pdeopt_ctx* ctx, const uint8_t* accept);
 int tsit5_rescale_fsal(pdeopt_ctx* ctx, const double* ratio);  // K[0] of environment b *= ratio[b]
+bool tsit5_solve_small_supported(const pdeopt_ctx* ctx);
+int tsit5_solve_small(pdeopt_ctx* ctx, double t0, double t1, double dt0, const pdeopt_pid* pid, int64_t max_steps, int n_save,
+                      const double* save_ts, void* save_host, pdeopt_tsit5_stats* stats);
 void graph_destroy(pdeopt_ctx* ctx);
 int launch_lerp(pdeopt_ctx* ctx, const void* a, const void* b, void* out, double theta,
                 size_t env_first, size_t env_count);

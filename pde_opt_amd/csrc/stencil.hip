@@ -15,6 +15,7 @@
 #include "stencil_fused_ac4.hpp"
 #include "stencil_fused_launch.hpp"
 #include "stencil_small.hpp"
+#include "stencil_small_adaptive.hpp"
 #include "stencil_sbm_tiled.hpp"
 
 namespace pdeopt {
@@ -627,21 +628,6 @@ int rk4_substep_h8(pdeopt_ctx* ctx, double dt, void* strip, const void* recv, co
 // ------------------------------------------------------------------------------------------
 namespace {
 
-constexpr double kTsA[6][6] = {
-    {0.161, 0, 0, 0, 0, 0},
-    {-0.008480655492356989, 0.335480655492357, 0, 0, 0, 0},
-    {2.8971530571054935, -6.359448489975075, 4.3622954328695815, 0, 0, 0},
-    {5.325864828439257, -11.748883564062828, 7.4955393428898365, -0.09249506636175525, 0, 0},
-    {5.86145544294642, -12.92096931784711, 8.159367898576159, -0.071584973281401,
-     -0.028269050394068383, 0},
-    {0.09646076681806523, 0.01, 0.4798896504144996, 1.379008574103742, -3.290069515436081,
-     2.324710524099774}};
-// abscissae of stages 2..7 (row sums of kTsA)
-constexpr double kTsC[6] = {0.161, 0.327, 0.9, 0.9800255409045097, 1.0, 1.0};
-constexpr double kTsE[7] = {0.00178001105222577714, 0.0008164344596567469, -0.007880878010261995,
-                            0.1447110071732629,     -0.5823571654525552,   0.45808210592918697,
-                            -1.0 / 66.0};
-
 template <typename T>
 struct LinComb {
   const T* y;
@@ -765,18 +751,6 @@ int tsit5_trial(pdeopt_ctx* ctx, double t, double dt, double rtol, double atol, 
                                        : tsit5_trial_t<double>(ctx, t, dt, rtol, atol, err);
 }
 
-// b_i(theta) of the 4th-order continuous extension (Tsitouras 2011, section 4); b_i(1) = the 5th-order weights
-static void tsit5_dense_weights(double th, double* b) {
-  const double t2 = th * th;
-  b[0] = -1.0530884977290216 * th * (th - 1.3299890189751412) * (t2 - 1.4364028541716351 * th + 0.7139816917074209);
-  b[1] = 0.1017 * t2 * (t2 - 2.1966568338249754 * th + 1.2949852507374631);
-  b[2] = 2.490627285651252793 * t2 * (t2 - 2.38535645472061657 * th + 1.57803468208092486);
-  b[3] = -16.54810288924490272 * (th - 1.21712927295533244) * (th - 0.61620406037800089) * t2;
-  b[4] = 47.37952196281928122 * (th - 1.203071208372362603) * (th - 0.658047292653547382) * t2;
-  b[5] = -34.87065786149660974 * (th - 1.2) * (th - 0.666666666666666667) * t2;
-  b[6] = 2.5 * (th - 1.0) * (th - 0.6) * t2;
-}
-
 template <typename T>
 static int tsit5_dense_t(pdeopt_ctx* ctx, double theta, double dt, int env_first, int env_count, void* dev_out) {
   double b[7];
@@ -852,6 +826,18 @@ int tsit5_commit(pdeopt_ctx* ctx, int accept) {
   }
   ctx->tsit5_fsal_valid = true;         // on rejection K[0] = f(t, y) is still valid
   return PDEOPT_OK;
+}
+
+bool tsit5_solve_small_supported(const pdeopt_ctx* ctx) {
+  return ctx->prob.dtype == PDEOPT_F32 ? small_tsit5_supported<float>(ctx) : small_tsit5_supported<double>(ctx);
+}
+
+int tsit5_solve_small(pdeopt_ctx* ctx, double t0, double t1, double dt0, const pdeopt_pid* pid, int64_t max_steps, int n_save,
+                      const double* save_ts, void* save_host, pdeopt_tsit5_stats* stats) {
+  if (!tsit5_solve_small_supported(ctx))
+    return fail(ctx, PDEOPT_EINVAL, "the in-kernel adaptive solve takes LDS-resident Cahn-Hilliard / Allen-Cahn FD problems only");
+  return ctx->prob.dtype == PDEOPT_F32 ? small_tsit5_solve<float>(ctx, t0, t1, dt0, pid, max_steps, n_save, save_ts, save_host, stats)
+                                       : small_tsit5_solve<double>(ctx, t0, t1, dt0, pid, max_steps, n_save, save_ts, save_host, stats);
 }
 
 int launch_lerp(pdeopt_ctx* ctx, const void* a, const void* b, void* out, double theta,

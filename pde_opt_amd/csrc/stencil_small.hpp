@@ -44,76 +44,91 @@ struct SmallArgs {
   ClosureSpec mu, mob;
 };
 
-template <typename T, int EQ, int CL, int KMAX, int NTMAX>
-__global__ __launch_bounds__(NTMAX) void small_persist_kernel(const SmallArgs<T> a) {
+// What a workgroup keeps for its environment: the LDS arrays, the LDS offsets of the thread's vectors and the folded
+// constants; `stage` = one right-hand-side evaluation on the owned vectors + whatever the integrator does with it.
+// Shared by the fixed-step kernel below and the adaptive Tsit5 kernel (stencil_small_adaptive.hpp).
+template <typename T, int EQ, int CL, int KMAX>
+struct SmallTile {
   using Vec = typename VecOf<T>::type;
-  constexpr int V = VecOf<T>::V;
-  constexpr bool kIsCH = EQ == PDEOPT_EQ_CAHN_HILLIARD;
+  static constexpr int V = VecOf<T>::V;
+  static constexpr bool kIsCH = EQ == PDEOPT_EQ_CAHN_HILLIARD;
+  static constexpr bool FOLD_MU = PDEOPT_PAIR_FOLD_MU && CL == CL_LOGIT1;
 
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  const int nx = a.nx, ny = a.ny;
-  const int cells = nx * ny;
-  T* const sU = reinterpret_cast<T*>(smem_raw);
-  T* const sMu = sU + cells;  // CH only
-
-  const int b = blockIdx.x;
-  const EnvParams<T>& p = a.ep[b];
-  T* const yg = a.y + (int64_t)b * a.bstride;
-  const T kap = p.kappa;
-
-  const int tid = threadIdx.x, NT = blockDim.x;
-  const int nvr = ny / V;          // vectors per row
-  const int nvec = nx * nvr;
-
+  T* sU;
+  T* sMu;  // CH only
+  int ny, cells;
   // owned vectors: the LDS offset of the centre; the rows above / below and the scalar neighbours left / right
   // (periodic) are re-derived from it where they are used -- two instructions each instead of four more registers
-  // per vector (a thread keeps y, the RK accumulator and the next stage input of up to KMAX vectors in registers)
-  constexpr bool YG = false;  // (y in global memory: measured variant, not needed with the 512-thread form)
+  // per vector (a thread keeps y and the integrator's slopes of up to KMAX vectors in registers)
   int oc[KMAX];
-  unsigned cflags = 0;  // bit 3k: owned, bit 3k + 1: first vector of its row, bit 3k + 2: last vector of its row
-  Vec y[YG ? 1 : KMAX], acc[KMAX], w[KMAX];
+  unsigned cflags;  // bit 3k: owned, bit 3k + 1: first vector of its row, bit 3k + 2: last vector of its row
+  const EnvParams<T>* p;
+  ClosureSpec mu, mob;
+  T kap, rhx, rhy, rhx2, rhy2, fA, fB, q1;
+
+  // map the thread's vectors, copy the environment's state y0 (global) into sU and into yout[]
+  __device__ __forceinline__ void init(char* smem, int nx, int ny_, const EnvParams<T>* ep, ClosureSpec mu_, ClosureSpec mob_, T rhx_,
+                                       T rhy_, T rhx2_, T rhy2_, const T* yg, Vec* yout) {
+    ny = ny_;
+    cells = nx * ny_;
+    sU = reinterpret_cast<T*>(smem);
+    sMu = sU + cells;
+    p = ep;
+    mu = mu_; mob = mob_;
+    kap = ep->kappa; rhx = rhx_; rhy = rhy_; rhx2 = rhx2_; rhy2 = rhy2_;
+    fA = fB = q1 = T(0);
+    // mu = mu_h(c) - kappa lap c: the linear-logit class in the folded form of stencil_fused.hpp (FOLD_MU)
+    if constexpr (FOLD_MU) {
+      fA = -kap * rhx2;
+      fB = -kap * rhy2;
+      q1 = ep->mu[1] - T(2) * (fA + fB);
+    }
+    const int tid = threadIdx.x, NT = blockDim.x;
+    const int nvr = ny / V;  // vectors per row
+    const int nvec = nx * nvr;
+    cflags = 0;
 #pragma unroll
-  for (int k = 0; k < KMAX; ++k) {
-    // A thread whose k-th vector index runs past the environment works on the LAST vector instead: the same inputs,
-    // the same arithmetic, the same values stored to the same LDS words as that vector's real owner -- straight-line
-    // stage code for every thread (with `if (owned)` around each vector the register allocator kept both arms'
-    // values alive and spilled: 1.2 KB of scratch at 8 vectors per thread); only the final store to global memory
-    // is the owner's alone.
-    const int vid = tid + k * NT;
-    const bool mine = vid < nvec;
-    const int v = mine ? vid : nvec - 1;
-    const int row = v / nvr, cv = v - row * nvr;
-    oc[k] = row * ny + cv * V;
-    cflags |= (mine ? 1u : 0u) << (3 * k) | (cv == 0 ? 1u : 0u) << (3 * k + 1) | (cv == nvr - 1 ? 1u : 0u) << (3 * k + 2);
-    acc[k] = Vec{};
-    w[k] = Vec{};
-    if constexpr (!YG) y[k] = Vec{};
-    {
+    for (int k = 0; k < KMAX; ++k) {
+      // A thread whose k-th vector index runs past the environment works on the LAST vector instead: the same inputs,
+      // the same arithmetic, the same values stored to the same LDS words as that vector's real owner -- straight-line
+      // stage code for every thread (with `if (owned)` around each vector the register allocator kept both arms'
+      // values alive and spilled: 1.2 KB of scratch at 8 vectors per thread); only stores to global memory are the
+      // owner's alone.
+      const int vid = tid + k * NT;
+      const bool mine = vid < nvec;
+      const int v = mine ? vid : nvec - 1;
+      const int row = v / nvr, cv = v - row * nvr;
+      oc[k] = row * ny + cv * V;
+      cflags |= (mine ? 1u : 0u) << (3 * k) | (cv == 0 ? 1u : 0u) << (3 * k + 1) | (cv == nvr - 1 ? 1u : 0u) << (3 * k + 2);
       const Vec y0 = *reinterpret_cast<const Vec*>(yg + oc[k]);
       *reinterpret_cast<Vec*>(sU + oc[k]) = y0;
-      if constexpr (!YG) y[k] = y0;
+      yout[k] = y0;
     }
+    __syncthreads();
   }
-  auto own = [&](int k) { return (cflags >> (3 * k)) & 1u; };
-  auto up_of = [&](int o) { const int r = o + ny; return r >= cells ? r - cells : r; };  // row + 1
-  auto dn_of = [&](int o) { const int r = o - ny; return r < 0 ? r + cells : r; };       // row - 1
-  auto left_of = [&](int o, int k) { return o - 1 + (((cflags >> (3 * k + 1)) & 1u) ? ny : 0); };
-  auto right_of = [&](int o, int k) { return o + V - (((cflags >> (3 * k + 2)) & 1u) ? ny : 0); };
-  __syncthreads();
-
-  // mu = mu_h(c) - kappa lap c: the linear-logit class in the folded form of stencil_fused.hpp (FOLD_MU)
-  constexpr bool FOLD_MU = PDEOPT_PAIR_FOLD_MU && CL == CL_LOGIT1;
-  T fA = T(0), fB = T(0), q1 = T(0);
-  if constexpr (FOLD_MU) {
-    fA = -kap * a.rhx2;
-    fB = -kap * a.rhy2;
-    q1 = p.mu[1] - T(2) * (fA + fB);
-  }
+  __device__ __forceinline__ bool own(int k) const { return (cflags >> (3 * k)) & 1u; }
+  __device__ __forceinline__ int up_of(int o) const { const int r = o + ny; return r >= cells ? r - cells : r; }  // row + 1
+  __device__ __forceinline__ int dn_of(int o) const { const int r = o - ny; return r < 0 ? r + cells : r; }       // row - 1
+  __device__ __forceinline__ int left_of(int o, int k) const { return o - 1 + (((cflags >> (3 * k + 1)) & 1u) ? ny : 0); }
+  __device__ __forceinline__ int right_of(int o, int k) const { return o + V - (((cflags >> (3 * k + 2)) & 1u) ? ny : 0); }
 
   // One Runge-Kutta stage: k = f(w) on the owned vectors (w in sU), `update(j, k_j)` applied to each while it is in
   // registers, then the next stage input `next` published.  The vectors of a thread are processed ONE AFTER THE
-  // OTHER (scheduling barriers): interleaved, their ~40 transient registers each would not fit beside the state.
-  auto stage = [&](auto update, const Vec* next) {
+  // OTHER (scheduling barriers): interleaved, their ~70 transient registers each would not fit beside the state.
+  template <typename U>
+  __device__ __forceinline__ void stage(U update, const Vec* next) {
+    rhs(update);
+    publish(next);
+  }
+  // the next stage input into sU, once every read of the current one is done
+  __device__ __forceinline__ void publish(const Vec* next) {
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) *reinterpret_cast<Vec*>(sU + oc[k]) = next[k];
+    __syncthreads();
+  }
+  template <typename U>
+  __device__ __forceinline__ void rhs(U update) {
     if constexpr (kIsCH) {
 #pragma unroll
       for (int k = 0; k < KMAX; ++k) {
@@ -129,27 +144,25 @@ __global__ __launch_bounds__(NTMAX) void small_persist_kernel(const SmallArgs<T>
             const T ym = (e == 0) ? left : c[e - 1];
             const T yp = (e == V - 1) ? right : c[e + 1];
             if constexpr (FOLD_MU)
-              m[e] = fA * (xp[e] + xm[e]) + (fB * (yp + ym) + (q1 * c[e] + p.mu[0] + t_logit<T>(c[e])));
+              m[e] = fA * (xp[e] + xm[e]) + (fB * (yp + ym) + (q1 * c[e] + p->mu[0] + t_logit<T>(c[e])));
             else
-              m[e] = eval_mu<T, CL>(a.mu, p.mu, c[e]) - kap * lap_at<T>(c[e], xp[e], xm[e], yp, ym, a.rhx2, a.rhy2);
+              m[e] = eval_mu<T, CL>(mu, p->mu, c[e]) - kap * lap_at<T>(c[e], xp[e], xm[e], yp, ym, rhx2, rhy2);
           }
           *reinterpret_cast<Vec*>(sMu + o) = m;
         }
-        if constexpr (KMAX > 2) __builtin_amdgcn_sched_barrier(0);  // one vector at a time: see `stage`
+        if constexpr (KMAX > 2) __builtin_amdgcn_sched_barrier(0);  // one vector at a time
       }
       __syncthreads();
 #pragma unroll
       for (int k = 0; k < KMAX; ++k) {
         {
           const int o = oc[k], ou = up_of(o), od = dn_of(o), ol = left_of(o, k), orr = right_of(o, k);
-          Vec yk;
-          if constexpr (YG) yk = *reinterpret_cast<const Vec*>(yg + o); else yk = y[k];
           const Vec kv = flux_divergence<T, CL, Vec, V>(
-              a.mob, p.mob, *reinterpret_cast<const Vec*>(sMu + od), *reinterpret_cast<const Vec*>(sMu + o),
+              mob, p->mob, *reinterpret_cast<const Vec*>(sMu + od), *reinterpret_cast<const Vec*>(sMu + o),
               *reinterpret_cast<const Vec*>(sMu + ou), *reinterpret_cast<const Vec*>(sU + od),
-              *reinterpret_cast<const Vec*>(sU + o), *reinterpret_cast<const Vec*>(sU + ou), sMu[ol], sMu[orr], sU[ol], sU[orr],
-              a.rhx, a.rhy);
-          update(k, kv, yk);
+              *reinterpret_cast<const Vec*>(sU + o), *reinterpret_cast<const Vec*>(sU + ou), sMu[ol], sMu[orr], sU[ol], sU[orr], rhx,
+              rhy);
+          update(k, kv);
         }
         if constexpr (KMAX > 2) __builtin_amdgcn_sched_barrier(0);
       }
@@ -159,8 +172,6 @@ __global__ __launch_bounds__(NTMAX) void small_persist_kernel(const SmallArgs<T>
       for (int k = 0; k < KMAX; ++k) {
         {
           const int o = oc[k];
-          Vec yk;
-          if constexpr (YG) yk = *reinterpret_cast<const Vec*>(yg + o); else yk = y[k];
           const Vec c = *reinterpret_cast<const Vec*>(sU + o);
           const Vec xp = *reinterpret_cast<const Vec*>(sU + up_of(o));
           const Vec xm = *reinterpret_cast<const Vec*>(sU + dn_of(o));
@@ -170,43 +181,48 @@ __global__ __launch_bounds__(NTMAX) void small_persist_kernel(const SmallArgs<T>
           for (int e = 0; e < V; ++e) {
             const T ym = (e == 0) ? left : c[e - 1];
             const T yp = (e == V - 1) ? right : c[e + 1];
-            const T mu = eval_mu<T, CL>(a.mu, p.mu, c[e]) - kap * lap_at<T>(c[e], xp[e], xm[e], yp, ym, a.rhx2, a.rhy2);
-            r[e] = -eval_mob<T, CL>(a.mob, p.mob, c[e]) * mu;
+            const T m = eval_mu<T, CL>(mu, p->mu, c[e]) - kap * lap_at<T>(c[e], xp[e], xm[e], yp, ym, rhx2, rhy2);
+            r[e] = -eval_mob<T, CL>(mob, p->mob, c[e]) * m;
           }
-          update(k, r, yk);
+          update(k, r);
         }
         if constexpr (KMAX > 2) __builtin_amdgcn_sched_barrier(0);
       }
     }
-    __syncthreads();  // every read of this stage's w is done: sU may take the next stage input
-#pragma unroll
-    for (int k = 0; k < KMAX; ++k) *reinterpret_cast<Vec*>(sU + oc[k]) = next[k];
-    __syncthreads();
-  };
+  }
+};
 
-  // the new state of vector k: into the registers (and, with y in global memory, back to its owner's cells there)
-  auto set_y = [&](int k, const Vec v) {
-    w[k] = v;
-    if constexpr (YG) *reinterpret_cast<Vec*>(yg + oc[k]) = v; else y[k] = v;
-  };
+template <typename T, int EQ, int CL, int KMAX, int NTMAX>
+__global__ __launch_bounds__(NTMAX) void small_persist_kernel(const SmallArgs<T> a) {
+  using Tile = SmallTile<T, EQ, CL, KMAX>;
+  using Vec = typename Tile::Vec;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const int b = blockIdx.x;
+  T* const yg = a.y + (int64_t)b * a.bstride;
+  Tile tile;
+  Vec y[KMAX], acc[KMAX], w[KMAX];
+  tile.init(smem_raw, a.nx, a.ny, a.ep + b, a.mu, a.mob, a.rhx, a.rhy, a.rhx2, a.rhy2, yg, y);
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k) {
+    acc[k] = Vec{};
+    w[k] = Vec{};
+  }
   for (int64_t s = 0; s < a.n; ++s) {
     if (a.rk4) {
       // the update formulas of the stage-pair kernels, in their association (stencil_fused.hpp: PAIR_12 / PAIR_34):
       //   w2 = y + dt/2 k1,  acc = y + dt/6 k1;   w3 = y + dt/2 k2,  acc += dt/3 k2;
       //   w4 = y + dt k3,    acc += dt/3 k3;      y' = acc + dt/6 k4
-      stage([&](int k, const Vec kv, const Vec yk) { w[k] = yk + a.h2 * kv; acc[k] = yk + a.h6 * kv; }, w);
-      stage([&](int k, const Vec kv, const Vec yk) { w[k] = yk + a.h2 * kv; acc[k] = acc[k] + a.h3 * kv; }, w);
-      stage([&](int k, const Vec kv, const Vec yk) { w[k] = yk + a.dt * kv; acc[k] = acc[k] + a.h3 * kv; }, w);
-      stage([&](int k, const Vec kv, const Vec) { set_y(k, acc[k] + a.h6 * kv); }, w);
+      tile.stage([&](int k, const Vec kv) { w[k] = y[k] + a.h2 * kv; acc[k] = y[k] + a.h6 * kv; }, w);
+      tile.stage([&](int k, const Vec kv) { w[k] = y[k] + a.h2 * kv; acc[k] = acc[k] + a.h3 * kv; }, w);
+      tile.stage([&](int k, const Vec kv) { w[k] = y[k] + a.dt * kv; acc[k] = acc[k] + a.h3 * kv; }, w);
+      tile.stage([&](int k, const Vec kv) { y[k] = acc[k] + a.h6 * kv; }, y);
     } else {
-      stage([&](int k, const Vec kv, const Vec yk) { set_y(k, yk + a.dt * kv); }, w);
+      tile.stage([&](int k, const Vec kv) { y[k] = y[k] + a.dt * kv; }, y);
     }
   }
-  if constexpr (!YG) {
 #pragma unroll
-    for (int k = 0; k < KMAX; ++k)
-      if (own(k)) *reinterpret_cast<Vec*>(yg + oc[k]) = y[k];
-  }
+  for (int k = 0; k < KMAX; ++k)
+    if (tile.own(k)) *reinterpret_cast<Vec*>(yg + tile.oc[k]) = y[k];
 }
 
 // --------------------------------------------------------------------------------------------- host
@@ -226,6 +242,19 @@ constexpr int kSmallMaxVec = 8 * 512;  // vectors of one environment: 8 per thre
 constexpr int64_t kSmallAutoCells = 4096;  // up to 64^2: always
 constexpr int kSmallAutoBatch = 192;       // larger LDS-resident grids: from this many environments on
 
+// The grid as the kernel walks it.  An (nx, 1) column -- the reference's 1-D runs (tests/test_solvers.py:25,68: 256 x 1)
+// -- is the same memory as a (1, nx) row, and the kernel's vectors run along rows: walk it as the row.  The direction
+// with one point contributes differences of a value with itself; its reciprocal spacing is set to 0 so that the zero
+// stays a zero whatever the domain's extent there.
+struct SmallDims {
+  int nx, ny;
+  double rx2, ry2;  // 1 / hx^2, 1 / hy^2
+};
+inline SmallDims small_dims(const pdeopt_problem& p) {
+  if (p.ny == 1 && p.nx > 1) return {1, p.nx, 0.0, 1.0 / (p.hx * p.hx)};
+  return {p.nx, p.ny, p.nx > 1 ? 1.0 / (p.hx * p.hx) : 0.0, p.ny > 1 ? 1.0 / (p.hy * p.hy) : 0.0};
+}
+
 // can the whole-step kernel run this problem at all?
 template <typename T>
 bool small_supported(const pdeopt_ctx* ctx) {
@@ -233,10 +262,11 @@ bool small_supported(const pdeopt_ctx* ctx) {
   const pdeopt_problem& p = ctx->prob;
   if (p.equation != PDEOPT_EQ_CAHN_HILLIARD && p.equation != PDEOPT_EQ_ALLEN_CAHN) return false;
   if (p.derivs != PDEOPT_DERIVS_FD || ctx->halo || p.nz > 1) return false;
-  if (p.ny % V != 0 || p.nx < 1) return false;
+  const SmallDims d = small_dims(p);
+  if (d.ny % V != 0 || d.nx < 1) return false;
   if (classify_closures(p.mu, p.mob) == CL_GENERIC) return false;
   if (small_lds_bytes<T>(ctx) > kSmallLdsMax) return false;
-  const int64_t nvec = (int64_t)p.nx * (p.ny / V);
+  const int64_t nvec = (int64_t)d.nx * (d.ny / V);
   return nvec <= (int64_t)kSmallMaxVec;
 }
 
@@ -268,18 +298,19 @@ int launch_small(pdeopt_ctx* ctx, int integrator, double dt, int64_t n) {
   SmallArgs<T> s{};
   const Geo g = make_geo(ctx);
   s.y = static_cast<T*>(ctx->Y) + (int64_t)ctx->win_lo * g.bstride;
-  s.nx = p.nx;
-  s.ny = p.ny;
+  const SmallDims d = small_dims(p);
+  s.nx = d.nx;
+  s.ny = d.ny;
   s.bstride = g.bstride;
   s.n = n;
   s.rk4 = integrator == PDEOPT_INT_RK4 ? 1 : 0;
   s.dt = T(dt); s.h2 = T(dt / 2); s.h3 = T(dt / 3); s.h6 = T(dt / 6);
-  s.rhx = T(0.5 / (p.hx * p.hx)); s.rhy = T(0.5 / (p.hy * p.hy));
-  s.rhx2 = T(1.0 / (p.hx * p.hx)); s.rhy2 = T(1.0 / (p.hy * p.hy));
+  s.rhx = T(0.5 * d.rx2); s.rhy = T(0.5 * d.ry2);
+  s.rhx2 = T(d.rx2); s.rhy2 = T(d.ry2);
   s.ep = static_cast<const EnvParams<T>*>(ctx->env_params_dev) + ctx->win_lo;
   s.mu = ClosureSpec{p.mu.kind, p.mu.flags, p.mu.n};
   s.mob = ClosureSpec{p.mob.kind, p.mob.flags, p.mob.n};
-  const int64_t nvec = (int64_t)p.nx * (p.ny / V);
+  const int64_t nvec = (int64_t)d.nx * (d.ny / V);
   int nt, kmax;
   small_shape(nvec, &nt, &kmax);
   const size_t lds = small_lds_bytes<T>(ctx);

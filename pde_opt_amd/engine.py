@@ -439,6 +439,27 @@ class HipEngine:
     def tsit5_commit(self, accept: bool):
         self._check(self._lib.pdeopt_tsit5_commit(self._h, int(bool(accept))))
 
+    def tsit5_solve_small_supported(self) -> bool:
+        """can ``tsit5_solve_small`` take the configured problem? (LDS-resident Cahn-Hilliard / Allen-Cahn FD grids)"""
+        return bool(self._lib.pdeopt_tsit5_solve_small_supported(self._h))
+
+    def tsit5_solve_small(self, t0: float, t1: float, dt0: float, controller, max_steps: int, save_ts=()):
+        """The whole adaptive Tsit5 solve ``t0 -> t1`` in one launch, one controller per environment
+        (``pdeopt_tsit5_solve_small``).  ``controller``: a ``PIDController``; ``save_ts``: ascending times in
+        ``(t0, t1]``.  Returns ``(saves, stats)``: saves ``(len(save_ts), batch) + state_shape`` (NaN where an
+        environment never got there), stats a list of dicts per environment (t, dt, accepted, rejected, status)."""
+        c = controller
+        pid = L.Pid(float(c.rtol), float(c.atol), float(c.pcoeff), float(c.icoeff), float(c.dcoeff),
+                    -np.inf if c.dtmin is None else float(c.dtmin), np.inf if c.dtmax is None else float(c.dtmax),
+                    float(c.factormin), float(c.factormax), float(c.safety))
+        ts = np.ascontiguousarray(np.asarray(save_ts, dtype=np.float64))
+        saves = np.empty((len(ts), self.batch) + self.state_shape, dtype=self.dtype)
+        stats = (L.Tsit5Stats * self.batch)()
+        self._check(self._lib.pdeopt_tsit5_solve_small(
+            self._h, float(t0), float(t1), float(dt0), C.byref(pid), int(max_steps), len(ts),
+            ts.ctypes.data_as(C.c_void_p) if len(ts) else None, saves.ctypes.data_as(C.c_void_p) if len(ts) else None, stats))
+        return saves, [dict(t=s.t, dt=s.dt, accepted=s.accepted, rejected=s.rejected, status=s.status, saved=s.saved) for s in stats]
+
     # -- domain decomposition (padded layout) ---------------------------------------------------
     def set_halo_layout(self, halo: int):
         """0 = periodic field, 4 / 8 = rank-local tile padded by a 4- / 8-cell halo (takes effect at the next

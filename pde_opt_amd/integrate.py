@@ -202,6 +202,8 @@ def _clip_dt(c: PIDController, dt: float) -> float:
 def _solve_adaptive(eng, equation, solver, t0, t1, dt0, saveat, c: PIDController, max_steps, throw, take):
     if solver.integrator != L.INT_TSIT5:
         raise ValueError("PIDController needs an embedded pair: use Tsit5")
+    if (eng.batch == 1 or c.per_environment) and t1 > t0 and dt0 > 0 and getattr(eng, "tsit5_solve_small_supported", lambda: False)():
+        return _solve_adaptive_in_kernel(eng, t0, t1, dt0, saveat, c, max_steps, throw, take)
     if c.per_environment and eng.batch > 1:
         return _solve_adaptive_per_env(eng, t0, t1, dt0, saveat, c, max_steps, throw, take, equation)
     t, dt = t0, dt0
@@ -243,6 +245,44 @@ def _solve_adaptive(eng, equation, solver, t0, t1, dt0, saveat, c: PIDController
     stats = {"num_steps": accepted + rejected, "num_accepted_steps": accepted, "num_rejected_steps": rejected,
              "kernel": eng.last_kernel}
     return Solution(np.asarray(ts_out), np.stack(ys_out), stats)
+
+
+_NO_STEP_LIMIT = 100_000_000  # max_steps=None on the in-kernel path: the launch still has to end
+
+
+def _solve_adaptive_in_kernel(eng, t0, t1, dt0, saveat, c: PIDController, max_steps, throw, take):
+    """The adaptive solve of a grid that fits one compute unit's LDS: trial steps, error norms, the PID controller and
+    the dense output all run inside ONE launch (``pdeopt_tsit5_solve_small``; csrc/stencil_small_adaptive.hpp), every
+    environment with its own controller -- the semantics of ``_solve_adaptive`` for one environment and of
+    ``_solve_adaptive_per_env`` for several, without a host round trip per step."""
+    B = eng.batch
+    ts_req = [float(v) for v in saveat.ts] if saveat.ts is not None else []
+    n_t0 = sum(1 for v in ts_req if v <= t0)
+    y_start = eng.get_state() if (saveat.t0 or n_t0) else None
+    saves, stats = eng.tsit5_solve_small(t0, t1, dt0, c, _NO_STEP_LIMIT if max_steps is None else int(max_steps), ts_req[n_t0:])
+    if any(s["status"] == L.TSIT5_STALLED for s in stats):
+        bad = next(s for s in stats if s["status"] == L.TSIT5_STALLED)
+        raise RuntimeError(f"step size underflow at t={bad['t']} (dt={bad['dt']})")
+    if throw and any(s["status"] == L.TSIT5_MAX_STEPS for s in stats):
+        bad = next(s for s in stats if s["status"] == L.TSIT5_MAX_STEPS)
+        raise RuntimeError(f"max_steps={max_steps} reached at t={bad['t']}")
+    ts_out, ys = [], []
+    if saveat.t0:
+        ts_out.append(t0); ys.append(y_start)
+    for q, tq in enumerate(ts_req):
+        ts_out.append(tq); ys.append(y_start if q < n_t0 else saves[q - n_t0])
+    if B == 1:  # the single-controller driver stops recording where the solve stopped (max_steps with throw=False)
+        keep = len(ts_out) - (len(ts_req) - n_t0 - stats[0]["saved"])
+        ts_out, ys = ts_out[:keep], ys[:keep]
+    if saveat.t1 or saveat.ts is None:
+        ts_out.append(max(s["t"] for s in stats)); ys.append(eng.get_state())
+    acc, rej = [s["accepted"] for s in stats], [s["rejected"] for s in stats]
+    if B == 1:
+        st = {"num_steps": acc[0] + rej[0], "num_accepted_steps": acc[0], "num_rejected_steps": rej[0]}
+    else:
+        st = {"num_steps": max(a + r for a, r in zip(acc, rej)), "num_accepted_steps": acc, "num_rejected_steps": rej}
+    st["kernel"] = eng.last_kernel
+    return Solution(np.asarray(ts_out), np.stack([take(y) for y in ys]), st)
 
 
 def _solve_adaptive_per_env(eng, t0, t1, dt0, saveat, c: PIDController, max_steps, throw, take, equation=None):
