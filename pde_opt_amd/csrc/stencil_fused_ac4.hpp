@@ -11,8 +11,10 @@
 //
 // Every stage evaluates k on the thread's own micro-tile (2 rows x 1 vector, accumulated in registers)
 // and on ONE vector of the ring the later stages still need (rings of 236 / 168 / 100 vectors <= 256
-// threads), keeps the results in registers across a barrier and then overwrites the stage input in
-// place.  y stays in a second LDS array as the base of every w.  Redundant ring work x1.46 / 1.33 / 1.2 / 1.
+// threads) and writes w = y + c k into the LDS array the stage did not read: the two arrays alternate
+// as input and output (y -> w1 -> w2 -> w3), one barrier per stage.  y, the base of every w, is held in
+// registers for exactly the cells a thread updates (own cells + its ring vector of each stage), so the
+// array y was loaded into is free from stage 2 on.  Redundant ring work x1.46 / 1.33 / 1.2 / 1.
 // Columns: the 4-cell halo is one 16-byte vector per side; validity shrinks by one column per stage
 // from its outer edge, exactly as far as the next stage reads.
 #pragma once
@@ -35,6 +37,9 @@ struct QuadArgs {
 #ifndef PDEOPT_AC4_FOLD
 #define PDEOPT_AC4_FOLD 1
 #endif
+#ifndef PDEOPT_AC4_DPP
+#define PDEOPT_AC4_DPP 0  // measured: 17.9 k env-steps/s with the DPP shifts against 18.6 k with the conflicted LDS reads (512^2 x 64)
+#endif
 #ifndef PDEOPT_AC4_THREADS
 #define PDEOPT_AC4_THREADS 512
 #endif
@@ -48,6 +53,16 @@ struct Ac4Geom {
   static constexpr int ring(int h) { return 2 * h * PV + 2 * TX; }
 };
 
+// Where a launch's time goes, measured on 512^2 x 64 with the global load / the store / both compiled out
+// (tools/mkvariant.sh -DPDEOPT_AC4_ABLATE=1|2|3): 34 us whole, 28 without the load, 26 without the store, 23 with
+// neither.  Tried against that in round 3, same box, interleaved runs (profiles/r03_ac4_experiments.txt):
+//   * y of the updated cells in registers + the two LDS arrays alternating as stage input / output (one barrier per
+//     stage instead of two): +6.5 % -- this kernel;
+//   * left / right neighbours by DPP wavefront shifts instead of the bank-conflicted scalar LDS reads: -3.6 %;
+//   * persistent workgroups (3 per CU) walking tiles with the next tile's loads in flight in registers during the
+//     stages and the stores draining behind: -4 % (after removing a vmcnt(0) the environment-parameter loads forced
+//     and a spill of the prefetch registers; 80 VGPRs).  Hiding a workgroup's own load / store latency buys nothing:
+//     the 11 us are the memory system's time for 134 MB with 768 workgroups' requests in flight, not exposed latency.
 template <int CL, bool RAGGED>
 __global__ __launch_bounds__(Ac4Geom::NT) void ac_rk4_quad_kernel(const QuadArgs<float> a, const int tiles_i, const int tiles_j,
                                                           const int nblk, const int xcd_remap) {
@@ -79,6 +94,8 @@ __global__ __launch_bounds__(Ac4Geom::NT) void ac_rk4_quad_kernel(const QuadArgs
   const int ly = tid >> 5;
   const int r0 = ly * RPT;
   const int cvo = lx + 1;
+  const int lane = tid & 63;
+  const bool own_l = lx == 0, own_r = lx == kLanesPerRow - 1;
 
   constexpr bool ragged = RAGGED;
   auto wrap_row = [&](int gi) { return g.periodic ? tile_wrap(gi, g.nx, ragged) : gi; };
@@ -86,15 +103,19 @@ __global__ __launch_bounds__(Ac4Geom::NT) void ac_rk4_quad_kernel(const QuadArgs
   const bool col_ok = !RAGGED || (j0 + lx * V) < g.ny;
   auto cell_ok = [&](int r) { return !RAGGED || (col_ok && (i0 + r0 + r) < g.nx); };
 
-  // ---- load y on tile + 4 into both arrays' source (sY); stage 1 reads sY directly
+  // ---- load y on tile + 4
+#if defined(PDEOPT_AC4_ABLATE) && (PDEOPT_AC4_ABLATE & 1)  // TIMING ONLY (tools/mkvariant.sh): no global load
+  for (int i = tid; i < G::kRows * PV; i += NT) *reinterpret_cast<Vec*>(sY + (i / PV) * P + (i % PV) * V) = Vec{0.1f, 0.2f, 0.1f, 0.2f} * a.dt;
+#else
   load_rows_per_wave<T, V, PV, NT, G::kRows, Vec>(sY, P, in, ld, i0 - 4, j0 - V, wrap_row, wrap_col, tid);
+#endif
   __syncthreads();
 
   // Constant mobility (CL_POLY_M0): k = -R (mu_h(u) - kappa lap u) is ONE cubic in u plus two weighted
   // neighbour sums,  k = q(u) + A (u_x+ + u_x-) + B (u_y+ + u_y-),  A = R kappa / hx^2, B = R kappa / hy^2,
   // q = -R mu_h - 2 (A + B) u  with the coefficients folded per environment: 7 instructions per cell
-  // instead of 11 in this VALU-bound kernel.  Algebraically the same expression, re-associated: the
-  // rounding differs from the literal form at the ulp level of the state per substep.
+  // instead of 11.  Algebraically the same expression, re-associated: the rounding differs from the literal
+  // form at the ulp level of the state per substep.
   constexpr bool FOLD = PDEOPT_AC4_FOLD && CL == CL_POLY_M0;
   T fA = T(0), fB = T(0), q0 = T(0), q1 = T(0), q2 = T(0), q3 = T(0);
   if constexpr (FOLD) {
@@ -106,13 +127,25 @@ __global__ __launch_bounds__(Ac4Geom::NT) void ac_rk4_quad_kernel(const QuadArgs
     q2 = -R * p.mu[2];
     q3 = -R * p.mu[3];
   }
-  // k at one vector (tile row r, LDS vector column cv) of the field held in `src`
-  auto k_at = [&](const T* src, const int r, const int cv) -> Vec {
+  // k at one vector (tile row r, LDS vector column cv) of the field held in `src`.
+  // The scalar neighbours left / right of the vector are read from LDS (ds_read_b32 with a 16-byte lane stride: a
+  // 4-way bank conflict).  PDEOPT_AC4_DPP takes them from the adjacent lanes' registers instead (adjacent lanes hold
+  // adjacent vectors; `lds_l` / `lds_r`: lanes at a row's or a wave's end and the ring's side vectors still read
+  // LDS): measured slower (above) -- the LDS has room (SQ_LDS_IDX_ACTIVE 0.52 of the launch) and the shifts add VALU
+  // work on the dependent path.  Off by default.
+  auto k_at = [&](const T* src, const int r, const int cv, const bool lds_l, const bool lds_r) -> Vec {
     const T* up = src + (r + 4) * P + cv * V;
     const Vec c = *reinterpret_cast<const Vec*>(up);
     const Vec xp = *reinterpret_cast<const Vec*>(up + P);
     const Vec xm = *reinterpret_cast<const Vec*>(up - P);
+#if PDEOPT_AC4_DPP
+    T left = lane_from_prev(T(0), c[V - 1]), right = lane_from_next(T(0), c[0]);
+    if (lds_l) left = up[-1];
+    if (lds_r) right = up[V];
+#else
     const T left = up[-1], right = up[V];
+    (void)lds_l; (void)lds_r;
+#endif
     Vec k;
 #pragma unroll
     for (int e = 0; e < V; ++e) {
@@ -142,47 +175,64 @@ __global__ __launch_bounds__(Ac4Geom::NT) void ac_rk4_quad_kernel(const QuadArgs
     }
   };
 
-  Vec acc[RPT];  // sum_i b_i k_i on the own cells, b = (1, 2, 2, 1) / 6
+  Vec acc[RPT];   // sum_i b_i k_i on the own cells, b = (1, 2, 2, 1) / 6
+  Vec yown[RPT];  // y on the own cells: the base of every w and of y', read from LDS once instead of once per stage
 #pragma unroll
-  for (int r = 0; r < RPT; ++r) acc[r] = Vec{};
+  for (int r = 0; r < RPT; ++r) {
+    acc[r] = Vec{};
+    yown[r] = *reinterpret_cast<const Vec*>(sY + (r0 + r + 4) * P + cvo * V);
+  }
+  // y at the ring vector this thread computes in a stage (the rings of tile+3, +2, +1 are different cells) is read
+  // from the y array where the stage needs it: stages 1 and 2 find it intact -- stage 2 overwrites that array with
+  // w2, but a cell is written by the one thread that also reads its y, in that order -- and stage 3's is fetched
+  // up front, before stage 2 runs over it.  With yown this is every use of y after the load.
+  int ring_r[3], ring_c[3];
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    ring_r[q] = ring_c[q] = 0;
+    if (tid < G::ring(3 - q)) ring_coord(3 - q, tid, &ring_r[q], &ring_c[q]);
+  }
+  Vec yring3 = Vec{};
+  if (tid < G::ring(1)) yring3 = *reinterpret_cast<const Vec*>(sY + (ring_r[2] + 4) * P + ring_c[2] * V);
   const T half = T(0.5) * a.dt;
 
-  // one of the stages 1..3: k on own cells + the ring of tile+H, then w = y + c k in place into sW
-  auto stage = [&](const T* src, const int H, const T cw, const T bw) {
-    Vec w_own[RPT], w_ring;
-    int rr = 0, rc = 0;
-    const bool has_ring = tid < G::ring(H);
-    if (has_ring) {
-      ring_coord(H, tid, &rr, &rc);
-      const Vec k = k_at(src, rr, rc);
-      w_ring = *reinterpret_cast<const Vec*>(sY + (rr + 4) * P + rc * V) + cw * k;
+  // One of the stages 1..3: k on own cells + the ring of tile+H, then w = y + c k into the OTHER array -- the two
+  // arrays alternate as stage input and output (y -> w1 -> w2 -> w3), so a stage ends in ONE barrier: nobody reads
+  // `dst` during this stage (its last readers passed the previous stage's barrier), nobody writes `src`.
+  // Round 2 wrote w in place and needed a second barrier per stage between the reads and the writes.
+  auto stage = [&](const T* src, T* dst, const int q, const T cw, const T bw) {
+    const int H = 3 - q;
+    if (tid < G::ring(H)) {
+      const int rr = ring_r[q], rc = ring_c[q];
+      const bool side = tid >= 2 * H * PV;  // the two vectors beside each tile row: lanes alternate left / right
+      const Vec k = k_at(src, rr, rc, side || rc == 0 || lane == 0, side || rc == PV - 1 || lane == 63);
+      const Vec yr = q == 2 ? yring3 : *reinterpret_cast<const Vec*>(sY + (rr + 4) * P + rc * V);
+      *reinterpret_cast<Vec*>(dst + (rr + 4) * P + rc * V) = yr + cw * k;
     }
 #pragma unroll
     for (int r = 0; r < RPT; ++r) {
-      const Vec k = k_at(src, r0 + r, cvo);
+      const Vec k = k_at(src, r0 + r, cvo, own_l, own_r);
       acc[r] += bw * k;
-      w_own[r] = *reinterpret_cast<const Vec*>(sY + (r0 + r + 4) * P + cvo * V) + cw * k;
+      *reinterpret_cast<Vec*>(dst + (r0 + r + 4) * P + cvo * V) = yown[r] + cw * k;
     }
-    __syncthreads();  // every read of the stage input is done
-#pragma unroll
-    for (int r = 0; r < RPT; ++r) *reinterpret_cast<Vec*>(sW + (r0 + r + 4) * P + cvo * V) = w_own[r];
-    if (has_ring) *reinterpret_cast<Vec*>(sW + (rr + 4) * P + rc * V) = w_ring;
     __syncthreads();
   };
 
-  stage(sY, 3, half, T(1));  // k1 on tile+3, w1 = y + dt/2 k1
-  stage(sW, 2, half, T(2));  // k2 on tile+2, w2 = y + dt/2 k2
-  stage(sW, 1, a.dt, T(2));  // k3 on tile+1, w3 = y + dt k3
+  stage(sY, sW, 0, half, T(1));  // k1 on tile+3, w1 = y + dt/2 k1
+  stage(sW, sY, 1, half, T(2));  // k2 on tile+2, w2 = y + dt/2 k2
+  stage(sY, sW, 2, a.dt, T(2));  // k3 on tile+1, w3 = y + dt   k3
 
   // ---- stage 4 on the tile, combine, store
   const int64_t pidx0 = base + (int64_t)(i0 + r0) * ld + (j0 + lx * V);
   const T sixth = a.dt * T(1.0 / 6.0);
 #pragma unroll
   for (int r = 0; r < RPT; ++r) {
-    const Vec k4 = k_at(sW, r0 + r, cvo);
+    const Vec k4 = k_at(sW, r0 + r, cvo, own_l, own_r);
     if (!cell_ok(r)) continue;
-    const Vec y = *reinterpret_cast<const Vec*>(sY + (r0 + r + 4) * P + cvo * V);
-    *reinterpret_cast<Vec*>(a.out + pidx0 + r * ld) = y + sixth * (acc[r] + k4);
+#if defined(PDEOPT_AC4_ABLATE) && (PDEOPT_AC4_ABLATE & 2)  // TIMING ONLY: no global store (the condition never holds)
+    if (k4[0] != 1.2345e-30f) continue;
+#endif
+    *reinterpret_cast<Vec*>(a.out + pidx0 + r * ld) = yown[r] + sixth * (acc[r] + k4);
   }
 }
 
