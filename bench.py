@@ -166,10 +166,13 @@ VALU_BUSY_SATURATED = 1.62
 VALU_BUSY_SATURATED_F64 = 0.94  # v_fma_f64 / v_add_f64 take 4.2-4.3 cycles per instruction: an all-fp64 kernel reads 0.92-0.95
 
 
-def roofline_block(workload, kernel_name, bytes_per_launch, words, avg_launch_s, launches):
+def roofline_block(workload, kernel_name, bytes_per_launch, words, avg_launch_s, launches, concurrent=1):
     """HBM roofline by SURVEY 8(d)'s algorithmic bytes and, where a PMC profile of this workload is committed, the
-    VALU-issue roofline of the same kernel; `bound` names the larger fraction (what binds the kernel)."""
-    alg_gbs = bytes_per_launch / avg_launch_s / 1e9
+    VALU-issue roofline of the same kernel; `bound` names the larger fraction (what binds the kernel).
+    `concurrent`: launches in flight side by side (two environment groups on two streams, PDEOPT_OPT_GROUP_STREAMS):
+    avg_launch_s is then ONE launch's duration -- what a kernel trace shows -- and the chip moves `concurrent` launches'
+    bytes in that time."""
+    alg_gbs = concurrent * bytes_per_launch / avg_launch_s / 1e9
     r = {
         "bound": "hbm",
         "kernel": kernel_name + " (average over the launches of a substep)",
@@ -181,6 +184,7 @@ def roofline_block(workload, kernel_name, bytes_per_launch, words, avg_launch_s,
         "algorithmic_words_per_cell_substep": words,
         "avg_launch_us": avg_launch_s * 1e6,
         "launches_timed": launches,
+        "concurrent_launches": concurrent,
     }
     try:
         pmc = json.load(open(PMC_FILE)).get(workload)
@@ -192,10 +196,10 @@ def roofline_block(workload, kernel_name, bytes_per_launch, words, avg_launch_s,
     c = pmc["counters_per_launch"]
     if pmc.get("hbm_bytes_per_launch"):
         r["traffic"] = pmc["hbm_bytes_per_launch"]
-        r["traffic_gbs"] = r["traffic"] / avg_launch_s / 1e9
+        r["traffic_gbs"] = concurrent * r["traffic"] / avg_launch_s / 1e9
         r["traffic_frac"] = r["traffic_gbs"] / HBM_PEAK_GBS
     if c.get("SQ_INSTS_VALU"):
-        per_simd = c["SQ_INSTS_VALU"] / N_SIMD
+        per_simd = concurrent * c["SQ_INSTS_VALU"] / N_SIMD
         cycles = avg_launch_s * SHADER_HZ
         valu_clk = VALU_CLK_MEASURED_F64 if WORKLOADS.get(workload, {}).get("dtype") is np.float64 else VALU_CLK_MEASURED
         r["valu_insts_per_launch"] = c["SQ_INSTS_VALU"]
@@ -216,7 +220,7 @@ def roofline_block(workload, kernel_name, bytes_per_launch, words, avg_launch_s,
             r["achieved"] = valu_share
             r["peak"] = 1.0
             r["frac"] = valu_share
-        r["valu_ginst_per_s"] = c["SQ_INSTS_VALU"] / avg_launch_s / 1e9
+        r["valu_ginst_per_s"] = concurrent * c["SQ_INSTS_VALU"] / avg_launch_s / 1e9
         r["valu_ginst_per_s_at_measured_issue_cost"] = N_SIMD * SHADER_HZ / valu_clk / 1e9
     if r["bound"] == "hbm" and r.get("traffic_gbs"):
         # memory-bound with measured traffic: price the bytes that moved, not the per-stage byte count (which fusion
@@ -501,7 +505,7 @@ def _oracle_closures(w):
 def parity_spot(name, eng, eq, solver, y0, threads):
     """Post-timing parity spot check (the bench line proves its own result): the SAME library call the timed
     region makes -- pdeopt_advance on the whole batch, environment groups and all -- on the fresh inputs,
-    first / last environment of the batch and the two environments either side of the middle (group edges)
+    first / last environment of the batch and the environments either side of the group edges
     against the CPU oracle: oracle/c_oracle.c for RK4 (one full environment step), oracle/np_oracle.py for
     the spectral integrators (8 substeps; it is a numpy port).  Returns the worst relative L2 error of the
     state increment (of the state for the GPE, whose norm is fixed) and the worst absolute state error."""
@@ -513,7 +517,15 @@ def parity_spot(name, eng, eq, solver, y0, threads):
     nsub = w["substeps"] if (w["integ"] == "rk4" and w["eq"] != "ch_sbm") else 8
     eng.set_state(y0)
     eng.advance(solver.integrator, dt, nsub, 0.0)
-    envs = sorted({0, batch // 2 - 1, batch // 2, batch - 1} & set(range(batch)))
+    # first / last environment of the batch and the two either side of every group edge (at most 8 environments)
+    ngroups = max(1, eng.last_groups())
+    gsz = -(-batch // ngroups)
+    edges = {0, batch - 1, batch // 2 - 1, batch // 2}
+    for g in range(1, ngroups):
+        if len(edges) >= 8:
+            break
+        edges |= {g * gsz - 1, g * gsz}
+    envs = sorted(edges & set(range(batch)))
     hx, hy = eq.domain.dx
     worst_rel = worst_abs = 0.0
     for b in envs:
@@ -619,6 +631,7 @@ def main():
     ap.add_argument("--tile-rows", type=int, default=0, help="0 auto, 16 or 32")
     ap.add_argument("--group-envs", type=int, default=0, help="environments per cache-resident group (0 auto, -1 whole batch)")
     ap.add_argument("--fuse", type=int, default=0, help="RK4 stage-pair fusion: 0 auto, -1 off")
+    ap.add_argument("--group-streams", type=int, default=0, help="environment groups: 0 auto (two side by side on two streams), 1 one at a time")
     ap.add_argument("--ablate", type=int, default=0, help="TIMING ONLY (wrong results): kernel phase ablation bits")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity-spot", action="store_true")
@@ -676,6 +689,7 @@ def main():
     eng.set_tile_rows(args.tile_rows)
     eng.set_group_envs(args.group_envs)
     eng.set_fuse_stages(args.fuse)
+    eng.set_group_streams(args.group_streams)
     if args.ablate:
         eng._check(eng._lib.pdeopt_set_option(eng._h, L.OPT_DEBUG_ABLATE, args.ablate))
     eng.configure(dtype=y0.dtype, batch=batch, **eq._engine_problem())
@@ -731,8 +745,9 @@ def main():
         total_bytes = words * esize * nx * ny * batch * substeps * args.steps
         launches = max(launches, 1)
         bytes_per_launch = total_bytes / launches
-        avg_launch_s = (dev_ms * 1e-3) / launches
-        achieved = bytes_per_launch / avg_launch_s / 1e9
+        # two environment groups side by side (PDEOPT_OPT_GROUP_STREAMS): a launch lasts twice its share of the timed region
+        concurrent = eng.last_group_streams()
+        avg_launch_s = (dev_ms * 1e-3) * concurrent / launches
         line = {
             "metric": METRIC if args.workload == "ch_rk4_1024_f32" else
                       f"env-steps/sec ({args.workload}, {substeps} substeps/env-step) & achieved HBM GB/s",
@@ -764,7 +779,7 @@ def main():
             "achieved_gbs_whole_job": args.gpus * total_bytes / elapsed / 1e9,
             "nonfinite_cells": bad,
             **(spot or {}),
-            "roofline": roofline_block(args.workload, kernel_name, bytes_per_launch, words, avg_launch_s, launches),
+            "roofline": roofline_block(args.workload, kernel_name, bytes_per_launch, words, avg_launch_s, launches, concurrent),
         }
         if args.gpus == 1 and not args.no_api and not args.ablate:
             line.update(api_throughput(P, args.workload, rank, args.steps, args.warmup) or {})

@@ -176,6 +176,9 @@ typedef enum {
                                  tests and notebooks, where a launch per stage pair is latency-bound): 0 = auto (grids
                                  up to 4096 cells, larger ones from 192 environments on), 1 = wherever it can run,
                                  -1 = never */
+  PDEOPT_OPT_GROUP_STREAMS = 9,/* explicit integrators running the batch in cache-resident groups: 0 = auto (two groups
+                                  side by side on two HIP streams, each half the size, so that one group's launch
+                                  fills the other's ramp and tail), 1 = one group at a time, 2 = force two */
   PDEOPT_OPT_DEBUG_ABLATE = 3 /* TIMING ONLY, results are wrong: bit0 skip the mu phase, bit1 skip
                                  the flux phase of the tiled kernel (where does the time go?) */
 } pdeopt_option;
@@ -418,7 +421,8 @@ int pdeopt_timer_stop(pdeopt_ctx* ctx, double* ms); /* record + synchronise + el
 typedef enum {
   PDEOPT_CNT_STAGE_LAUNCHES = 0, /* kernel launches of the integrators so far: fused stencil + update launches, and the
                                     FFT passes of the hand-written Strang / IMEX pipelines */
-  PDEOPT_CNT_LAST_GROUPS = 1     /* environment groups the last pdeopt_advance ran the batch in (1 = one sweep) */
+  PDEOPT_CNT_LAST_GROUPS = 1,    /* environment groups the last pdeopt_advance ran the batch in (1 = one sweep) */
+  PDEOPT_CNT_GROUP_STREAMS = 2   /* groups the last pdeopt_advance kept in flight side by side (PDEOPT_OPT_GROUP_STREAMS): 1 or 2 */
 } pdeopt_counter;
 int pdeopt_get_counter(pdeopt_ctx* ctx, int which, int64_t* value);
 /* name of the kernel variant the last advance/rhs dispatched (for tests and profiles) */

@@ -40,8 +40,10 @@ OPT_HALO_LAYOUT = 5
 OPT_GRAPH = 6
 OPT_IMEX_LDS_FFT = 7
 OPT_SMALL_PERSIST = 8
+OPT_GROUP_STREAMS = 9
 CNT_STAGE_LAUNCHES = 0
 CNT_LAST_GROUPS = 1
+CNT_GROUP_STREAMS = 2
 COPY_H2D, COPY_D2H, COPY_D2D = 0, 1, 2
 FIELD_Y, FIELD_TA, FIELD_TB, FIELD_ACC = 0, 1, 2, 3
 PATH_AUTO, PATH_GENERIC, PATH_TILED = 0, 1, 2

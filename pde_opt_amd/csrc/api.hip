@@ -235,6 +235,9 @@ int pdeopt_ctx_destroy(pdeopt_ctx* ctx) {
   free_fields(ctx);
   if (ctx->red_dev) (void)hipFree(ctx->red_dev);
   if (ctx->red_mean_dev) (void)hipFree(ctx->red_mean_dev);
+  if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+  if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
+  if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
   if (ctx->stream && !ctx->stream_borrowed) (void)hipStreamDestroy(ctx->stream);
@@ -282,6 +285,10 @@ int pdeopt_set_option(pdeopt_ctx* ctx, int option, int64_t value) {
       return PDEOPT_OK;
     case PDEOPT_OPT_GROUP_ENVS:
       ctx->opt_group_envs = value;
+      return PDEOPT_OK;
+    case PDEOPT_OPT_GROUP_STREAMS:
+      if (value < 0 || value > 2) return fail(ctx, PDEOPT_EINVAL, "group-streams option must be 0, 1 or 2");
+      ctx->opt_group_streams = value;
       return PDEOPT_OK;
     case PDEOPT_OPT_SMALL_PERSIST:
       if (value < -1 || value > 1) return fail(ctx, PDEOPT_EINVAL, "small-persist option must be -1, 0 or 1");
@@ -600,6 +607,7 @@ int pdeopt_advance(pdeopt_ctx* ctx, int integrator, double t0, double dt, int64_
   ctx->tsit5_fsal_valid = false;
   ctx->tsit5_pending = false;
   ctx->last_groups = 1;
+  ctx->last_group_streams = 1;
   if (ctx->halo)
     return fail(ctx, PDEOPT_EINVAL, "padded layout: drive the substep with pdeopt_rk4_phase + halo exchange");
   const int eq = ctx->prob.equation;
@@ -830,6 +838,9 @@ int pdeopt_get_counter(pdeopt_ctx* ctx, int which, int64_t* value) {
       return PDEOPT_OK;
     case PDEOPT_CNT_LAST_GROUPS:
       *value = ctx->last_groups;
+      return PDEOPT_OK;
+    case PDEOPT_CNT_GROUP_STREAMS:
+      *value = ctx->last_group_streams;
       return PDEOPT_OK;
     default:
       return fail(ctx, PDEOPT_EINVAL, "unknown counter %d", which);

@@ -173,6 +173,9 @@ struct pdeopt_ctx {
   std::string graph_name;
   int64_t opt_fuse_stages = 0;   // RK4 stage-pair fusion: 0 auto, -1 off (one launch per stage), 1 stage pairs (AC: no single-pass kernel)
   int64_t opt_debug_ablate = 0;  // timing-only ablations, results are wrong when set
+  int64_t opt_group_streams = 0;  // PDEOPT_OPT_GROUP_STREAMS
+  hipStream_t stream2 = nullptr;  // second stream of the two-groups-side-by-side schedule (created on first use)
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   int64_t opt_small_persist = 0; // whole-environment-step kernel for LDS-resident grids: 0 auto, 1 wherever it can, -1 never
   // Gaussian light spots of the GPE (pdeopt_set_gpe_spots)
   int n_spots = 0;
@@ -182,6 +185,7 @@ struct pdeopt_ctx {
   bool imex_per_env = false;  // some environment has imex_scale != 1: one environment per complex field
   int launch_part = 0;        // tiles of the next stage-pair launches: 0 all, 1 interior, 2 edge (pdeopt_rk4_phase_part)
   int win_lo = 0, win_n = 0;  // environment window the stage launchers operate on
+  int64_t last_group_streams = 1;  // PDEOPT_CNT_GROUP_STREAMS
   int64_t last_groups = 1;    // environment groups of the last advance (PDEOPT_CNT_LAST_GROUPS)
   double imex_A = 0.5, ts_re = 1.0, ts_im = 0.0, strang_dx = 1.0;
   double* red_dev = nullptr;  // reduction scratch

@@ -99,6 +99,11 @@ class HipEngine:
     def set_fuse_stages(self, v: int):
         self._check(self._lib.pdeopt_set_option(self._h, L.OPT_FUSE_STAGES, int(v)))
 
+    def set_group_streams(self, v: int):
+        """explicit integrators running the batch in cache-resident groups: 0 auto (two groups side by side on two
+        HIP streams), 1 one group at a time, 2 force two (``PDEOPT_OPT_GROUP_STREAMS``)"""
+        self._check(self._lib.pdeopt_set_option(self._h, L.OPT_GROUP_STREAMS, int(v)))
+
     def set_small_persist(self, v: int):
         """whole-environment-step kernel for LDS-resident grids (Euler / RK4): 0 auto, 1 wherever it can run, -1 never"""
         self._check(self._lib.pdeopt_set_option(self._h, L.OPT_SMALL_PERSIST, int(v)))
@@ -543,6 +548,12 @@ class HipEngine:
         """environment groups the last ``advance`` ran the batch in (1 = the whole batch per sweep)"""
         v = C.c_int64()
         self._check(self._lib.pdeopt_get_counter(self._h, L.CNT_LAST_GROUPS, C.byref(v)))
+        return v.value
+
+    def last_group_streams(self) -> int:
+        """groups the last ``advance`` kept in flight side by side on separate HIP streams (1 or 2)"""
+        v = C.c_int64()
+        self._check(self._lib.pdeopt_get_counter(self._h, L.CNT_GROUP_STREAMS, C.byref(v)))
         return v.value
 
     def sync(self):

@@ -79,6 +79,79 @@ def test_explicit_grouped_equals_ungrouped_bitwise(dtype, case, shape, batch, gr
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("case", ["ch_rk4_pair", "ch_rk4_stage", "ch_euler_pair", "ch_euler_odd", "ac_rk4_quad"])
+@pytest.mark.parametrize("shape,batch,group", [((64, 128), 5, 2), ((48, 40), 7, 3), ((128, 128), 4, 1)])
+def test_two_groups_side_by_side_equal_one_at_a_time_bitwise(dtype, case, shape, batch, group):
+    """PDEOPT_OPT_GROUP_STREAMS: two groups in flight on two HIP streams (the schedule bench.py's headline runs) --
+    the same kernels on the same windows in another order; an odd group count leaves the last one alone"""
+    rng = np.random.default_rng(12)
+    nx, ny = shape
+    dom = std_domain(P, nx, ny)
+    if case.startswith("ch"):
+        eq = P.CahnHilliard2DPeriodic(dom, 0.002, MU["regsol"], MOB["c1mc"])
+        u = white_noise_state(rng, (batch, nx, ny), dtype, "c")
+        dt = 2e-7
+    else:
+        eq = P.AllenCahn2DPeriodic(dom, 0.002, MU["cubic"], MOB["one"])
+        u = white_noise_state(rng, (batch, nx, ny), dtype, "sym")
+        dt = 5e-5
+    opts, integ, n = {}, L.INT_RK4, 6
+    if case == "ch_rk4_stage":
+        opts["fuse_stages"] = -1
+    elif case == "ch_euler_pair":
+        integ = L.INT_EULER
+    elif case == "ch_euler_odd":
+        integ, n = L.INT_EULER, 7
+    out = []
+    for streams in (1, 2):
+        eng = P.HipEngine()
+        eng.set_group_envs(group)
+        eng.set_group_streams(streams)
+        eng.set_graph(-1)
+        for k, v in opts.items():
+            getattr(eng, "set_" + k)(v)
+        eng.configure(dtype=u.dtype, batch=batch, **eq._engine_problem())
+        eng.set_state(u)
+        eng.advance(integ, dt, n // 2)
+        eng.advance(integ, dt, n - n // 2)  # a second call: the second stream starts behind the first call's results
+        assert eng.last_group_streams() == streams
+        assert eng.last_groups() == -(-batch // group)
+        st = eng.reduce(L.RED_MEAN)  # work queued on the ctx stream after the join sees both groups' results
+        out.append((eng.get_state(), st))
+        eng.close()
+    (a, ma), (b, mb) = out
+    assert np.isfinite(a).all() and np.any(a != u)
+    np.testing.assert_array_equal(a, b)
+    np.testing.assert_array_equal(ma, mb)
+
+
+def test_auto_schedule_runs_large_batches_as_two_side_by_side_halves():
+    """auto: a batch that fits the cache as one group runs as two halves side by side once it is large (> 2 M cells);
+    small ones keep the single sweep (and the hipGraph replay); results do not depend on it"""
+    dom = std_domain(P, 256, 256)
+    eq = P.AllenCahn2DPeriodic(dom, 0.002, MU["cubic"], MOB["one"])
+    rng = np.random.default_rng(13)
+    u = white_noise_state(rng, (40, 256, 256), np.float32, "sym")
+    res = []
+    for streams in (0, 1):
+        eng = P.HipEngine()
+        eng.set_group_streams(streams)
+        eng.configure(dtype=u.dtype, batch=40, **eq._engine_problem())
+        eng.set_state(u)
+        eng.advance(L.INT_RK4, 5e-5, 4)
+        res.append((eng.get_state(), eng.last_group_streams(), eng.last_groups()))
+        eng.close()
+    assert res[0][1:] == (2, 2) and res[1][1:] == (1, 1), (res[0][1:], res[1][1:])
+    np.testing.assert_array_equal(res[0][0], res[1][0])
+    eng = P.HipEngine()
+    eng.configure(dtype=u.dtype, batch=8, **eq._engine_problem())
+    eng.set_state(u[:8])
+    eng.advance(L.INT_RK4, 5e-5, 4)
+    assert eng.last_group_streams() == 1
+    eng.close()
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
 @pytest.mark.parametrize("shape,batch,group", [((64, 64), 5, 2), ((128, 64), 7, 4), ((64, 256), 3, 2)])
 def test_imex_grouped_equals_ungrouped_bitwise(dtype, shape, batch, group):
     """IMEX packs two environments per complex field: groups are even-sized, an odd batch leaves the last
@@ -150,18 +223,18 @@ def _ch_ic(n, seed, dtype=np.float32):
 
 
 def test_config3_rk4_headline_batch_vs_c_oracle():
-    """ch_rk4_1024_f32 exactly as bench.py runs it: 32 environments, auto grouping -> 2 groups of 16,
-    32-row stage-pair kernels with the XCD-aware block map.  Environments {0, 15, 16, 31} = first / last of
-    each group against oracle/c_oracle.c (fp32 state to 5e-7 absolute, increment to 5e-4 relative)."""
+    """ch_rk4_1024_f32 exactly as bench.py runs it: 32 environments, auto grouping -> 4 groups of 8, two side by
+    side on two streams (256 MiB resident), 32-row stage-pair kernels with the XCD-aware block map.  First / last
+    environment of each group against oracle/c_oracle.c (fp32 state to 5e-7 absolute, increment to 5e-4 relative)."""
     n, batch, nsub, dt = 1024, 32, 4, 2e-7
     dom = std_domain(P, n, n)
     eq = P.CahnHilliard2DPeriodic(dom, 0.002, MU["regsol"], MOB["c1mc"])
     y0 = np.stack([_ch_ic(n, b) for b in range(batch)])
     out, groups, kernel = _advance(eq, None, y0, L.INT_RK4, dt, nsub, 0)
-    assert groups == 2, groups
+    assert groups == 4, groups
     assert kernel == "stage_pair<f32,CH,logit,rows32>", kernel
     hx, hy = dom.dx
-    for b in (0, 15, 16, 31):
+    for b in (0, 7, 8, 15, 16, 23, 24, 31):
         ref = CO.rk4(0, y0[b], hx, hy, 0.002, REGSOL_C, C1MC_C, dt, nsub, threads=8)
         assert np.max(np.abs(out[b] - ref)) < 5e-7, (b, np.max(np.abs(out[b] - ref)))
         inc, inc_ref = out[b].astype(np.float64) - y0[b], ref.astype(np.float64) - y0[b]
@@ -171,15 +244,15 @@ def test_config3_rk4_headline_batch_vs_c_oracle():
 
 
 def test_config3_rk4_f64_batch_vs_c_oracle():
-    """fp64 headline variant (16 environments = 2 groups of 8)"""
+    """fp64 headline variant (16 environments = 4 groups of 4, two side by side)"""
     n, batch, nsub, dt = 1024, 16, 3, 2e-7
     dom = std_domain(P, n, n)
     eq = P.CahnHilliard2DPeriodic(dom, 0.002, MU["regsol"], MOB["c1mc"])
     y0 = np.stack([_ch_ic(n, 100 + b, np.float64) for b in range(batch)])
     out, groups, kernel = _advance(eq, None, y0, L.INT_RK4, dt, nsub, 0)
-    assert groups == 2 and "stage_pair<f64,CH" in kernel, (groups, kernel)
+    assert groups == 4 and "stage_pair<f64,CH" in kernel, (groups, kernel)
     hx, hy = dom.dx
-    for b in (0, 7, 8, 15):
+    for b in (0, 3, 4, 7, 8, 11, 12, 15):
         ref = CO.rk4(0, y0[b], hx, hy, 0.002, REGSOL_C, C1MC_C, dt, nsub, threads=8)
         assert rel_l2(out[b] - y0[b], ref - y0[b]) < 1e-10, (b, rel_l2(out[b] - y0[b], ref - y0[b]))
 
@@ -192,11 +265,11 @@ def test_config2_ac_rk4_batch64_vs_c_oracle():
     y0 = np.stack([(0.01 * np.random.default_rng(b).standard_normal((n, n))).astype(np.float32) for b in range(batch)])
     hx, hy = dom.dx
     cmu, cmob = CO.closure(0, 0, (0.0, -1.0, 0.0, 1.0)), CO.closure(0, 0, (1.0,))
-    for group in (0, 24):  # auto (the whole batch fits the cache) and a forced split 24 + 24 + 16
+    for group in (0, 24):  # auto (the batch fits the cache: two halves side by side) and a forced split 24 + 24 + 16
         out, groups, kernel = _advance(eq, None, y0, L.INT_RK4, dt, nsub, group)
         assert "rk4_quad" in kernel, kernel
-        assert groups == (1 if group == 0 else 3)
-        for b in (0, 23, 24, 47, 48, 63):
+        assert groups == (2 if group == 0 else 3)
+        for b in (0, 23, 24, 31, 32, 47, 48, 63):
             ref = CO.rk4(1, y0[b], hx, hy, 0.002, cmu, cmob, dt, nsub, threads=8)
             assert np.max(np.abs(out[b] - ref)) < 5e-8, (b, np.max(np.abs(out[b] - ref)))
             inc, inc_ref = out[b].astype(np.float64) - y0[b], ref.astype(np.float64) - y0[b]
