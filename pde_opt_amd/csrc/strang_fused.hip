@@ -526,22 +526,66 @@ int strang_fused_t(pdeopt_ctx* ctx, double t0, double dt, int64_t n) {
       group = (p.batch + ngroups - 1) / ngroups;
     }
   }
+  // two groups side by side on two streams, each half the size (PDEOPT_OPT_GROUP_STREAMS; stencil.hip:
+  // advance_explicit has the reasoning and the measurement for the explicit integrators)
+  bool side_by_side = false;
+  if (!timed && ctx->opt_group_streams != 1 && n > 1 && group >= 2 &&
+      (group < p.batch ? (ctx->opt_group_envs == 0 || ctx->opt_group_streams == 2)
+                       : (ctx->opt_group_streams == 0 && ctx->opt_group_envs == 0 && cells * p.batch > (1 << 21)))) {
+    if (ctx->opt_group_envs == 0) group = (group + 1) / 2;
+    side_by_side = true;
+  }
   ctx->last_groups = (p.batch + group - 1) / group;
+  auto first = [&]() -> int { return row_dispatch<T, ROW_FIRST>(ctx, sf, tr, ti); };
+  auto substep = [&](int64_t s) -> int {
+    int r;
+    if ((r = col_dispatch<T, false>(ctx, sf))) return r;
+    if (timed && (r = refresh_time_aux(ctx, PDEOPT_AUX_GPE_POTENTIAL, t0 + (double)s * dt))) return r;
+    if ((r = row_dispatch<T, ROW_MID>(ctx, sf, tr, ti, t0 + (double)s * dt))) return r;
+    if ((r = col_dispatch<T, true>(ctx, sf))) return r;
+    return s + 1 < n ? row_dispatch<T, ROW_JOIN>(ctx, sf, tr, ti) : row_dispatch<T, ROW_LAST>(ctx, sf, tr, ti);
+  };
+  if (side_by_side && ctx->last_groups >= 2) {
+    ctx->last_group_streams = 2;
+    if (!ctx->stream2) {
+      PDEOPT_HIP_CHECK(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+      PDEOPT_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+      PDEOPT_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+    }
+    PDEOPT_HIP_CHECK(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
+    PDEOPT_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
+    auto on = [&](int lo, bool second, auto fn) -> int {
+      ctx->win_lo = lo;
+      ctx->win_n = std::min(group, p.batch - lo);
+      if (second) std::swap(ctx->stream, ctx->stream2);  // the dispatch helpers take the ctx stream
+      const int r = fn();
+      if (second) std::swap(ctx->stream, ctx->stream2);
+      return r;
+    };
+    for (int lo = 0; lo < p.batch && !rc; lo += 2 * group) {
+      const bool two = lo + group < p.batch;
+      rc = on(lo, false, first);
+      if (two && !rc) rc = on(lo + group, true, first);
+      for (int64_t s = 0; s < n && !rc; ++s) {
+        rc = on(lo, false, [&] { return substep(s); });
+        if (two && !rc) rc = on(lo + group, true, [&] { return substep(s); });
+      }
+    }
+    const hipError_t e1 = hipEventRecord(ctx->ev_join, ctx->stream2);
+    const hipError_t e2 = hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0);
+    ctx->win_lo = 0;
+    ctx->win_n = p.batch;
+    if (rc) return rc;
+    PDEOPT_HIP_CHECK(ctx, e1);
+    PDEOPT_HIP_CHECK(ctx, e2);
+    ctx->last_kernel = "strang_fused_lds_fft";
+    return PDEOPT_OK;
+  }
   for (int lo = 0; lo < p.batch && !rc; lo += group) {
     ctx->win_lo = lo;
     ctx->win_n = std::min(group, p.batch - lo);
-    if ((rc = row_dispatch<T, ROW_FIRST>(ctx, sf, tr, ti))) break;
-    for (int64_t s = 0; s < n; ++s) {
-      if ((rc = col_dispatch<T, false>(ctx, sf))) break;
-      if (timed && (rc = refresh_time_aux(ctx, PDEOPT_AUX_GPE_POTENTIAL, t0 + (double)s * dt))) break;
-      if ((rc = row_dispatch<T, ROW_MID>(ctx, sf, tr, ti, t0 + (double)s * dt))) break;
-      if ((rc = col_dispatch<T, true>(ctx, sf))) break;
-      if (s + 1 < n)
-        rc = row_dispatch<T, ROW_JOIN>(ctx, sf, tr, ti);
-      else
-        rc = row_dispatch<T, ROW_LAST>(ctx, sf, tr, ti);
-      if (rc) break;
-    }
+    if ((rc = first())) break;
+    for (int64_t s = 0; s < n && !rc; ++s) rc = substep(s);
   }
   ctx->win_lo = 0;
   ctx->win_n = p.batch;

@@ -300,8 +300,8 @@ def test_config3_imex_batch32_vs_oracle():
 
 
 def test_config4_gpe_strang_batch128_vs_oracle():
-    """BASELINE config 4: GPE 512^2 complex64, Strang split step, 128 environments on one GPU -> 2 groups of
-    64.  Every environment starts from its own wave packet; first / last of each group against
+    """BASELINE config 4: GPE 512^2 complex64, Strang split step, 128 environments on one GPU -> 4 groups of
+    32, two side by side.  Every environment starts from its own wave packet; first / last of each group against
     oracle/np_oracle.py (solvers.py:99-115 restated)."""
     n, batch, nsub, dt = 512, 128, 4, 1e-3
     dom = P.Domain((n, n), ((-12.0, 12.0), (-12.0, 12.0)), "dimensionless")
@@ -315,9 +315,9 @@ def test_config4_gpe_strang_batch128_vs_oracle():
         y0[b, ..., 0], y0[b, ..., 1] = psi.real, psi.imag
     solver = P.StrangSplitting(eq.A_term, eq.dx, eq.fft, eq.ifft, 1.0)
     out, groups, kernel = _advance(eq, solver, y0, L.INT_STRANG, dt, nsub, 0)
-    assert groups == 2 and kernel == "strang_fused_lds_fft", (groups, kernel)
+    assert groups == 4 and kernel == "strang_fused_lds_fft", (groups, kernel)  # 4 groups of 32, two side by side
     bt = lambda t, yy: O.gpe_b_terms(yy, X, Y, 1000.0, 0.0, 1.0, 0.0)
-    for b in (0, 63, 64, 127):
+    for b in (0, 31, 32, 63, 64, 95, 96, 127):
         ref = y0[b].astype(np.float64)
         for i in range(nsub):
             ref = O.strang_step(bt, i * dt, ref, dt, eq.A_term, eq.dx, 1.0)
