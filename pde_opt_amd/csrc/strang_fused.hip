@@ -854,8 +854,47 @@ int imex_fused_t(pdeopt_ctx* ctx, double dt, int64_t n) {
     }
     return r;
   };
-  // (two groups in flight on two streams, so that one's traffic runs under the other's arithmetic, measured
-  // 1445 vs 1443 env-steps/s at 2 x 8 environments against 1 x 16, and slower at 2 x 16 / 2 x 4: one stream)
+  // Two groups in flight on two streams (PDEOPT_OPT_GROUP_STREAMS = 2 only).  Round 2 measured 1445 vs 1443
+  // env-steps/s at 2 x 8 environments against 1 x 16, and slower at 2 x 16 / 2 x 4; round 3 re-measured after the
+  // explicit and the Strang pipelines gained 6-7 % from it: see profiles/r03_group_streams_ab.txt.
+  if (ctx->opt_group_streams == 2 && n > 1 && group >= 4 && ctx->last_groups >= 1 && p.batch >= 4) {
+    if (ctx->opt_group_envs == 0) group = std::max(2, (group / 2 + 1) & ~1);
+    ctx->last_groups = (p.batch + group - 1) / group;
+  }
+  if (ctx->opt_group_streams == 2 && ctx->last_groups >= 2 && n > 1) {
+    ctx->last_group_streams = 2;
+    if (!ctx->stream2) {
+      PDEOPT_HIP_CHECK(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+      PDEOPT_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+      PDEOPT_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+    }
+    PDEOPT_HIP_CHECK(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
+    PDEOPT_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
+    for (int lo = 0; lo < p.batch && !rc; lo += 2 * group) {
+      const bool two = lo + group < p.batch;
+      for (int64_t s = 0; s < n && !rc; ++s) {
+        ctx->win_lo = lo;
+        ctx->win_n = std::min(group, p.batch - lo);
+        rc = substep();
+        if (two && !rc) {
+          ctx->win_lo = lo + group;
+          ctx->win_n = std::min(group, p.batch - lo - group);
+          std::swap(ctx->stream, ctx->stream2);
+          rc = substep();
+          std::swap(ctx->stream, ctx->stream2);
+        }
+      }
+    }
+    const hipError_t e1 = hipEventRecord(ctx->ev_join, ctx->stream2);
+    const hipError_t e2 = hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0);
+    ctx->win_lo = 0;
+    ctx->win_n = p.batch;
+    if (rc) return rc;
+    PDEOPT_HIP_CHECK(ctx, e1);
+    PDEOPT_HIP_CHECK(ctx, e2);
+    ctx->last_kernel += "+imex_fused_lds_fft";
+    return PDEOPT_OK;
+  }
   for (int lo = 0; lo < p.batch && !rc; lo += group) {
     ctx->win_lo = lo;
     ctx->win_n = std::min(group, p.batch - lo);

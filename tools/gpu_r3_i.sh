@@ -1,4 +1,11 @@
 #!/bin/bash
 mkdir -p gpurun_out
-timeout 2400 python -m pytest tests -q -m gpu 2>&1 | tail -8 > gpurun_out/pytest_i.log
-cat gpurun_out/pytest_i.log
+run() { timeout 300 python bench.py --no-cpu-baseline --no-api --steps 5 --warmup 2 "$@" | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1])
+print('$*', round(d['value'],1), 'env-steps/s', round(d['ms_per_step'],2), 'ms/step', d.get('parity_spot_ok'), d['roofline'].get('concurrent_launches'))"; }
+for r in 1 2 3; do
+run --workload ch_imex_1024_f32 --group-streams 2
+run --workload ch_imex_1024_f32 --group-streams 1
+run --workload ch_imex_1024_f32 --group-streams 2 --group-envs 8
+done 2>&1 | tee gpurun_out/ab_group_streams_imex.txt
