@@ -8,13 +8,15 @@ R=gpurun_out/round
 cp $R/bench.json profiles/${TAG}_bench.json
 cp $R/ch_rk4_1024_f32/summary.txt profiles/${TAG}_ch_rk4_1024_f32_summary.txt
 cp $(ls -t $R/ch_rk4_1024_f32/trace/*/*kernel_stats.csv | head -1) profiles/${TAG}_ch_rk4_1024_f32_kernel_stats.csv
-for w in ac_rk4_512_f32 ch_imex_1024_f32 gpe_strang_512_c64 ch_rk4_1024_f64 ch_rk4_64_f32_small ch_sbm_1024_f32 decomp_tile2048; do
+for w in ac_rk4_512_f32 ch_imex_1024_f32 gpe_strang_512_c64 ch_rk4_1024_f64 ch_rk4_64_f32_small ch_rk4_128_f32_small ac_rk4_64_f32_small ch_sbm_1024_f32 decomp_tile2048; do
   [ -f $R/${w}_trace_summary.txt ] && cp $R/${w}_trace_summary.txt profiles/${TAG}_${w}_trace_summary.txt
 done
 [ -f gpurun_out/small_grid_ch.txt ] && cp gpurun_out/small_grid_ch.txt profiles/${TAG}_small_grid_ch.txt
 for f in $R/bench_*.json; do cp $f profiles/${TAG}_$(basename $f); done
 cp gpurun_out/busy_summary.txt profiles/${TAG}_pmc_busy.txt
 [ -f gpurun_out/valubench.txt ] && cp gpurun_out/valubench.txt profiles/${TAG}_valubench_raw.txt
+[ -f gpurun_out/lds_issue_bench.txt ] && cp gpurun_out/lds_issue_bench.txt profiles/${TAG}_lds_issue_bench.txt
+[ -f gpurun_out/adaptive_bench.txt ] && cp gpurun_out/adaptive_bench.txt profiles/${TAG}_adaptive_in_kernel.txt
 bash tools/make_pmc_json.sh ${TAG}
 for f in stencil.hip strang_fused.hip; do python tools/kernel_resources.py $f > /tmp/kres_$f.txt; done
 (echo "# hipcc -Rpass-analysis=kernel-resource-usage (tools/kernel_resources.py), gfx950, product flags; lds = static LDS only"; \

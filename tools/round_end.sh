@@ -5,10 +5,11 @@
 # occupancy of the headline kernel) -> tools/valubench + its PMC calibration.  Afterwards, here: tools/install_profiles.sh <tag>.
 cd ${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p gpurun_out
-timeout 900 python -m pytest tests -q -m gpu > gpurun_out/pytest_gpu.log 2>&1
+timeout 1200 python -m pytest tests -q -m gpu > gpurun_out/pytest_gpu.log 2>&1
 grep -E "passed|failed|error" gpurun_out/pytest_gpu.log | tail -2
 timeout 2400 bash tools/profile_round.sh
 [ -x tools/valubench.bin ] && timeout 200 ./tools/valubench.bin > gpurun_out/valubench.txt 2>&1
-[ -x tools/ldsbench.bin ] && timeout 200 ./tools/ldsbench.bin > gpurun_out/ldsbench.txt 2>&1
+[ -x tools/lds_issue_bench.bin ] && timeout 200 ./tools/lds_issue_bench.bin > gpurun_out/lds_issue_bench.txt 2>&1
+timeout 300 python tools/adaptive_bench.py > gpurun_out/adaptive_bench.txt 2>&1
 timeout 300 python tools/small_grid_bench.py ch > gpurun_out/small_grid_ch.txt 2>&1
 tail -4 gpurun_out/busy_summary.txt | cut -c1-400
