@@ -217,6 +217,81 @@ def test_per_environment_step_sizes_equal_solo_solves():
     assert shared.stats["num_accepted_steps"] >= max(both.stats["num_accepted_steps"])
 
 
+def _engine_in_kernel():
+    e = OracleEngine()
+    e.small_adaptive = True  # diffeqsolve routes to integrate._solve_adaptive_in_kernel (the one-launch solve's driver)
+    return e
+
+
+@pytest.mark.parametrize("saveat", [dict(t1=True), dict(ts=[0.0, 0.013, 0.05, 0.2]), dict(t0=True, ts=[0.02, 0.2], t1=True),
+                                    dict(ts=[-1.0, 0.0, 0.1])])
+def test_one_launch_adaptive_driver_equals_the_step_by_step_loop(saveat):
+    """integrate._solve_adaptive_in_kernel (what drives pdeopt_tsit5_solve_small) against integrate._solve_adaptive on
+    the same oracle arithmetic: save times, their order, the states, the statistics -- one environment and several
+    with their own controllers"""
+    nx = 48
+    dom = std_domain(P, nx, 1)
+    eq = P.AllenCahn2DPeriodic(dom, 0.002, lambda c: c**3 - c, lambda c: np.ones_like(c))
+    rng = np.random.default_rng(10)
+    y0 = np.stack([np.where(np.arange(nx)[:, None] < nx // 2, -1.0, 1.0), 0.05 * rng.standard_normal((nx, 1)),
+                   0.5 * rng.standard_normal((nx, 1))])
+    ctl = dict(rtol=1e-5, atol=1e-7, pcoeff=0.2, icoeff=0.6)
+    a = P.diffeqsolve(eq, P.Tsit5(), 0.0, 0.2, 1e-4, y0[0], saveat=P.SaveAt(**saveat), stepsize_controller=P.PIDController(**ctl),
+                      engine=_engine_in_kernel())
+    b = P.diffeqsolve(eq, P.Tsit5(), 0.0, 0.2, 1e-4, y0[0], saveat=P.SaveAt(**saveat), stepsize_controller=P.PIDController(**ctl),
+                      engine=OracleEngine())
+    np.testing.assert_array_equal(a.ts, b.ts)
+    np.testing.assert_array_equal(a.ys, b.ys)
+    assert {k: a.stats[k] for k in ("num_steps", "num_accepted_steps", "num_rejected_steps")} == {
+        k: b.stats[k] for k in ("num_steps", "num_accepted_steps", "num_rejected_steps")}
+    per = P.PIDController(**ctl, per_environment=True)
+    a = P.diffeqsolve(eq, P.Tsit5(), 0.0, 0.2, 1e-4, y0, saveat=P.SaveAt(**saveat), stepsize_controller=per, engine=_engine_in_kernel())
+    b = P.diffeqsolve(eq, P.Tsit5(), 0.0, 0.2, 1e-4, y0, saveat=P.SaveAt(**saveat), stepsize_controller=per, engine=OracleEngine())
+    np.testing.assert_array_equal(a.ts, b.ts)
+    np.testing.assert_allclose(a.ys, b.ys, rtol=0, atol=1e-12)  # the batched host loop scales slopes by dt_b / dt_ref
+    assert a.stats["num_accepted_steps"] == b.stats["num_accepted_steps"]
+    assert a.stats["num_rejected_steps"] == b.stats["num_rejected_steps"]
+    # a step size shared by the batch is not the one-launch solve's job
+    c = P.diffeqsolve(eq, P.Tsit5(), 0.0, 0.2, 1e-4, y0, saveat=P.SaveAt(**saveat), stepsize_controller=P.PIDController(**ctl),
+                      engine=_engine_in_kernel())
+    d = P.diffeqsolve(eq, P.Tsit5(), 0.0, 0.2, 1e-4, y0, saveat=P.SaveAt(**saveat), stepsize_controller=P.PIDController(**ctl),
+                      engine=OracleEngine())
+    np.testing.assert_array_equal(c.ys, d.ys)
+
+
+def test_one_launch_adaptive_driver_step_budget_and_stall():
+    nx = 32
+    dom = std_domain(P, nx, 1)
+    eq = P.AllenCahn2DPeriodic(dom, 0.002, lambda c: c**3 - c, lambda c: np.ones_like(c))
+    y0 = np.where(np.arange(nx)[:, None] < nx // 2, -1.0, 1.0).astype(np.float64)
+    ctl = P.PIDController(rtol=1e-6, atol=1e-9)
+    ts = list(np.linspace(0.0, 0.2, 6))
+    with pytest.raises(RuntimeError, match="max_steps=5"):
+        P.diffeqsolve(eq, P.Tsit5(), 0.0, 0.2, 1e-4, y0, saveat=P.SaveAt(ts=ts), stepsize_controller=ctl, max_steps=5,
+                      engine=_engine_in_kernel())
+    a = P.diffeqsolve(eq, P.Tsit5(), 0.0, 0.2, 1e-4, y0, saveat=P.SaveAt(ts=ts, t1=True), stepsize_controller=ctl, max_steps=5,
+                      throw=False, engine=_engine_in_kernel())
+    b = P.diffeqsolve(eq, P.Tsit5(), 0.0, 0.2, 1e-4, y0, saveat=P.SaveAt(ts=ts, t1=True), stepsize_controller=ctl, max_steps=5,
+                      throw=False, engine=OracleEngine())
+    np.testing.assert_array_equal(a.ts, b.ts)
+    np.testing.assert_array_equal(a.ys, b.ys)
+    assert a.stats["num_steps"] == b.stats["num_steps"] == 5 and a.ts[-1] < 0.2
+    # per-environment: every save time is reported, the slots an environment never reached are NaN
+    per = P.PIDController(rtol=1e-6, atol=1e-9, per_environment=True)
+    yb = np.stack([y0, 0.1 * y0])
+    a = P.diffeqsolve(eq, P.Tsit5(), 0.0, 0.2, 1e-4, yb, saveat=P.SaveAt(ts=ts), stepsize_controller=per, max_steps=5, throw=False,
+                      engine=_engine_in_kernel())
+    b = P.diffeqsolve(eq, P.Tsit5(), 0.0, 0.2, 1e-4, yb, saveat=P.SaveAt(ts=ts), stepsize_controller=per, max_steps=5, throw=False,
+                      engine=OracleEngine())
+    np.testing.assert_array_equal(a.ts, b.ts)
+    assert np.array_equal(np.isnan(a.ys), np.isnan(b.ys)) and np.isnan(a.ys).any()
+    np.testing.assert_allclose(np.nan_to_num(a.ys), np.nan_to_num(b.ys), rtol=0, atol=1e-12)
+    # a step that cannot advance t ends the launch instead of spinning; the driver reports it
+    with pytest.raises(RuntimeError, match="underflow"):
+        P.diffeqsolve(eq, P.Tsit5(), 1e20, 1e20 + 1e5, 1e-4, y0, stepsize_controller=P.PIDController(rtol=1e-6, atol=1e-9, dtmax=1e-3),
+                      engine=_engine_in_kernel())
+
+
 def test_check_convergence_harness_on_the_oracle_engine(monkeypatch):
     """``numerics.utils.testing.check_convergence`` + ``numerics.symbolic`` (the reference's
     tests/test_rhs_convergence.py harness) with the oracle standing in for the GPU: second order for AC and CH."""
