@@ -13,6 +13,7 @@
 #include "stencil_fused.hpp"
 #include "stencil_fused_ac.hpp"
 #include "stencil_fused_ac4.hpp"
+#include "stencil_fused_ch4.hpp"
 #include "stencil_fused_launch.hpp"
 #include "stencil_small.hpp"
 #include "stencil_small_adaptive.hpp"
@@ -391,6 +392,8 @@ int advance_explicit(pdeopt_ctx* ctx, int integrator, double t0, double dt, int6
 
   // Allen-Cahn fp32: the whole RK4 substep in one pass (2 words per cell instead of 7)
   const bool quad = integrator == PDEOPT_INT_RK4 && ac_quad_supported(ctx);
+  // Cahn-Hilliard fp32, periodic divisible grids: the same (stencil_fused_ch4.hpp); PDEOPT_OPT_FUSE_STAGES = 2 asks for it
+  const bool chquad = integrator == PDEOPT_INT_RK4 && ctx->opt_fuse_stages == PDEOPT_CH_QUAD_FUSE && ch_quad_supported(ctx);
 
   // two Euler substeps in one launch (result into TA, TB takes the kernel's unused y + dt k2 output)
   auto euler_pair = [&](void*& Y, void*& TA) -> int {
@@ -411,6 +414,11 @@ int advance_explicit(pdeopt_ctx* ctx, int integrator, double t0, double dt, int6
     }
     if (quad) {
       r = launch_ac_quad(ctx, Y, TA, dt);
+      std::swap(Y, TA);
+      return r;
+    }
+    if (chquad) {
+      r = launch_ch_quad(ctx, Y, TA, dt);
       std::swap(Y, TA);
       return r;
     }
@@ -448,7 +456,7 @@ int advance_explicit(pdeopt_ctx* ctx, int integrator, double t0, double dt, int6
     GraphKey key;
     memset(&key, 0, sizeof(key));  // padding bytes take part in the memcmp below
     key.integrator = integrator;
-    key.fused = quad ? 100 : (euler2 ? 50 : (fused ? (int)(1 + ctx->opt_fuse_stages) : 0));
+    key.fused = quad ? 100 : chquad ? 101 : (euler2 ? 50 : (fused ? (int)(1 + ctx->opt_fuse_stages) : 0));
     key.dt = dt;
     key.Y = ctx->Y; key.TA = ctx->TA; key.TB = ctx->TB; key.ACC = ctx->ACC; key.KS = ctx->KS;
     key.ep = ctx->env_params_dev;

@@ -9,7 +9,7 @@ import pytest
 import pde_opt_amd as P
 from oracle import np_oracle as O
 from pde_opt_amd import _lib as L
-from util import MOB, MU, TOL, rel_l2, std_domain, white_noise_state
+from util import MOB, MU, TOL, inc_tol_f32, rel_l2, std_domain, white_noise_state
 
 pytestmark = pytest.mark.gpu
 
@@ -726,6 +726,47 @@ def test_allen_cahn_single_pass_rk4_equals_stage_pairs(shape, batch, mob):
     for i in range(40):
         ref = O.rk4_step(f, 0.0, ref, 5e-5)
     assert rel_l2(outs[0][0].astype(np.float64) - u[0], ref - u[0]) < 5e-4
+
+
+@pytest.mark.parametrize("closures", [("regsol", "c1mc"), ("cubic", "one_plus_sq"), ("regsol4", "c1mc")])
+@pytest.mark.parametrize("shape,batch", [((32, 128), 3), ((256, 384), 2), ((1024, 1024), 2), ((64, 256), 5)])
+def test_cahn_hilliard_single_pass_rk4_equals_stage_pairs(shape, batch, closures):
+    """csrc/stencil_fused_ch4.hpp (all four RK4 stages of Cahn-Hilliard in one pass over HBM, fp32, three LDS arrays,
+    tile + 8 halo) against the stage-pair kernels: the same mu form, face fluxes, divergence and update association
+    -- bitwise -- and against the oracle.  The smallest grid is one workgroup tile whose halo is the tile itself."""
+    mu, mob = closures
+    if mu not in MU:
+        pytest.skip("closure not in the test catalogue")
+    rng = np.random.default_rng(31)
+    nx, ny = shape
+    dom = std_domain(P, nx, ny)
+    eq = P.CahnHilliard2DPeriodic(dom, 0.002, MU[mu], MOB[mob])
+    u = white_noise_state(rng, (batch, nx, ny), np.float32, "c")
+    dt = 2e-7 if mob == "c1mc" else 2e-8
+    kappas = 0.002 * (1.0 + 0.1 * np.arange(batch))
+    outs = {}
+    for fuse in (2, 0):
+        eng = P.HipEngine()
+        eng.set_fuse_stages(fuse)
+        eng.set_small_persist(-1)
+        eng.set_graph(-1)
+        eng.configure(dtype=np.float32, batch=batch, **eq._engine_problem())
+        eng.set_env_params(0, kappa=kappas)
+        eng.set_state(u)
+        eng.advance(L.INT_RK4, dt, 7)
+        outs[fuse] = eng.get_state()
+        assert ("rk4_quad" in eng.last_kernel) == (fuse == 2), eng.last_kernel
+        eng.close()
+    assert np.isfinite(outs[2]).all() and np.any(outs[2] != u)
+    np.testing.assert_array_equal(outs[2], outs[0])
+    hx, hy = dom.dx
+    for b in (0, batch - 1):
+        f = lambda t, v: O.ch_rhs_fd(v, hx, hy, kappas[b], MU[mu], MOB[mob])
+        ref = u[b].astype(np.float64)
+        for i in range(7):
+            ref = O.rk4_step(f, 0.0, ref, dt)
+        assert np.max(np.abs(outs[2][b] - ref)) < 5e-7
+        assert rel_l2(outs[2][b].astype(np.float64) - u[b], ref - u[b]) < inc_tol_f32(ref, u[b]), b
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])

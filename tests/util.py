@@ -4,6 +4,7 @@ import numpy as np
 MU = {
     "cubic": lambda c: c**3 - c,
     "regsol": lambda c: np.log(c / (1 - c)) + 3 * (1 - 2 * c),
+    "regsol4": lambda c: np.log(c / (1 - c)) + 3 * (1 - 2 * c) + 0.5 * c**3,  # logit + a cubic polynomial part
 }
 MOB = {
     "one": lambda c: np.ones_like(c),
