@@ -167,9 +167,10 @@ typedef enum {
                                  8 = 8-cell halo (+ a tail margin): ONE exchange per RK4 substep -- the first
                                  stage pair is evaluated on the tile + 4 ring, so the second finds its input there
                                  (fused Cahn-Hilliard stage pairs only; pdeopt_rk4_phase_plan reports {0, -1}) */
-  PDEOPT_OPT_FUSE_STAGES = 4, /* RK4: temporally fused stages: 0 = auto (stage pairs 1+2 / 3+4 where a fused
-                                 kernel exists; fp32 Allen-Cahn: the whole substep in one pass), 1 = stage
-                                 pairs only, -1 = off (one launch per stage) */
+  PDEOPT_OPT_FUSE_STAGES = 4, /* RK4: temporally fused stages: 0 = auto (the whole substep in one pass over HBM where
+                                 such a kernel exists: fp32 Allen-Cahn; fp32 Cahn-Hilliard on periodic grids of 32 x 128
+                                 tiles; stage pairs 1+2 / 3+4 otherwise), 1 = stage pairs only, 2 = as 0,
+                                 -1 = off (one launch per stage) */
   PDEOPT_OPT_SMALL_PERSIST = 8,/* Euler / RK4 on grids whose stage input (+ chemical potential) fits one compute unit's
                                  LDS (CH <= 128^2 fp32, 96^2 fp64): ALL n substeps of pdeopt_advance in ONE launch, one
                                  workgroup per environment, the state in registers (the sizes of the reference's own

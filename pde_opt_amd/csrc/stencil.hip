@@ -392,8 +392,8 @@ int advance_explicit(pdeopt_ctx* ctx, int integrator, double t0, double dt, int6
 
   // Allen-Cahn fp32: the whole RK4 substep in one pass (2 words per cell instead of 7)
   const bool quad = integrator == PDEOPT_INT_RK4 && ac_quad_supported(ctx);
-  // Cahn-Hilliard fp32, periodic divisible grids: the same (stencil_fused_ch4.hpp); PDEOPT_OPT_FUSE_STAGES = 2 asks for it
-  const bool chquad = integrator == PDEOPT_INT_RK4 && ctx->opt_fuse_stages == PDEOPT_CH_QUAD_FUSE && ch_quad_supported(ctx);
+  // Cahn-Hilliard fp32, periodic divisible grids: the same (stencil_fused_ch4.hpp); PDEOPT_OPT_FUSE_STAGES = 1 keeps the stage pairs
+  const bool chquad = integrator == PDEOPT_INT_RK4 && (ctx->opt_fuse_stages == 0 || ctx->opt_fuse_stages == PDEOPT_CH_QUAD_FUSE) && ch_quad_supported(ctx);
 
   // two Euler substeps in one launch (result into TA, TB takes the kernel's unused y + dt k2 output)
   auto euler_pair = [&](void*& Y, void*& TA) -> int {

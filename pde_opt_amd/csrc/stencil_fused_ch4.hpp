@@ -274,12 +274,13 @@ __global__ __launch_bounds__(Ch4Geom::NT, Ch4Geom::kWavesPerSimd) void ch_rk4_qu
   }
 }
 
-// whether the single-pass Cahn-Hilliard RK4 kernel covers the configured problem (PDEOPT_OPT_FUSE_STAGES = 2 asks for it)
+// whether the single-pass Cahn-Hilliard RK4 kernel covers the configured problem (the default where it applies; PDEOPT_OPT_FUSE_STAGES = 1 keeps the stage pairs)
 inline bool ch_quad_supported(const pdeopt_ctx* ctx) {
   using G = Ch4Geom;
   const pdeopt_problem& p = ctx->prob;
   if (p.equation != PDEOPT_EQ_CAHN_HILLIARD || p.dtype != PDEOPT_F32 || p.derivs != PDEOPT_DERIVS_FD) return false;
   if (ctx->halo || ctx->opt_kernel_path == 1 || ctx->opt_debug_ablate) return false;
+  if (ctx->opt_tile_rows != 0 && ctx->opt_tile_rows != G::TX) return false;  // a caller asking for 16-row tiles gets the pair kernels
   if (!tiled_supported<float>(ctx)) return false;
   if (p.nx % G::TX != 0 || p.ny % G::TY != 0 || p.nx < 16 || p.ny < 16) return false;  // divisible grids; the tile + 8 halo wraps once
   return classify_closures(p.mu, p.mob) != CL_GENERIC;

@@ -40,7 +40,7 @@ def _advance(eq, solver, y0, integ, dt, n, group, **opts):
 
 # ----------------------------------------------------------------------------- grouped == ungrouped
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
-@pytest.mark.parametrize("case", ["ch_rk4_pair", "ch_rk4_stage", "ch_rk4_generic", "ch_euler_pair", "ch_euler_odd",
+@pytest.mark.parametrize("case", ["ch_rk4_quad", "ch_rk4_pair", "ch_rk4_stage", "ch_rk4_generic", "ch_euler_pair", "ch_euler_odd",
                                   "ac_rk4_quad", "ac_rk4_pair"])
 @pytest.mark.parametrize("shape,batch,group", [((64, 128), 5, 2), ((48, 40), 7, 3), ((128, 128), 4, 3)])
 def test_explicit_grouped_equals_ungrouped_bitwise(dtype, case, shape, batch, group):
@@ -64,7 +64,7 @@ def test_explicit_grouped_equals_ungrouped_bitwise(dtype, case, shape, batch, gr
         integ = L.INT_EULER
     elif case == "ch_euler_odd":
         integ, n = L.INT_EULER, 7  # pairs + one single trailing substep
-    elif case == "ac_rk4_pair":
+    elif case in ("ac_rk4_pair", "ch_rk4_pair"):
         opts["fuse_stages"] = 1
     whole, g1, k1 = _advance(eq, None, u, integ, dt, n, -1, graph=-1, **opts)
     parts, g2, k2 = _advance(eq, None, u, integ, dt, n, group, graph=-1, **opts)
@@ -72,6 +72,8 @@ def test_explicit_grouped_equals_ungrouped_bitwise(dtype, case, shape, batch, gr
     assert k1 == k2
     if case == "ch_rk4_pair":
         assert "stage_pair" in k1, k1
+    if case == "ch_rk4_quad" and dtype is np.float32 and nx % 32 == 0 and ny % 128 == 0:
+        assert "rk4_quad" in k1, k1  # the whole-substep kernel where its 32 x 128 tiles divide the grid
     if case == "ac_rk4_quad" and dtype is np.float32:
         assert "rk4_quad" in k1, k1
     assert np.isfinite(whole).all() and np.any(whole != u)
@@ -224,7 +226,7 @@ def _ch_ic(n, seed, dtype=np.float32):
 
 def test_config3_rk4_headline_batch_vs_c_oracle():
     """ch_rk4_1024_f32 exactly as bench.py runs it: 32 environments, auto grouping -> 4 groups of 8, two side by
-    side on two streams (256 MiB resident), 32-row stage-pair kernels with the XCD-aware block map.  First / last
+    side on two streams (256 MiB resident), the whole-substep kernel on 32 x 128 tiles with the XCD-aware block map.  First / last
     environment of each group against oracle/c_oracle.c (fp32 state to 5e-7 absolute, increment to 5e-4 relative)."""
     n, batch, nsub, dt = 1024, 32, 4, 2e-7
     dom = std_domain(P, n, n)
@@ -232,7 +234,7 @@ def test_config3_rk4_headline_batch_vs_c_oracle():
     y0 = np.stack([_ch_ic(n, b) for b in range(batch)])
     out, groups, kernel = _advance(eq, None, y0, L.INT_RK4, dt, nsub, 0)
     assert groups == 4, groups
-    assert kernel == "stage_pair<f32,CH,logit,rows32>", kernel
+    assert kernel == "rk4_quad<f32,CH,logit,rows32>", kernel
     hx, hy = dom.dx
     for b in (0, 7, 8, 15, 16, 23, 24, 31):
         ref = CO.rk4(0, y0[b], hx, hy, 0.002, REGSOL_C, C1MC_C, dt, nsub, threads=8)

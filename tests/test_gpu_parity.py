@@ -686,7 +686,7 @@ def test_linear_logit_class_matches_the_cubic_one():
     for coef in ((3.0, -6.0), (3.0, -6.0, 0.0, 0.0)):
         eq = P.CahnHilliard2DPeriodic(dom, 0.002, ClosureDesc(POLY, LOGIT_PRIOR, coef), MOB["c1mc"])
         sol = P.diffeqsolve(eq, P.RK4(), 0.0, 8 * 2e-7, 2e-7, y0)
-        assert "pair" in sol.stats["kernel"]
+        assert "rk4_quad" in sol.stats["kernel"]
         outs.append(sol.ys[-1])
     eps = np.finfo(np.float32).eps
     np.testing.assert_allclose(outs[0], outs[1], rtol=0, atol=8 * eps)
@@ -745,7 +745,7 @@ def test_cahn_hilliard_single_pass_rk4_equals_stage_pairs(shape, batch, closures
     dt = 2e-7 if mob == "c1mc" else 2e-8
     kappas = 0.002 * (1.0 + 0.1 * np.arange(batch))
     outs = {}
-    for fuse in (2, 0):
+    for fuse in (0, 1):  # auto: the whole-substep kernel; 1: stage pairs
         eng = P.HipEngine()
         eng.set_fuse_stages(fuse)
         eng.set_small_persist(-1)
@@ -755,18 +755,19 @@ def test_cahn_hilliard_single_pass_rk4_equals_stage_pairs(shape, batch, closures
         eng.set_state(u)
         eng.advance(L.INT_RK4, dt, 7)
         outs[fuse] = eng.get_state()
-        assert ("rk4_quad" in eng.last_kernel) == (fuse == 2), eng.last_kernel
+        assert ("rk4_quad" in eng.last_kernel) == (fuse == 0), eng.last_kernel
+        assert ("stage_pair" in eng.last_kernel) == (fuse == 1), eng.last_kernel
         eng.close()
-    assert np.isfinite(outs[2]).all() and np.any(outs[2] != u)
-    np.testing.assert_array_equal(outs[2], outs[0])
+    assert np.isfinite(outs[0]).all() and np.any(outs[0] != u)
+    np.testing.assert_array_equal(outs[0], outs[1])
     hx, hy = dom.dx
     for b in (0, batch - 1):
         f = lambda t, v: O.ch_rhs_fd(v, hx, hy, kappas[b], MU[mu], MOB[mob])
         ref = u[b].astype(np.float64)
         for i in range(7):
             ref = O.rk4_step(f, 0.0, ref, dt)
-        assert np.max(np.abs(outs[2][b] - ref)) < 5e-7
-        assert rel_l2(outs[2][b].astype(np.float64) - u[b], ref - u[b]) < inc_tol_f32(ref, u[b]), b
+        assert np.max(np.abs(outs[0][b] - ref)) < 5e-7
+        assert rel_l2(outs[0][b].astype(np.float64) - u[b], ref - u[b]) < inc_tol_f32(ref, u[b]), b
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])

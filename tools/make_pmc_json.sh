@@ -6,7 +6,7 @@ TAG=$1
 ROOT=$(cd $(dirname $0)/.. && pwd); cd $ROOT
 R=gpurun_out/round
 rm -f profiles/pmc_${TAG}.json
-python tools/pmc_to_json.py ch_rk4_1024_f32 ${TAG} stage_pair_kernel gpurun_out/busy/pmc_busy gpurun_out/busy/pmc_busy2 \
+python tools/pmc_to_json.py ch_rk4_1024_f32 ${TAG} "ch_rk4_quad_kernel|stage_pair_kernel" gpurun_out/busy/pmc_busy gpurun_out/busy/pmc_busy2 \
   $R/ch_rk4_1024_f32/pmc_fetch $R/ch_rk4_1024_f32/pmc_write $R/ch_rk4_1024_f32/pmc_sq $R/ch_rk4_1024_f32/pmc_l2 > /dev/null 2>&1
 # secondary workloads: fabric traffic + VALU issue per launch (tools/pmc_traffic.sh), every kernel of the substep
 python tools/pmc_to_json.py ac_rk4_512_f32 ${TAG} "ac_rk4_quad_kernel" $R/pmc_ac_rk4_512_f32/pmc_fetch $R/pmc_ac_rk4_512_f32/pmc_write $R/pmc_ac_rk4_512_f32/pmc_valu > /dev/null 2>&1
