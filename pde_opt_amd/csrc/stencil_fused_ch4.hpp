@@ -20,6 +20,16 @@
 // Redundant work against the cell count: mu x1.62 / 1.48 / 1.26 / 1.13, k x1.55 / 1.33 / 1.2 / 1 -- 15 % more than
 // the two pair kernels do.  The arithmetic IS the pair kernels' (same mu form, face fluxes, divergence, update
 // association): results are bitwise theirs.
+//
+// Measured on the headline (32 x 1024^2, two groups side by side; profiles/r03_ch4_experiments.txt):
+//   512 threads (every thread owns cells, rings first)                   1880-1905 env-steps/s   (stage pairs: 1826-1880)
+//   1024 threads = 512 owners + 512 helpers (mu passes, tile load)       1966
+//   ... helpers take the rings WHILE the owners march (this kernel)      2034
+//   ... as persistent workgroups, next tile + parameters by LDS-DMA under stage 4   1843  (tile load by DMA alone: 1946)
+// Phase ablation of a 78.6 us launch (PDEOPT_CH4_ABLATE): no mu passes 50.8, no rings 68.6, no marches 62.4, neither 46.9,
+// none of the three (load, 9 barriers, w writes, store) 23.3 -- close to a sum: two workgroups per CU overlap little, and
+// a persistent workgroup hiding its own load does not change that (third measurement of that kind on this part: the
+// stage-pair kernel in round 2, the Allen-Cahn kernel and this one in round 3).
 #pragma once
 
 #include <type_traits>
@@ -113,6 +123,9 @@ __global__ __launch_bounds__(Ch4Geom::NT, Ch4Geom::kWavesPerSimd) void ch_rk4_qu
   // mu(src) -> M on the tile + H region: rows [-H, TX + H), the NCV vectors of ncv(H) (stage_pair_kernel: mu_pass)
   auto mu_pass = [&](auto h_c, const T* const src0) {
     constexpr int H = decltype(h_c)::value;
+#if defined(PDEOPT_CH4_ABLATE) && (PDEOPT_CH4_ABLATE & 1)  // TIMING ONLY (tools/mkvariant.sh): no mu passes
+    return;
+#endif
     constexpr int NCV = G::ncv(H), CV0 = HV - G::hvs(H), NVEC = (TX + 2 * H) * NCV;
 #pragma unroll 3
     for (int base0 = 0; base0 < NVEC; base0 += NT) {
@@ -226,7 +239,11 @@ __global__ __launch_bounds__(Ch4Geom::NT, Ch4Geom::kWavesPerSimd) void ch_rk4_qu
   // One of the stages 1..3 after its mu pass: k on the ring of tile + H and on the own cells; w = y + cw k into dst0.
   auto stage = [&](auto h_c, const T* const src0, T* const dst0, const T cw, const T bw) {
     constexpr int H = decltype(h_c)::value;
+#if defined(PDEOPT_CH4_ABLATE) && (PDEOPT_CH4_ABLATE & 2)  // TIMING ONLY: no ring work
+    if (false) {
+#else
     if (rw >= 0) {
+#endif
       for (int idx = rw; idx < G::ring(H); idx += kRingWorkers) {
         int rr, rc;
         ring_coord(h_c, idx, &rr, &rc);
@@ -239,7 +256,11 @@ __global__ __launch_bounds__(Ch4Geom::NT, Ch4Geom::kWavesPerSimd) void ch_rk4_qu
     __builtin_amdgcn_sched_barrier(0);
     if (owner) {
       Vec k[RPT];
+#if defined(PDEOPT_CH4_ABLATE) && (PDEOPT_CH4_ABLATE & 4)  // TIMING ONLY: no march
+      for (int r = 0; r < RPT; ++r) k[r] = *reinterpret_cast<const Vec*>(M0 + (r0 + r) * P + cvo * V);
+#else
       march(src0, k);
+#endif
 #pragma unroll
       for (int r = 0; r < RPT; ++r) {
         *reinterpret_cast<Vec*>(dst0 + (r0 + r) * P + cvo * V) = yown[r] + cw * k[r];
@@ -267,7 +288,11 @@ __global__ __launch_bounds__(Ch4Geom::NT, Ch4Geom::kWavesPerSimd) void ch_rk4_qu
   // ---- stage 4 on the tile, combine, store
   if (owner) {
     Vec k4[RPT];
+#if defined(PDEOPT_CH4_ABLATE) && (PDEOPT_CH4_ABLATE & 4)
+    for (int r = 0; r < RPT; ++r) k4[r] = *reinterpret_cast<const Vec*>(M0 + (r0 + r) * P + cvo * V);
+#else
     march(B0, k4);
+#endif
     const int64_t pidx0 = base + (int64_t)(i0 + r0) * ld + (j0 + lx * V);
 #pragma unroll
     for (int r = 0; r < RPT; ++r) *reinterpret_cast<Vec*>(a.out + pidx0 + r * ld) = acc[r] + a.h6 * k4[r];
