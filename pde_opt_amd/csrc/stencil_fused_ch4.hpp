@@ -32,6 +32,7 @@
 // stage-pair kernel in round 2, the Allen-Cahn kernel and this one in round 3).
 #pragma once
 
+#include <atomic>
 #include <type_traits>
 
 #include "stencil_fused.hpp"
@@ -334,7 +335,13 @@ inline int launch_ch_quad(pdeopt_ctx* ctx, const void* y, void* out, double dt) 
   const int remap = tile_flags(nblk, tiles_i, tiles_j);
   const size_t lds = G::lds_bytes();
   auto go = [&](auto kern, const char* name) -> int {
-    PDEOPT_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    // 79.5 KB of dynamic LDS need the opt-in once per device and kernel (a static per instantiation of this lambda)
+    static std::atomic<uint64_t> allowed{0};
+    const uint64_t bit = 1ull << (ctx->device & 63);
+    if (!(allowed.load(std::memory_order_relaxed) & bit)) {
+      PDEOPT_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      allowed.fetch_or(bit, std::memory_order_relaxed);
+    }
     hipLaunchKernelGGL(kern, dim3(nblk), dim3(G::NT), lds, ctx->stream, s, tiles_i, tiles_j, nblk, remap);
     PDEOPT_HIP_CHECK(ctx, hipGetLastError());
     ctx->last_kernel = name;
