@@ -43,9 +43,18 @@ struct QuadArgs {
 #ifndef PDEOPT_AC4_THREADS
 #define PDEOPT_AC4_THREADS 512
 #endif
+#ifndef PDEOPT_AC4_HELPERS
+#define PDEOPT_AC4_HELPERS 0  // measured 17.9 k against 19.7 k env-steps/s without (512^2 x 64): this kernel lives on its three workgroups per CU
+#endif
 struct Ac4Geom {
-  static constexpr int NT = PDEOPT_AC4_THREADS;  // 256 -> 16-row tiles, 512 -> 32-row tiles
-  static constexpr int V = 4, RPT = 2, TX = (NT / kLanesPerRow) * RPT, PV = kLanesPerRow + 2, P = PV * V,
+  // NOWN threads own the tile's cells (256 -> 16-row tiles, 512 -> 32-row tiles).  PDEOPT_AC4_HELPERS doubles the
+  // workgroup: the second half owns nothing, shares the tile load and takes the ring vectors WHILE the owners
+  // evaluate their cells (stencil_fused_ch4.hpp's scheme, where it pays) -- two 1024-thread workgroups per CU
+  // (8 waves per SIMD) instead of three of 512 (6).  Slower here: the memory share of this kernel wants the third
+  // workgroup more than its stages want the shorter path.
+  static constexpr int NOWN = PDEOPT_AC4_THREADS;
+  static constexpr int NT = PDEOPT_AC4_HELPERS ? 2 * NOWN : NOWN;
+  static constexpr int V = 4, RPT = 2, TX = (NOWN / kLanesPerRow) * RPT, PV = kLanesPerRow + 2, P = PV * V,
                        TY = kLanesPerRow * V;
   static constexpr int kRows = TX + 8;  // LDS rows: tile row + 4
   static constexpr size_t lds_bytes() { return (size_t)(2 * kRows * P + 3 * V) * sizeof(float); }
@@ -71,7 +80,8 @@ __global__ __launch_bounds__(Ac4Geom::NT) void ac_rk4_quad_kernel(const QuadArgs
   using G = Ac4Geom;
   constexpr int V = G::V, RPT = G::RPT, TX = G::TX, PV = G::PV, P = G::P, TY = G::TY;
   constexpr int NT = G::NT;
-  static_assert(G::ring(3) <= NT, "largest ring must fit one pass");
+  constexpr bool HELPERS = NT > G::NOWN;
+  static_assert(G::ring(3) <= (HELPERS ? NT - G::NOWN : NT), "largest ring must fit one pass");
 
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   T* const sY = reinterpret_cast<T*>(smem_raw) + V;  // rows: tile row + 4, cols: tile col + V
@@ -96,6 +106,8 @@ __global__ __launch_bounds__(Ac4Geom::NT) void ac_rk4_quad_kernel(const QuadArgs
   const int cvo = lx + 1;
   const int lane = tid & 63;
   const bool own_l = lx == 0, own_r = lx == kLanesPerRow - 1;
+  const bool owner = tid < G::NOWN;                 // wave-uniform
+  const int rw = HELPERS ? tid - G::NOWN : tid;     // ring worker index (negative: none)
 
   constexpr bool ragged = RAGGED;
   auto wrap_row = [&](int gi) { return g.periodic ? tile_wrap(gi, g.nx, ragged) : gi; };
@@ -180,7 +192,7 @@ __global__ __launch_bounds__(Ac4Geom::NT) void ac_rk4_quad_kernel(const QuadArgs
 #pragma unroll
   for (int r = 0; r < RPT; ++r) {
     acc[r] = Vec{};
-    yown[r] = *reinterpret_cast<const Vec*>(sY + (r0 + r + 4) * P + cvo * V);
+    yown[r] = owner ? *reinterpret_cast<const Vec*>(sY + (r0 + r + 4) * P + cvo * V) : Vec{};
   }
   // y at the ring vector this thread computes in a stage (the rings of tile+3, +2, +1 are different cells) is read
   // from the y array where the stage needs it: stages 1 and 2 find it intact -- stage 2 overwrites that array with
@@ -190,10 +202,10 @@ __global__ __launch_bounds__(Ac4Geom::NT) void ac_rk4_quad_kernel(const QuadArgs
 #pragma unroll
   for (int q = 0; q < 3; ++q) {
     ring_r[q] = ring_c[q] = 0;
-    if (tid < G::ring(3 - q)) ring_coord(3 - q, tid, &ring_r[q], &ring_c[q]);
+    if (rw >= 0 && rw < G::ring(3 - q)) ring_coord(3 - q, rw, &ring_r[q], &ring_c[q]);
   }
   Vec yring3 = Vec{};
-  if (tid < G::ring(1)) yring3 = *reinterpret_cast<const Vec*>(sY + (ring_r[2] + 4) * P + ring_c[2] * V);
+  if (rw >= 0 && rw < G::ring(1)) yring3 = *reinterpret_cast<const Vec*>(sY + (ring_r[2] + 4) * P + ring_c[2] * V);
   const T half = T(0.5) * a.dt;
 
   // One of the stages 1..3: k on own cells + the ring of tile+H, then w = y + c k into the OTHER array -- the two
@@ -202,18 +214,20 @@ __global__ __launch_bounds__(Ac4Geom::NT) void ac_rk4_quad_kernel(const QuadArgs
   // Round 2 wrote w in place and needed a second barrier per stage between the reads and the writes.
   auto stage = [&](const T* src, T* dst, const int q, const T cw, const T bw) {
     const int H = 3 - q;
-    if (tid < G::ring(H)) {
+    if (rw >= 0 && rw < G::ring(H)) {
       const int rr = ring_r[q], rc = ring_c[q];
-      const bool side = tid >= 2 * H * PV;  // the two vectors beside each tile row: lanes alternate left / right
+      const bool side = rw >= 2 * H * PV;  // the two vectors beside each tile row: lanes alternate left / right
       const Vec k = k_at(src, rr, rc, side || rc == 0 || lane == 0, side || rc == PV - 1 || lane == 63);
       const Vec yr = q == 2 ? yring3 : *reinterpret_cast<const Vec*>(sY + (rr + 4) * P + rc * V);
       *reinterpret_cast<Vec*>(dst + (rr + 4) * P + rc * V) = yr + cw * k;
     }
+    if (owner) {
 #pragma unroll
-    for (int r = 0; r < RPT; ++r) {
-      const Vec k = k_at(src, r0 + r, cvo, own_l, own_r);
-      acc[r] += bw * k;
-      *reinterpret_cast<Vec*>(dst + (r0 + r + 4) * P + cvo * V) = yown[r] + cw * k;
+      for (int r = 0; r < RPT; ++r) {
+        const Vec k = k_at(src, r0 + r, cvo, own_l, own_r);
+        acc[r] += bw * k;
+        *reinterpret_cast<Vec*>(dst + (r0 + r + 4) * P + cvo * V) = yown[r] + cw * k;
+      }
     }
     __syncthreads();
   };
@@ -227,6 +241,7 @@ __global__ __launch_bounds__(Ac4Geom::NT) void ac_rk4_quad_kernel(const QuadArgs
   const T sixth = a.dt * T(1.0 / 6.0);
 #pragma unroll
   for (int r = 0; r < RPT; ++r) {
+    if (!owner) break;
     const Vec k4 = k_at(sW, r0 + r, cvo, own_l, own_r);
     if (!cell_ok(r)) continue;
 #if defined(PDEOPT_AC4_ABLATE) && (PDEOPT_AC4_ABLATE & 2)  // TIMING ONLY: no global store (the condition never holds)
