@@ -235,6 +235,7 @@ int pdeopt_ctx_destroy(pdeopt_ctx* ctx) {
   free_fields(ctx);
   if (ctx->red_dev) (void)hipFree(ctx->red_dev);
   if (ctx->red_mean_dev) (void)hipFree(ctx->red_mean_dev);
+  if (ctx->adaptive_blk) (void)hipFree(ctx->adaptive_blk);
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
   if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
   if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);

@@ -173,6 +173,8 @@ struct pdeopt_ctx {
   std::string graph_name;
   int64_t opt_fuse_stages = 0;   // RK4 stage-pair fusion: 0 auto, -1 off (one launch per stage), 1 stage pairs (AC: no single-pass kernel)
   int64_t opt_debug_ablate = 0;  // timing-only ablations, results are wrong when set
+  void* adaptive_blk = nullptr;   // save times + statistics + save slots of pdeopt_tsit5_solve_small
+  size_t adaptive_cap = 0;
   int64_t opt_group_streams = 0;  // PDEOPT_OPT_GROUP_STREAMS
   hipStream_t stream2 = nullptr;  // second stream of the two-groups-side-by-side schedule (created on first use)
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;

@@ -314,12 +314,19 @@ int small_tsit5_solve(pdeopt_ctx* ctx, double t0, double t1, double dt0, const p
   const size_t ts_bytes = ((size_t)n_save * sizeof(double) + 255) / 256 * 256;
   const size_t st_bytes = ((size_t)batch * sizeof(pdeopt_tsit5_stats) + 255) / 256 * 256;
   const size_t out_bytes = (size_t)n_save * batch * cells * sizeof(T);
-  char* blk = nullptr;
-  PDEOPT_HIP_CHECK(ctx, hipMalloc((void**)&blk, ts_bytes + st_bytes + out_bytes + 256));
-  struct Free {
-    char* p;
-    ~Free() { (void)hipFree(p); }
-  } guard{blk};
+  // kept with the ctx (grow-only): a solve of a 64^2 grid is a few hundred microseconds, a hipMalloc / hipFree pair is not free
+  const size_t need = ts_bytes + st_bytes + out_bytes + 256;
+  if (ctx->adaptive_cap < need) {
+    if (ctx->adaptive_blk) {
+      PDEOPT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+      (void)hipFree(ctx->adaptive_blk);
+      ctx->adaptive_blk = nullptr;
+      ctx->adaptive_cap = 0;
+    }
+    PDEOPT_HIP_CHECK(ctx, hipMalloc(&ctx->adaptive_blk, need));
+    ctx->adaptive_cap = need;
+  }
+  char* const blk = static_cast<char*>(ctx->adaptive_blk);
   s.save_ts = reinterpret_cast<const double*>(blk);
   s.stats = reinterpret_cast<pdeopt_tsit5_stats*>(blk + ts_bytes);
   s.save_out = reinterpret_cast<T*>(blk + ts_bytes + st_bytes);
