@@ -58,6 +58,8 @@ BUDGETS = [
     ("imex_row_fwd_reg_kernel<float, 1024>", 128, "4 waves per SIMD"),
     ("imex_row_inv_reg_kernel<float, 1024>", 128, "4 waves per SIMD"),
     ("ac_rk4_quad_kernel<4, ", 72, "single-pass Allen-Cahn, 32-row tiles: 7 waves per SIMD"),
+    # the headline's kernel: two 1024-thread workgroups per CU (79.5 KB of LDS each) = 8 waves per SIMD
+    ("ch_rk4_quad_kernel<", 64, "single-pass Cahn-Hilliard: two 1024-thread workgroups per CU"),
 ]
 
 
