@@ -150,7 +150,8 @@ typedef enum {
 /* kernel-selection knobs (pdeopt_set_option) */
 typedef enum {
   PDEOPT_OPT_KERNEL_PATH = 0, /* 0 = auto, 1 = force the generic (untiled) kernels, 2 = force LDS-tiled */
-  PDEOPT_OPT_TILE_ROWS = 1,   /* rows per LDS tile: 0 = auto, 16 or 32 */
+  PDEOPT_OPT_TILE_ROWS = 1,   /* rows per LDS tile: 0 = auto, 16 or 32; 64: the 64 x 64 tile of the single-pass
+                                 Cahn-Hilliard kernel */
   PDEOPT_OPT_GROUP_ENVS = 2,  /* explicit integrators: advance the batch in groups of this many
                                  environments so a group's working set stays in the 256 MiB
                                  Infinity Cache across stages and substeps (0 = auto, < 0 = whole

@@ -262,8 +262,8 @@ int pdeopt_set_option(pdeopt_ctx* ctx, int option, int64_t value) {
       ctx->opt_kernel_path = value;
       return PDEOPT_OK;
     case PDEOPT_OPT_TILE_ROWS:
-      if (value != 0 && value != 16 && value != 32)
-        return fail(ctx, PDEOPT_EINVAL, "tile rows must be 0 (auto), 16 or 32");
+      if (value != 0 && value != 16 && value != 32 && value != 64)
+        return fail(ctx, PDEOPT_EINVAL, "tile rows must be 0 (auto), 16, 32 or 64");
       ctx->opt_tile_rows = value;
       return PDEOPT_OK;
     case PDEOPT_OPT_IMEX_LDS_FFT:

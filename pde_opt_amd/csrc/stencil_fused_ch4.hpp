@@ -58,29 +58,35 @@ struct Quad4Args {
 #ifndef PDEOPT_CH4_THREADS
 #define PDEOPT_CH4_THREADS 1024
 #endif
-struct Ch4Geom {
+// LPR lanes (= 16-byte vectors) across a tile row.  32: the pair kernels' 32 x 128 tile.  16: a 64 x 64 tile -- the same 512
+// owners, but a shorter perimeter in vectors: the rings are 496 / 272 / 200 vectors instead of 560 / 336 / 200 (stage 1's
+// ring fits the 512 helpers in ONE trip), the tile + 8 halo is x1.56 instead of x1.69 of the tile, 74.9 KB of LDS -- and
+// 5.5 % SLOWER on the headline (short rows); it serves the grids that 64 x 64 divides and 32 x 128 does not.
+template <int LPR_>
+struct Ch4GeomT {
   // NOWN threads own the tile's cells (2 rows x 1 vector each); threads past them, if any, are helpers: they take their
   // share of the mu passes, the rings and the tile load and sit out the marches
+  static constexpr int LPR = LPR_;
   static constexpr int NOWN = 512, NT = PDEOPT_CH4_THREADS, V = 4, RPT = 2, HV = 2;
   static constexpr int kWavesPerSimd = 2 * NT / 256;  // two workgroups per CU (LDS)
-  static constexpr int TX = (NOWN / kLanesPerRow) * RPT;  // 32 rows
-  static constexpr int PV = kLanesPerRow + 2 * HV;      // 36 vectors per LDS row: the tile + 8 columns each side
-  static constexpr int P = PV * V, TY = kLanesPerRow * V;
+  static constexpr int TX = (NOWN / LPR) * RPT;         // 32 / 64 rows
+  static constexpr int PV = LPR + 2 * HV;               // vectors per LDS row: the tile + 8 columns each side
+  static constexpr int P = PV * V, TY = LPR * V;
   static constexpr int kRowsA = TX + 16, kRowsM = TX + 14, kRowsB = TX + 12;
   static constexpr size_t lds_bytes() { return (size_t)((kRowsA + kRowsM + kRowsB) * P + 4 * V) * sizeof(float); }
   // the region tile + H minus the tile, in vectors: 2 H full rows of NCV(H) vectors + 2 HVS(H) side vectors per tile row
   static constexpr int hvs(int H) { return (H + V - 1) / V; }
-  static constexpr int ncv(int H) { return kLanesPerRow + 2 * hvs(H); }
+  static constexpr int ncv(int H) { return LPR + 2 * hvs(H); }
   static constexpr int ring(int H) { return 2 * H * ncv(H) + TX * 2 * hvs(H); }
 };
+using Ch4Geom = Ch4GeomT<32>;
 
-template <int CL>
-__global__ __launch_bounds__(Ch4Geom::NT, Ch4Geom::kWavesPerSimd) void ch_rk4_quad_kernel(const Quad4Args<float> a, const int tiles_i, const int tiles_j,
+template <int CL, typename G>
+__global__ __launch_bounds__(G::NT, G::kWavesPerSimd) void ch_rk4_quad_kernel(const Quad4Args<float> a, const int tiles_i, const int tiles_j,
                                                                     const int nblk, const int xcd_remap) {
   using T = float;
   using Vec = typename VecOf<T>::type;
-  using G = Ch4Geom;
-  constexpr int V = G::V, RPT = G::RPT, TX = G::TX, PV = G::PV, P = G::P, TY = G::TY, NT = G::NT, HV = G::HV;
+  constexpr int V = G::V, RPT = G::RPT, TX = G::TX, PV = G::PV, P = G::P, TY = G::TY, NT = G::NT, HV = G::HV, LPR = G::LPR;
 
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   // pointers to (tile row 0, LDS vector column 0) of each array: element (r, cv) = base + r P + cv V, r may be negative
@@ -101,8 +107,8 @@ __global__ __launch_bounds__(Ch4Geom::NT, Ch4Geom::kWavesPerSimd) void ch_rk4_qu
   const T kap = p.kappa;
 
   const int tid = threadIdx.x;
-  const int lx = tid & 31;
-  const int ly = tid >> 5;
+  const int lx = tid & (LPR - 1);
+  const int ly = tid / LPR;
   const int r0 = ly * RPT;
   const int cvo = lx + HV;
   const bool owner = tid < G::NOWN;  // wave-uniform
@@ -212,7 +218,7 @@ __global__ __launch_bounds__(Ch4Geom::NT, Ch4Geom::kWavesPerSimd) void ch_rk4_qu
       const int t2 = idx - TOP;
       const int rr = t2 / (2 * HVS), s = t2 - rr * (2 * HVS);
       *r = rr;
-      *cv = s < HVS ? (CV0 + s) : (HV + kLanesPerRow + (s - HVS));
+      *cv = s < HVS ? (CV0 + s) : (HV + LPR + (s - HVS));
     }
   };
 
@@ -301,19 +307,31 @@ __global__ __launch_bounds__(Ch4Geom::NT, Ch4Geom::kWavesPerSimd) void ch_rk4_qu
 }
 
 // whether the single-pass Cahn-Hilliard RK4 kernel covers the configured problem (the default where it applies; PDEOPT_OPT_FUSE_STAGES = 1 keeps the stage pairs)
-inline bool ch_quad_supported(const pdeopt_ctx* ctx) {
-  using G = Ch4Geom;
+#ifndef PDEOPT_CH4_TILE
+#define PDEOPT_CH4_TILE 32  // preferred tile: 32 (x 128); 64 (x 64) where only that divides the grid.  Measured on the headline: 32 x 128 2040, 64 x 64 1927 env-steps/s
+                            // (less redundant work, but 320-byte rows: 20 of 64 lanes per load, shorter bursts)
+#endif
+// which tile shape runs the configured grid: 0 = none (the kernel does not apply), else the tile's rows (32 or 64)
+inline int ch_quad_tile(const pdeopt_ctx* ctx) {
   const pdeopt_problem& p = ctx->prob;
-  if (p.equation != PDEOPT_EQ_CAHN_HILLIARD || p.dtype != PDEOPT_F32 || p.derivs != PDEOPT_DERIVS_FD) return false;
-  if (ctx->halo || ctx->opt_kernel_path == 1 || ctx->opt_debug_ablate) return false;
-  if (ctx->opt_tile_rows != 0 && ctx->opt_tile_rows != G::TX) return false;  // a caller asking for 16-row tiles gets the pair kernels
-  if (!tiled_supported<float>(ctx)) return false;
-  if (p.nx % G::TX != 0 || p.ny % G::TY != 0 || p.nx < 16 || p.ny < 16) return false;  // divisible grids; the tile + 8 halo wraps once
-  return classify_closures(p.mu, p.mob) != CL_GENERIC;
+  if (p.equation != PDEOPT_EQ_CAHN_HILLIARD || p.dtype != PDEOPT_F32 || p.derivs != PDEOPT_DERIVS_FD) return 0;
+  if (ctx->halo || ctx->opt_kernel_path == 1 || ctx->opt_debug_ablate) return 0;
+  if (ctx->opt_tile_rows == 16) return 0;  // a caller asking for 16-row tiles gets the pair kernels
+  if (!tiled_supported<float>(ctx)) return 0;
+  if (classify_closures(p.mu, p.mob) == CL_GENERIC) return 0;
+  // divisible grids only; the tile + 8 halo wraps at most once
+  const bool ok64 = p.nx % 64 == 0 && p.ny % 64 == 0, ok32 = p.nx % 32 == 0 && p.ny % 128 == 0;
+  if (ctx->opt_tile_rows == 64) return ok64 ? 64 : 0;
+  if (ctx->opt_tile_rows == 32) return ok32 ? 32 : 0;
+  if (PDEOPT_CH4_TILE == 64 && ok64) return 64;
+  return ok32 ? 32 : (ok64 ? 64 : 0);
 }
+// whether the single-pass Cahn-Hilliard RK4 kernel covers the configured problem (the default where it applies;
+// PDEOPT_OPT_FUSE_STAGES = 1 keeps the stage pairs)
+inline bool ch_quad_supported(const pdeopt_ctx* ctx) { return ch_quad_tile(ctx) != 0; }
 
-inline int launch_ch_quad(pdeopt_ctx* ctx, const void* y, void* out, double dt) {
-  using G = Ch4Geom;
+template <typename G>
+int launch_ch_quad_g(pdeopt_ctx* ctx, const void* y, void* out, double dt) {
   const pdeopt_problem& p = ctx->prob;
   Quad4Args<float> s{};
   s.g = make_geo(ctx);
@@ -335,7 +353,7 @@ inline int launch_ch_quad(pdeopt_ctx* ctx, const void* y, void* out, double dt) 
   const int remap = tile_flags(nblk, tiles_i, tiles_j);
   const size_t lds = G::lds_bytes();
   auto go = [&](auto kern, const char* name) -> int {
-    // 79.5 KB of dynamic LDS need the opt-in once per device and kernel (a static per instantiation of this lambda)
+    // 75-80 KB of dynamic LDS need the opt-in once per device and kernel (a static per instantiation of this lambda)
     static std::atomic<uint64_t> allowed{0};
     const uint64_t bit = 1ull << (ctx->device & 63);
     if (!(allowed.load(std::memory_order_relaxed) & bit)) {
@@ -344,12 +362,16 @@ inline int launch_ch_quad(pdeopt_ctx* ctx, const void* y, void* out, double dt) 
     }
     hipLaunchKernelGGL(kern, dim3(nblk), dim3(G::NT), lds, ctx->stream, s, tiles_i, tiles_j, nblk, remap);
     PDEOPT_HIP_CHECK(ctx, hipGetLastError());
-    ctx->last_kernel = name;
+    ctx->last_kernel = std::string(name) + (G::TX == 64 ? ",rows64>" : ",rows32>");
     return PDEOPT_OK;
   };
-  if (cl == CL_LOGIT && p.mu.n <= 2) return go(ch_rk4_quad_kernel<CL_LOGIT1>, "rk4_quad<f32,CH,logit,rows32>");
-  if (cl == CL_LOGIT) return go(ch_rk4_quad_kernel<CL_LOGIT>, "rk4_quad<f32,CH,logit,rows32>");
-  return go(ch_rk4_quad_kernel<CL_POLY>, "rk4_quad<f32,CH,poly,rows32>");
+  if (cl == CL_LOGIT && p.mu.n <= 2) return go(ch_rk4_quad_kernel<CL_LOGIT1, G>, "rk4_quad<f32,CH,logit");
+  if (cl == CL_LOGIT) return go(ch_rk4_quad_kernel<CL_LOGIT, G>, "rk4_quad<f32,CH,logit");
+  return go(ch_rk4_quad_kernel<CL_POLY, G>, "rk4_quad<f32,CH,poly");
+}
+
+inline int launch_ch_quad(pdeopt_ctx* ctx, const void* y, void* out, double dt) {
+  return ch_quad_tile(ctx) == 64 ? launch_ch_quad_g<Ch4GeomT<16>>(ctx, y, out, dt) : launch_ch_quad_g<Ch4GeomT<32>>(ctx, y, out, dt);
 }
 
 }  // namespace pdeopt

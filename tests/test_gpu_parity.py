@@ -729,11 +729,12 @@ def test_allen_cahn_single_pass_rk4_equals_stage_pairs(shape, batch, mob):
 
 
 @pytest.mark.parametrize("closures", [("regsol", "c1mc"), ("cubic", "one_plus_sq"), ("regsol4", "c1mc")])
-@pytest.mark.parametrize("shape,batch", [((32, 128), 3), ((256, 384), 2), ((1024, 1024), 2), ((64, 256), 5)])
+@pytest.mark.parametrize("shape,batch", [((32, 128), 3), ((256, 384), 2), ((1024, 1024), 2), ((64, 256), 5), ((128, 192), 2), ((64, 64), 3)])
 def test_cahn_hilliard_single_pass_rk4_equals_stage_pairs(shape, batch, closures):
     """csrc/stencil_fused_ch4.hpp (all four RK4 stages of Cahn-Hilliard in one pass over HBM, fp32, three LDS arrays,
     tile + 8 halo) against the stage-pair kernels: the same mu form, face fluxes, divergence and update association
-    -- bitwise -- and against the oracle.  The smallest grid is one workgroup tile whose halo is the tile itself."""
+    -- bitwise -- and against the oracle.  The smallest grids are one workgroup tile whose halo is the tile itself;
+    (128, 192) and (64, 64) run the 64 x 64 tile."""
     mu, mob = closures
     if mu not in MU:
         pytest.skip("closure not in the test catalogue")
@@ -757,6 +758,8 @@ def test_cahn_hilliard_single_pass_rk4_equals_stage_pairs(shape, batch, closures
         outs[fuse] = eng.get_state()
         assert ("rk4_quad" in eng.last_kernel) == (fuse == 0), eng.last_kernel
         assert ("stage_pair" in eng.last_kernel) == (fuse == 1), eng.last_kernel
+        if fuse == 0:  # 32 x 128 tiles where they divide the grid, 64 x 64 tiles otherwise
+            assert ("rows32" in eng.last_kernel) == (ny % 128 == 0), eng.last_kernel
         eng.close()
     assert np.isfinite(outs[0]).all() and np.any(outs[0] != u)
     np.testing.assert_array_equal(outs[0], outs[1])
