@@ -33,6 +33,14 @@ int ensure_buffer(pdeopt_ctx* ctx, void** p, size_t bytes) {
   return PDEOPT_OK;
 }
 
+int ensure_stream2(pdeopt_ctx* ctx) {
+  if (ctx->stream2) return PDEOPT_OK;
+  PDEOPT_HIP_CHECK(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+  PDEOPT_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+  PDEOPT_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+  return PDEOPT_OK;
+}
+
 namespace {
 
 void free_fields(pdeopt_ctx* ctx) {

@@ -236,6 +236,7 @@ int fail(pdeopt_ctx* ctx, int code, const char* fmt, ...);
   } while (0)
 
 int ensure_buffer(pdeopt_ctx* ctx, void** p, size_t bytes);
+int ensure_stream2(pdeopt_ctx* ctx);  // the ctx's second stream + fork / join events, created on first use
 // api.hip: bring a time-dependent auxiliary field to local time t (no-op for static fields)
 int refresh_time_aux(pdeopt_ctx* ctx, int which, double t);
 inline bool has_time_aux(const pdeopt_ctx* ctx, int which) { return ctx->aux[which].fn != nullptr; }

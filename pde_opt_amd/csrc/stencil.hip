@@ -505,11 +505,7 @@ int advance_explicit(pdeopt_ctx* ctx, int integrator, double t0, double dt, int6
   ctx->last_groups = (batch + group - 1) / group;
   if (side_by_side && ctx->last_groups >= 2) {
     ctx->last_group_streams = 2;
-    if (!ctx->stream2) {
-      PDEOPT_HIP_CHECK(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
-      PDEOPT_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
-      PDEOPT_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
-    }
+    if ((rc = ensure_stream2(ctx))) return rc;
     // the second stream starts after everything already queued on the ctx stream (the state upload, the previous call)
     PDEOPT_HIP_CHECK(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
     PDEOPT_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));

@@ -547,11 +547,7 @@ int strang_fused_t(pdeopt_ctx* ctx, double t0, double dt, int64_t n) {
   };
   if (side_by_side && ctx->last_groups >= 2) {
     ctx->last_group_streams = 2;
-    if (!ctx->stream2) {
-      PDEOPT_HIP_CHECK(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
-      PDEOPT_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
-      PDEOPT_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
-    }
+    if ((rc = ensure_stream2(ctx))) return rc;
     PDEOPT_HIP_CHECK(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
     PDEOPT_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
     auto on = [&](int lo, bool second, auto fn) -> int {
@@ -863,11 +859,7 @@ int imex_fused_t(pdeopt_ctx* ctx, double dt, int64_t n) {
   }
   if (ctx->opt_group_streams == 2 && ctx->last_groups >= 2 && n > 1) {
     ctx->last_group_streams = 2;
-    if (!ctx->stream2) {
-      PDEOPT_HIP_CHECK(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
-      PDEOPT_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
-      PDEOPT_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
-    }
+    if ((rc = ensure_stream2(ctx))) return rc;
     PDEOPT_HIP_CHECK(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
     PDEOPT_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
     for (int lo = 0; lo < p.batch && !rc; lo += 2 * group) {
