@@ -11,5 +11,6 @@ timeout 2400 bash tools/profile_round.sh
 [ -x tools/valubench.bin ] && timeout 200 ./tools/valubench.bin > gpurun_out/valubench.txt 2>&1
 [ -x tools/lds_issue_bench.bin ] && timeout 200 ./tools/lds_issue_bench.bin > gpurun_out/lds_issue_bench.txt 2>&1
 timeout 300 python tools/adaptive_bench.py > gpurun_out/adaptive_bench.txt 2>&1
+timeout 300 python tools/single_env_latency.py > gpurun_out/single_env_latency.txt 2>&1
 timeout 300 python tools/small_grid_bench.py ch > gpurun_out/small_grid_ch.txt 2>&1
 tail -4 gpurun_out/busy_summary.txt | cut -c1-400
