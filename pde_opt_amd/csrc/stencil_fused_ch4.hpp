@@ -62,13 +62,13 @@ struct Quad4Args {
 // owners, but a shorter perimeter in vectors: the rings are 496 / 272 / 200 vectors instead of 560 / 336 / 200 (stage 1's
 // ring fits the 512 helpers in ONE trip), the tile + 8 halo is x1.56 instead of x1.69 of the tile, 74.9 KB of LDS -- and
 // 5.5 % SLOWER on the headline (short rows); it serves the grids that 64 x 64 divides and 32 x 128 does not.
-template <int LPR_>
+template <int LPR_, int NOWN_ = 512, int NT_ = PDEOPT_CH4_THREADS, int WGS_PER_CU_ = 2>
 struct Ch4GeomT {
   // NOWN threads own the tile's cells (2 rows x 1 vector each); threads past them, if any, are helpers: they take their
   // share of the mu passes, the rings and the tile load and sit out the marches
   static constexpr int LPR = LPR_;
-  static constexpr int NOWN = 512, NT = PDEOPT_CH4_THREADS, V = 4, RPT = 2, HV = 2;
-  static constexpr int kWavesPerSimd = 2 * NT / 256;  // two workgroups per CU (LDS)
+  static constexpr int NOWN = NOWN_, NT = NT_, V = 4, RPT = 2, HV = 2;
+  static constexpr int kWavesPerSimd = (WGS_PER_CU_ * NT / 64 + 3) / 4;  // WGS_PER_CU workgroups per CU (LDS)
   static constexpr int TX = (NOWN / LPR) * RPT;         // 32 / 64 rows
   static constexpr int PV = LPR + 2 * HV;               // vectors per LDS row: the tile + 8 columns each side
   static constexpr int P = PV * V, TY = LPR * V;
@@ -371,6 +371,9 @@ int launch_ch_quad_g(pdeopt_ctx* ctx, const void* y, void* out, double dt) {
 }
 
 inline int launch_ch_quad(pdeopt_ctx* ctx, const void* y, void* out, double dt) {
+#ifdef PDEOPT_CH4_ROWS16  // A/B build: 16 x 128 tiles, 256 owners + helpers, three workgroups per CU (51.8 KB each)
+  if (ch_quad_tile(ctx) == 32) return launch_ch_quad_g<Ch4GeomT<32, 256, PDEOPT_CH4_ROWS16, 3>>(ctx, y, out, dt);
+#endif
   return ch_quad_tile(ctx) == 64 ? launch_ch_quad_g<Ch4GeomT<16>>(ctx, y, out, dt) : launch_ch_quad_g<Ch4GeomT<32>>(ctx, y, out, dt);
 }
 
