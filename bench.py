@@ -477,8 +477,6 @@ def run_decomp(args, P, world, rank, local_rank, dist, make_solver=None):
         e.close()
     if spot is not None and not spot["parity_spot_ok"]:
         raise SystemExit(f"parity spot check FAILED: {spot}")
-    if bad > 0:
-        raise SystemExit(f"the timed state holds {int(bad)} non-finite cells: the run measured NaN arithmetic")
     return spot
 
 
@@ -801,6 +799,8 @@ def main():
     eng.close()
     if spot is not None and not spot["parity_spot_ok"]:
         raise SystemExit(f"parity spot check FAILED: {spot}")
+    if bad > 0:
+        raise SystemExit(f"the timed state holds {int(bad)} non-finite cells: the run measured NaN arithmetic")
 
 
 if __name__ == "__main__":
