@@ -150,8 +150,8 @@ SPOT_TOL_F64 = {"rk4": 1e-9, "imex": 1e-8, "strang": 1e-10}
 SPOT_ABS_TOL_F32 = 5e-7
 
 # per-launch PMC averages of this round's build (tools/pmc_to_json.py); the previous round's while none is committed yet
-PMC_FILE = next((f for f in (os.path.join(ROOT, "profiles", n) for n in ("pmc_r03.json", "pmc_r02.json")) if os.path.exists(f)),
-                os.path.join(ROOT, "profiles", "pmc_r03.json"))
+PMC_FILE = next((f for f in (os.path.join(ROOT, "profiles", n) for n in ("pmc_r04.json", "pmc_r03.json", "pmc_r02.json")) if os.path.exists(f)),
+                os.path.join(ROOT, "profiles", "pmc_r04.json"))
 N_SIMD, SHADER_HZ = 1024, 2.4e9  # 256 CUs x 4 SIMDs; MI355X_MICROARCH.md chip table
 # What the VALU can do, measured IN the kernel (tools/valubench.hip: s_memtime / s_memrealtime stamps around >= 1 ms bodies,
 # profiles/r03_valubench_raw.txt): a SIMD issues one wave64 fp32 VALU instruction per ~2 shader cycles once >= 3 waves are
@@ -298,34 +298,44 @@ def api_throughput(P, name, rank, steps, warmup):
     return out
 
 
-def decomp_roofline(bytes_per_gpu, elapsed, substeps_total, tile_shape):
-    """The decomposed field runs the headline's stage-pair kernels on one tile per GPU (two launches per substep): the
-    same two pipes as the headline -- fabric traffic and VALU, from that kernel's counters scaled by the cells a launch
-    covers -- over the WALL time of the substep loop, halo exchange included."""
+def decomp_roofline(bytes_per_gpu, elapsed, launches, tile_shape, kernel_name, concurrent=1):
+    """The decomposed field's roofline: SURVEY 8(d)'s algorithmic bytes of one GPU's share over the WALL time of the
+    substep loop (halo exchange included), and -- where a PMC profile OF THIS WORKLOAD AT THIS TILE SIZE is committed
+    (profiles/pmc_<round>.json, key ch_rk4_decomp_tile<nx>x<ny>: rocprofv3 --pmc passes of `bench.py --workload
+    ch_rk4_4096_decomp --decomp-grid <nx>`) -- the fabric traffic and VALU-busy share of the kernel(s) that ran, per launch,
+    over the wall time per launch.  No other workload's counters are scaled in (round 3 did that and priced stage-pair
+    launches with the whole-substep kernel's counters).  `launches`: stencil launches of ONE rank in the timed region;
+    `concurrent`: ranks sharing the GPU (virtual ranks), whose launches run side by side."""
     alg_gbs = bytes_per_gpu / elapsed / 1e9
-    r = {"bound": "hbm", "achieved": alg_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg_gbs / HBM_PEAK_GBS, "traffic": None,
-         "algorithmic_gbs": alg_gbs, "algorithmic_frac_of_hbm_peak": alg_gbs / HBM_PEAK_GBS, "launches_timed": 2 * substeps_total,
-         "note": "per-GPU share of SURVEY 8(d)'s algorithmic bytes over the WALL time of the substep loop (exchange included)"}
+    launch_s = elapsed / max(launches, 1)
+    key = "ch_rk4_decomp_tile%dx%d" % tuple(tile_shape)
+    r = {"bound": "hbm", "kernel": kernel_name, "achieved": alg_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg_gbs / HBM_PEAK_GBS,
+         "traffic": None, "algorithmic_gbs": alg_gbs, "algorithmic_frac_of_hbm_peak": alg_gbs / HBM_PEAK_GBS,
+         "launches_timed": launches, "concurrent_launches": concurrent, "avg_launch_us": launch_s * 1e6,
+         "note": "per-GPU share of SURVEY 8(d)'s algorithmic bytes over the WALL time of the substep loop (exchange included); "
+                 "avg_launch_us = wall time per stencil launch of one rank; no PMC profile of this workload at this tile size (" + key + ") is committed"}
     try:
-        pmc = json.load(open(PMC_FILE)).get("ch_rk4_1024_f32")
+        pmc = json.load(open(PMC_FILE)).get(key)
     except Exception:
         pmc = None
     if pmc and pmc.get("hbm_bytes_per_launch"):
-        scale = (tile_shape[0] * tile_shape[1]) / (16.0 * 1024 * 1024)  # the profiled launch covers 16 x 1024^2 cells
-        launch_s = elapsed / (2 * substeps_total)
         c = pmc["counters_per_launch"]
-        r["traffic"] = pmc["hbm_bytes_per_launch"] * scale
-        r["traffic_gbs"] = r["traffic"] / launch_s / 1e9
+        r["traffic"] = pmc["hbm_bytes_per_launch"]
+        r["traffic_gbs"] = concurrent * r["traffic"] / launch_s / 1e9
         r["traffic_frac"] = r["traffic_gbs"] / HBM_PEAK_GBS
-        r["avg_launch_us"] = launch_s * 1e6
         r["achieved"], r["frac"] = r["traffic_gbs"], r["traffic_frac"]
+        r["pmc_kernels"] = pmc.get("kernels")
         if c.get("SQ_ACTIVE_INST_VALU"):
-            # VALU-busy cycles of the kernel (4 per instruction) over the wall cycles per launch, against an all-VALU kernel's reading
-            r["valu_util"] = 4.0 * c["SQ_ACTIVE_INST_VALU"] * scale / N_SIMD / (launch_s * SHADER_HZ) / VALU_BUSY_SATURATED
-        r["note"] = ("stage_pair_kernel on one tile per GPU: fabric bytes and VALU-busy cycles of that kernel (" + os.path.relpath(PMC_FILE, ROOT) +
-                     ", ch_rk4_1024_f32) scaled by the cells of a launch, over the WALL time per launch of the substep loop -- halo exchange "
-                     "included; at a 2048^2 tile the 1024 workgroup tiles of a launch take two rounds on the chip's 768 resident slots "
-                     "(DESIGN.md section 6), which is what holds this fraction below the headline's")
+            # VALU-busy cycles of the launch (4 per instruction) over the wall cycles per launch, against an all-VALU kernel's reading
+            r["valu_util"] = concurrent * 4.0 * c["SQ_ACTIVE_INST_VALU"] / N_SIMD / (launch_s * SHADER_HZ) / VALU_BUSY_SATURATED
+            r["valu_insts_per_launch"] = c.get("SQ_INSTS_VALU")
+            if r["valu_util"] > r["traffic_frac"]:
+                r.update(bound="valu", achieved=r["valu_util"], peak=1.0, frac=r["valu_util"],
+                         unit="VALU utilisation (SQ_ACTIVE_INST_VALU share of SIMD cycles / what an all-VALU kernel reads: 1.62)")
+        r["pmc_source"] = os.path.relpath(PMC_FILE, ROOT) + ": " + pmc.get("source", "")
+        r["note"] = ("counters of THIS workload's own kernel(s) at this tile size (" + key + ", per launch, committed rocprofv3 --pmc profile) "
+                     "over the live WALL time per launch of the substep loop, halo exchange included; algorithmic_gbs = SURVEY 8(d)'s 64 B "
+                     "per cell and substep over the same time")
     return r
 
 
@@ -425,23 +435,35 @@ def run_decomp(args, P, world, rank, local_rank, dist, make_solver=None):
         advance(nspot)
         for e in engines:
             e.sync()
-        if rank == 0:
-            from oracle import c_oracle as CO
+        # ... and EVERY rank compares ITS tile with the C oracle run on the whole periodic field (each rank runs the
+        # oracle itself: 7 substeps of the 4096^2 field are a fraction of a second per rank); the worst rank's errors
+        # travel to rank 0 (max all-reduce), which reports them -- a wrong tile on any rank fails the run
+        from oracle import c_oracle as CO
 
-            _, cmu, cmob = _oracle_closures(WORKLOADS["ch_rk4_1024_f32"])
-            ref = CO.rk4(0, y0, dom.dx[0], dom.dx[1], 0.002, cmu, cmob, dt, nspot, threads=usable_cores()).astype(np.float64)
-            rel = mabs = 0.0
-            for s_ in sols:  # all virtual ranks' tiles (one tile under torchrun: this rank's)
-                got = s_.local_state().astype(np.float64)
-                si, sj = s_.grid.tile_slices(n, n)
-                base = y0[si, sj].astype(np.float64)
-                rel = max(rel, float(np.linalg.norm((got - base) - (ref[si, sj] - base)) / np.linalg.norm(ref[si, sj] - base)))
-                mabs = max(mabs, float(np.max(np.abs(got - ref[si, sj]))))
-            spot = {"parity_spot_rel_err": rel, "parity_spot_max_abs_err": mabs,
-                    "parity_spot_tol": SPOT_TOL_F32["rk4"], "parity_spot_max_abs_tol": SPOT_ABS_TOL_F32,
-                    "parity_spot_ok": bool(rel < SPOT_TOL_F32["rk4"] and mabs < SPOT_ABS_TOL_F32),
-                    "parity_spot": f"{len(sols)} tile(s) of {sol.tile_shape[0]}x{sol.tile_shape[1]} after {nspot} substeps "
-                                   f"({sol.mode}) vs oracle/c_oracle.c on the whole periodic field"}
+        _, cmu, cmob = _oracle_closures(WORKLOADS["ch_rk4_1024_f32"])
+        ref = CO.rk4(0, y0, dom.dx[0], dom.dx[1], 0.002, cmu, cmob, dt, nspot, threads=usable_cores()).astype(np.float64)
+        rel = mabs = 0.0
+        for s_ in sols:  # all virtual ranks' tiles (one tile under torchrun: this rank's)
+            got = s_.local_state().astype(np.float64)
+            si, sj = s_.grid.tile_slices(n, n)
+            base = y0[si, sj].astype(np.float64)
+            e_rel = float(np.linalg.norm((got - base) - (ref[si, sj] - base)) / np.linalg.norm(ref[si, sj] - base))
+            e_abs = float(np.max(np.abs(got - ref[si, sj])))
+            rel = max(rel, e_rel if np.isfinite(e_rel) else np.inf)  # max(0.0, nan) is 0.0: a NaN tile must not pass
+            mabs = max(mabs, e_abs if np.isfinite(e_abs) else np.inf)
+        tiles_checked = len(sols)
+        if dist is not None and world > 1:
+            import torch
+
+            worst = torch.tensor([rel, mabs], dtype=torch.float64, device="cuda" if on_gpu else "cpu")
+            dist.all_reduce(worst, op=dist.ReduceOp.MAX)
+            rel, mabs = float(worst[0]), float(worst[1])
+            tiles_checked = world
+        spot = {"parity_spot_rel_err": rel, "parity_spot_max_abs_err": mabs,
+                "parity_spot_tol": SPOT_TOL_F32["rk4"], "parity_spot_max_abs_tol": SPOT_ABS_TOL_F32,
+                "parity_spot_ok": bool(rel < SPOT_TOL_F32["rk4"] and mabs < SPOT_ABS_TOL_F32),
+                "parity_spot": f"all {tiles_checked} tile(s) of {sol.tile_shape[0]}x{sol.tile_shape[1]} after {nspot} substeps "
+                               f"({sol.mode}), each rank against oracle/c_oracle.c on the whole periodic field (worst rank reported)"}
     if dist is not None and world > 1:
         dist.barrier()
     if rank == 0:
@@ -455,6 +477,7 @@ def run_decomp(args, P, world, rank, local_rank, dist, make_solver=None):
             "config": {"workload": "ch_rk4_4096_decomp", "grid": [n, n], "tiles": [px, py], "tile": list(sol.tile_shape),
                        "integrator": "rk4", "dt": dt, "substeps_per_env_step": substeps, "halo": getattr(sol.backend, "halo", 4),
                        "exchange": f"one all-gather of packed halo strips per {'substep' if nex == 1 else 'fused stage pair'} ({nex} per substep)",
+                       "stencil_launches_per_substep": launches / max(args.steps * substeps, 1),
                        "ranks": (f"{vranks} virtual ranks on ONE GPU (in-process group, csrc/comm.hip: the RCCL run's loop with device "
                                  "copies as the collective)") if vranks else f"{world} process(es), one GPU each",
                        "strip_bytes": int(sol.backend.strip_elems) * 4, "driver_mode": sol.mode, "kernel": eng.last_kernel},
@@ -464,8 +487,8 @@ def run_decomp(args, P, world, rank, local_rank, dist, make_solver=None):
             "achieved_gbs_whole_job": total_bytes / elapsed / 1e9,
             "nonfinite_cells": float(np.size(tile) - np.isfinite(tile).sum()),
             **(spot or {}),
-            "roofline": decomp_roofline(total_bytes / max(world, 1), elapsed, args.steps * substeps,
-                                        (n, n) if vranks else sol.tile_shape),
+            "roofline": decomp_roofline(total_bytes / max(world, 1), elapsed, launches, sol.tile_shape, eng.last_kernel,
+                                        concurrent=vranks or 1),
         }
         print(json.dumps(line))
         sys.stdout.flush()

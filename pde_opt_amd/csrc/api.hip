@@ -619,13 +619,31 @@ int pdeopt_advance(pdeopt_ctx* ctx, int integrator, double t0, double dt, int64_
   ctx->last_group_streams = 1;
   if (ctx->halo)
     return fail(ctx, PDEOPT_EINVAL, "padded layout: drive the substep with pdeopt_rk4_phase + halo exchange");
+  if (integrator != PDEOPT_INT_EULER && integrator != PDEOPT_INT_RK4) {  // a table sampled for a fixed-step advance is stale here
+    ctx->tt_times.clear();
+    ctx->tt_terms.clear();
+    ctx->tt_cursor = 0;
+  }
   const int eq = ctx->prob.equation;
   switch (integrator) {
     case PDEOPT_INT_EULER:
     case PDEOPT_INT_RK4:
       if (eq == PDEOPT_EQ_GPE)
         return fail(ctx, PDEOPT_EINVAL, "the GPE is integrated by Strang splitting only");
-      return advance_explicit(ctx, integrator, t0, dt, n_substeps);
+    {
+      ctx->tt_misses = 0;
+      const int rc = advance_explicit(ctx, integrator, t0, dt, n_substeps);
+      // the table of pdeopt_set_time_table belongs to the advance it was sampled for: it does not outlive it
+      const bool had_table = !ctx->tt_times.empty();
+      ctx->tt_times.clear();
+      ctx->tt_terms.clear();
+      ctx->tt_cursor = 0;
+      if (!rc && had_table && ctx->tt_misses)
+        return fail(ctx, PDEOPT_EINVAL, "pdeopt_set_time_table: %lld stage time(s) of this advance are not in the table and no "
+                    "pdeopt_set_time_terms callback is registered (times must be formed as t0 + (double) s * dt, + dt / 2, + dt)",
+                    (long long)ctx->tt_misses);
+      return rc;
+    }
     case PDEOPT_INT_IMEX:
       if (eq != PDEOPT_EQ_CAHN_HILLIARD && eq != PDEOPT_EQ_ALLEN_CAHN && eq != PDEOPT_EQ_CAHN_HILLIARD_3D)
         return fail(ctx, PDEOPT_EINVAL, "IMEX needs a periodic Cahn-Hilliard/Allen-Cahn equation");

@@ -173,12 +173,28 @@ int comm_init_local(pdeopt_ctx* ctx, pdeopt_local_group* g, int rank) {
   c.world = g->world;
   c.rank = rank;
   c.seq = 0;
-  for (int p = 0; p < 2; ++p) {
-    PDEOPT_HIP_CHECK(ctx, hipEventCreateWithFlags(&g->ready[p][rank], hipEventDisableTiming));
-    PDEOPT_HIP_CHECK(ctx, hipEventCreateWithFlags(&g->done[p][rank], hipEventDisableTiming));
+  for (int p = 0; p < 2; ++p) {  // the events stay with the group: a rank that re-attaches finds its own again
+    if (!g->ready[p][rank]) PDEOPT_HIP_CHECK(ctx, hipEventCreateWithFlags(&g->ready[p][rank], hipEventDisableTiming));
+    if (!g->done[p][rank]) PDEOPT_HIP_CHECK(ctx, hipEventCreateWithFlags(&g->done[p][rank], hipEventDisableTiming));
   }
   return PDEOPT_OK;
 }
+
+namespace {
+// host-side wait for the peers' copies out of this rank's send buffers (done[p][r] of every exchange recorded so far)
+void wait_peer_copies(CommState& c) {
+  pdeopt_local_group& g = *c.group;
+  for (int p = 0; p < 2; ++p)
+    for (int r = 0; r < c.world; ++r) {
+      hipEvent_t e = nullptr;
+      {
+        std::lock_guard<std::mutex> lk(g.m);
+        if (r != c.rank && g.done_recorded[p][r]) e = g.done[p][r];
+      }
+      if (e) (void)hipEventSynchronize(e);
+    }
+}
+}  // namespace
 
 void comm_destroy(pdeopt_ctx* ctx) {
   CommState* c = ctx->comm;
@@ -187,10 +203,22 @@ void comm_destroy(pdeopt_ctx* ctx) {
   if (c->cstream) (void)hipStreamSynchronize(c->cstream);
   if (c->comm) (void)c->comm_destroy(c->comm);
   if (c->group) {
+    // peers copy OUT of this rank's send buffers on their own streams (other devices, with one engine per GPU): their
+    // copies of every exchange so far must have run before the buffers are freed
+    wait_peer_copies(*c);
     // the group outlives its members' buffers: un-publish them (the events stay with the group until it is destroyed)
     std::lock_guard<std::mutex> lk(c->group->m);
     c->group->send[0][c->rank] = c->group->send[1][c->rank] = nullptr;
     c->group->attached[c->rank] = 0;
+    c->group->done_recorded[0][c->rank] = c->group->done_recorded[1][c->rank] = 0;
+    // a group whose barrier timed out (or whose rank failed) is `broken` for good while any rank is attached: every
+    // rank's call fails from then on.  It recovers once ALL ranks have detached (pdeopt_comm_destroy / ctx_destroy)
+    bool any = false;
+    for (int a : c->group->attached) any = any || a;
+    if (!any) {
+      c->group->broken = false;
+      c->group->arrived = 0;
+    }
   }
   if (c->send2) (void)hipFree(c->send2);
   if (c->send) (void)hipFree(c->send);
@@ -294,7 +322,8 @@ int rk4_decomposed_advance(pdeopt_ctx* ctx, double dt, int64_t n, const int* nbr
   int rc;
   if (c.strip_bytes != strip_bytes) {
     PDEOPT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-    if (c.local()) {  // nobody may still be copying out of the old buffers: the group is idle between advance calls
+    if (c.local()) {  // nobody may still be copying out of the old buffers: wait for the peers' last copies
+      wait_peer_copies(c);
       std::lock_guard<std::mutex> lk(c.group->m);
       c.group->send[0][c.rank] = c.group->send[1][c.rank] = nullptr;
     }

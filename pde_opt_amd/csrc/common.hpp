@@ -149,6 +149,7 @@ struct pdeopt_ctx {
   // pdeopt_set_time_table: the three scalars at a list of evaluation times, looked up before the callback is asked
   std::vector<double> tt_times, tt_terms;
   size_t tt_cursor = 0;
+  int64_t tt_misses = 0;  // stage times a non-empty table did not hold while no callback was registered
   void* env_params_dev = nullptr;
   std::vector<char> env_params_host;
   pdeopt::AuxField aux[pdeopt::kNumAux];
@@ -164,7 +165,7 @@ struct pdeopt_ctx {
   int pair_nbr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   void* halo_scratch = nullptr;  // single-rank loop-back buffer for pack/unpack
   void* halo_scratch2 = nullptr; // second loop-back strip (halo-8 loop: fused pack writes one while the next is read)
-  size_t halo_scratch_bytes = 0;
+  size_t halo_scratch_bytes = 0, halo_scratch2_bytes = 0;
   int64_t opt_imex_lds_fft = 0;  // IMEX transforms: 0 auto (hand-written passes where the size is covered), -1 rocFFT
   int64_t opt_graph = 0;         // hipGraph replay of the substep loop: 0 auto (launch-bound sizes), 1 always, -1 never
   hipGraphExec_t graph_exec = nullptr;

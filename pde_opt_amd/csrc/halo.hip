@@ -123,7 +123,7 @@ int ensure_scratch(pdeopt_ctx* ctx, size_t bytes) {
   if (ctx->halo_scratch) (void)hipFree(ctx->halo_scratch);
   if (ctx->halo_scratch2) (void)hipFree(ctx->halo_scratch2);  // sized like the first (stencil.hip: loop-back, halo 8)
   ctx->halo_scratch = ctx->halo_scratch2 = nullptr;
-  ctx->halo_scratch_bytes = 0;
+  ctx->halo_scratch_bytes = ctx->halo_scratch2_bytes = 0;
   int rc = ensure_buffer(ctx, &ctx->halo_scratch, bytes);
   if (!rc) ctx->halo_scratch_bytes = bytes;
   return rc;

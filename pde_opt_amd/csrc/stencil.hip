@@ -71,6 +71,9 @@ StageArgs<T> make_args(pdeopt_ctx* ctx, const void* in, const void* y, void* out
       }
     }
     if (!found && ctx->time_fn) ctx->time_fn(ctx->cur_t, tv, ctx->time_user);
+    // a table that does not hold this stage time and no callback to ask: the constant terms would be used silently
+    // (a caller whose times differ from the library's t0 + s dt, + dt/2 arithmetic by an ulp) -- pdeopt_advance reports it
+    if (!found && !ctx->time_fn && nt) ctx->tt_misses++;
     s.tw_a = T(tv[0]);
     s.tw_b = T(tv[1]);
     s.tsrc = T(tv[2]);
@@ -393,7 +396,7 @@ int advance_explicit(pdeopt_ctx* ctx, int integrator, double t0, double dt, int6
   // Allen-Cahn fp32: the whole RK4 substep in one pass (2 words per cell instead of 7)
   const bool quad = integrator == PDEOPT_INT_RK4 && ac_quad_supported(ctx);
   // Cahn-Hilliard fp32, periodic divisible grids: the same (stencil_fused_ch4.hpp); PDEOPT_OPT_FUSE_STAGES = 1 keeps the stage pairs
-  const bool chquad = integrator == PDEOPT_INT_RK4 && (ctx->opt_fuse_stages == 0 || ctx->opt_fuse_stages == PDEOPT_CH_QUAD_FUSE) && ch_quad_supported(ctx);
+  const bool chquad = integrator == PDEOPT_INT_RK4 && ch_quad_chosen(ctx);
 
   // two Euler substeps in one launch (result into TA, TB takes the kernel's unused y + dt k2 output)
   auto euler_pair = [&](void*& Y, void*& TA) -> int {
@@ -579,7 +582,11 @@ void graph_destroy(pdeopt_ctx* ctx) {
 int rk4_phase_plan(pdeopt_ctx* ctx, int* fields, int* nphases) {
   const bool fused = ctx->opt_kernel_path != 1 && ctx->prob.derivs == PDEOPT_DERIVS_FD &&
                      (ctx->prob.dtype == PDEOPT_F32 ? fused_supported<float>(ctx) : fused_supported<double>(ctx));
-  if (fused && ctx->halo == 8 && ctx->prob.equation == PDEOPT_EQ_CAHN_HILLIARD) {
+  if (ctx->halo == 8 && ch_quad_chosen(ctx)) {
+    // halo-8 layout, the whole substep in one kernel (stencil_fused_ch4.hpp): its tile + 8 input is the halo
+    *nphases = 1;
+    fields[0] = 0;
+  } else if (fused && ctx->halo == 8 && ctx->prob.equation == PDEOPT_EQ_CAHN_HILLIARD) {
     // halo-8 layout: ONE exchange per substep.  Pair 1+2 runs on the tile + 4 ring (it reads y on tile + 8), so
     // pair 3+4 finds TB on its tile + 4 input region without an exchange of TB.
     *nphases = 2;
@@ -611,11 +618,16 @@ int rk4_phase(pdeopt_ctx* ctx, int phase, double dt, int part) {
   if (phase < 0 || phase >= n) return fail(ctx, PDEOPT_EINVAL, "phase %d outside 0..%d", phase, n - 1);
   ctx->win_lo = 0;
   ctx->win_n = ctx->prob.batch;
-  if (ctx->halo == 8 && n != 2)
-    return fail(ctx, PDEOPT_EINVAL, "the halo-8 layout needs the fused Cahn-Hilliard stage pairs (closure class / tile shape / "
+  if (ctx->halo == 8 && n != 2 && n != 1)
+    return fail(ctx, PDEOPT_EINVAL, "the halo-8 layout needs the fused Cahn-Hilliard kernels (closure class / tile shape / "
                                     "PDEOPT_OPT_FUSE_STAGES rule them out here): use halo layout 4");
   if (ctx->halo == 8 && part != 0)
     return fail(ctx, PDEOPT_EINVAL, "interior / edge launches belong to the halo-4 layout (two exchanges per substep)");
+  if (n == 1) {  // the whole substep in one pass: y (+ halo) -> y'
+    rc = launch_ch_quad(ctx, ctx->Y, ctx->TA, dt);
+    std::swap(ctx->Y, ctx->TA);
+    return rc;
+  }
   if (n == 2) {
     ctx->launch_part = part;
     if (phase == 0) {
@@ -654,7 +666,16 @@ int rk4_loopback_advance(pdeopt_ctx* ctx, double dt, int64_t n) {
     if ((rc = halo_pack(ctx, 0, nullptr))) return rc;
     // the strip written by substep s (fused pack) is read by substep s + 1 (fused unpack): two buffers
     const size_t bytes = halo_strip_elems(ctx) * ctx->esize;
-    if ((rc = ensure_buffer(ctx, &ctx->halo_scratch2, bytes))) return rc;
+    if (ctx->halo_scratch2_bytes < bytes) {  // its own grow-only size: ensure_buffer() keeps any existing pointer
+      if (ctx->halo_scratch2) {
+        PDEOPT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        (void)hipFree(ctx->halo_scratch2);
+        ctx->halo_scratch2 = nullptr;
+        ctx->halo_scratch2_bytes = 0;
+      }
+      if ((rc = ensure_buffer(ctx, &ctx->halo_scratch2, bytes))) return rc;
+      ctx->halo_scratch2_bytes = bytes;
+    }
     void* cur = ctx->halo_scratch;
     void* nxt = ctx->halo_scratch2;
     for (int64_t s = 0; s < n && !rc; ++s) {
@@ -678,6 +699,13 @@ int rk4_substep_h8(pdeopt_ctx* ctx, double dt, void* strip, const void* recv, co
   ctx->pair_recv = recv;
   if (recv)
     for (int q = 0; q < 8; ++q) ctx->pair_nbr[q] = nbr[q];
+  if (ch_quad_chosen(ctx)) {  // one kernel: halo from the gathered strips in, the new strip out
+    ctx->pair_strip = strip;
+    const int rc = rk4_phase(ctx, 0, dt, 0);
+    ctx->pair_recv = nullptr;
+    ctx->pair_strip = nullptr;
+    return rc;
+  }
   int rc = rk4_phase(ctx, 0, dt, 0);
   ctx->pair_recv = nullptr;
   if (rc) return rc;

@@ -53,6 +53,18 @@ struct Quad4Args {
   Geo g;
   const EnvParams<T>* ep;
   ClosureSpec mu, mob;
+  // A rank's tile of a decomposed field (halo-8 layout, HALO kernels; stencil_fused.hpp: PairArgs has the same
+  // fields for the stage pairs).  The tile + 8 input of this kernel IS the layout's halo: one kernel and one exchange
+  // per substep, nothing re-evaluated on a ring outside the tile.
+  //   recv != nullptr: the edge tiles take the halo cells of y straight from the gathered strips (all ranks' strips,
+  //   rank-major, strip_rank elements each; nbr: ranks of {up, down, left, right, UL, UR, DL, DR}) -- no unpack launch;
+  //   nullptr: the halo frame of the field holds them (pdeopt_halo_unpack ran).
+  //   strip != nullptr: the edge tiles also write the cells of y' within 8 of the tile border into this rank's strip
+  //   (halo.hip's layout) -- no pack launch.
+  const T* recv;
+  T* strip;
+  int64_t strip_env, strip_rank;
+  int nbr[8];
 };
 
 #ifndef PDEOPT_CH4_THREADS
@@ -81,7 +93,7 @@ struct Ch4GeomT {
 };
 using Ch4Geom = Ch4GeomT<32>;
 
-template <int CL, typename G>
+template <int CL, typename G, bool HALO = false>
 __global__ __launch_bounds__(G::NT, G::kWavesPerSimd) void ch_rk4_quad_kernel(const Quad4Args<float> a, const int tiles_i, const int tiles_j,
                                                                     const int nblk, const int xcd_remap) {
   using T = float;
@@ -114,9 +126,64 @@ __global__ __launch_bounds__(G::NT, G::kWavesPerSimd) void ch_rk4_quad_kernel(co
   const bool owner = tid < G::NOWN;  // wave-uniform
 
   // ---- y on tile + 8 -> A, one tile row per wave and trip (stencil_generic.hpp: load_rows_per_wave)
-  auto wrap_row = [&](int gi) { return tile_wrap(gi, g.nx, false); };
-  auto wrap_col = [&](int gj) { return tile_wrap(gj, g.ny, false); };
-  load_rows_per_wave<T, V, PV, NT, G::kRowsA, Vec>(A0 - 8 * P, P, in, ld, i0 - 8, j0 - HV * V, wrap_row, wrap_col, tid);
+  bool edge_tile = false;  // wave-uniform
+  if constexpr (HALO) edge_tile = ti == 0 || ti == tiles_i - 1 || tj == 0 || tj == tiles_j - 1;
+  if (HALO && edge_tile && a.recv != nullptr) {
+    // Fused unpack (stage_pair_kernel does the same for its tile + 4 launch): interior cells from the field, the cells
+    // of the 8-wide halo from the strip piece of the neighbour they belong to (halo.hip: my halo piece q <- piece
+    // FROM[q] of neighbour q).  A vector never straddles two sources (every boundary is a multiple of V).  Per thread:
+    // one source pointer + pitch for each row class, chosen by its column class; per trip the wave-uniform row picks.
+    constexpr int NW = NT / 64, H = 8;
+    static_assert(HV * V == H, "the tile + 8 input is the layout's halo");
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    if (lane < PV) {
+      const int nx = g.nx, ny = g.ny;
+      const StripOffsets<H> so(nx, ny);
+      const T* const rb = a.recv + (int64_t)b * a.strip_env;
+      const int64_t S = a.strip_rank;
+      const int gj = j0 - H + lane * V;
+      const T *pT, *pM, *pB;
+      int64_t qT, qM, qB;  // pitches
+      if (gj >= 0 && gj < ny) {
+        pT = rb + a.nbr[0] * S + so.bottom + gj; qT = ny;  // up's bottom rows
+        pM = in + gj; qM = ld;
+        pB = rb + a.nbr[1] * S + so.top + gj; qB = ny;     // down's top rows
+      } else if (gj < 0) {
+        const int c = gj + H;
+        pT = rb + a.nbr[4] * S + so.br + c; pM = rb + a.nbr[2] * S + so.right + c; pB = rb + a.nbr[6] * S + so.tr + c;
+        qT = qM = qB = H;
+      } else {
+        const int c = gj - ny;
+        pT = rb + a.nbr[5] * S + so.bl + c; pM = rb + a.nbr[3] * S + so.left + c; pB = rb + a.nbr[7] * S + so.tl + c;
+        qT = qM = qB = H;
+      }
+      T* const lds = A0 - 8 * P + lane * V;
+      constexpr int kRows = G::kRowsA, kTrips = (kRows + NW - 1) / NW;
+      Vec f[kTrips];
+#pragma unroll
+      for (int k = 0; k < kTrips; ++k) {
+        int row = wave + k * NW;
+        if constexpr (kRows % NW != 0) row = row < kRows ? row : kRows - 1;
+        const int gi = i0 - H + row;  // wave-uniform
+        const T* src;
+        if (gi < 0) src = pT + (int64_t)(gi + H) * qT;
+        else if (gi < nx) src = pM + (int64_t)gi * qM;
+        else src = pB + (int64_t)(gi - nx) * qB;
+        f[k] = *reinterpret_cast<const Vec*>(src);
+      }
+#pragma unroll
+      for (int k = 0; k < kTrips; ++k) {
+        const int row = wave + k * NW;
+        if (kRows % NW == 0 || k + 1 < kTrips || row < kRows) *reinterpret_cast<Vec*>(lds + row * P) = f[k];
+      }
+    }
+  } else {
+    // periodic field: wrap by index; a rank's padded tile: the neighbours are in memory (halo frame)
+    auto wrap_row = [&](int gi) { return HALO ? gi : tile_wrap(gi, g.nx, false); };
+    auto wrap_col = [&](int gj) { return HALO ? gj : tile_wrap(gj, g.ny, false); };
+    load_rows_per_wave<T, V, PV, NT, G::kRowsA, Vec>(A0 - 8 * P, P, in, ld, i0 - 8, j0 - HV * V, wrap_row, wrap_col, tid);
+  }
   __syncthreads();
 
   constexpr bool FOLD_MU = PDEOPT_PAIR_FOLD_MU && CL == CL_LOGIT1;
@@ -302,7 +369,29 @@ __global__ __launch_bounds__(G::NT, G::kWavesPerSimd) void ch_rk4_quad_kernel(co
 #endif
     const int64_t pidx0 = base + (int64_t)(i0 + r0) * ld + (j0 + lx * V);
 #pragma unroll
-    for (int r = 0; r < RPT; ++r) *reinterpret_cast<Vec*>(a.out + pidx0 + r * ld) = acc[r] + a.h6 * k4[r];
+    for (int r = 0; r < RPT; ++r) {
+      const Vec ynew = acc[r] + a.h6 * k4[r];
+      *reinterpret_cast<Vec*>(a.out + pidx0 + r * ld) = ynew;
+      if constexpr (HALO) {
+        // fused pack (stage_pair_kernel's PAIR_34 epilogue): wave-uniform test first, interior tiles skip everything
+        if (a.strip != nullptr && edge_tile) {
+          constexpr int H = 8;
+          const StripOffsets<H> so(g.nx, g.ny);
+          T* const st = a.strip + (int64_t)b * a.strip_env;
+          const int gi = i0 + r0 + r, gj = j0 + lx * V;
+          const bool top = gi < H, bot = gi >= g.nx - H, lef = gj < H, rig = gj >= g.ny - H;
+          const int bi = gi - (g.nx - H), rj = gj - (g.ny - H);
+          if (top) *reinterpret_cast<Vec*>(st + so.top + (int64_t)gi * g.ny + gj) = ynew;
+          if (bot) *reinterpret_cast<Vec*>(st + so.bottom + (int64_t)bi * g.ny + gj) = ynew;
+          if (lef) *reinterpret_cast<Vec*>(st + so.left + (int64_t)gi * H + gj) = ynew;
+          if (rig) *reinterpret_cast<Vec*>(st + so.right + (int64_t)gi * H + rj) = ynew;
+          if (top && lef) *reinterpret_cast<Vec*>(st + so.tl + gi * H + gj) = ynew;
+          if (top && rig) *reinterpret_cast<Vec*>(st + so.tr + gi * H + rj) = ynew;
+          if (bot && lef) *reinterpret_cast<Vec*>(st + so.bl + bi * H + gj) = ynew;
+          if (bot && rig) *reinterpret_cast<Vec*>(st + so.br + bi * H + rj) = ynew;
+        }
+      }
+    }
   }
 }
 
@@ -315,7 +404,8 @@ __global__ __launch_bounds__(G::NT, G::kWavesPerSimd) void ch_rk4_quad_kernel(co
 inline int ch_quad_tile(const pdeopt_ctx* ctx) {
   const pdeopt_problem& p = ctx->prob;
   if (p.equation != PDEOPT_EQ_CAHN_HILLIARD || p.dtype != PDEOPT_F32 || p.derivs != PDEOPT_DERIVS_FD) return 0;
-  if (ctx->halo || ctx->opt_kernel_path == 1 || ctx->opt_debug_ablate) return 0;
+  // periodic fields, and a rank's tile of a decomposed field in the halo-8 layout (its 8-cell halo is this kernel's tile + 8 input)
+  if ((ctx->halo != 0 && ctx->halo != 8) || ctx->opt_kernel_path == 1 || ctx->opt_debug_ablate) return 0;
   if (ctx->opt_tile_rows == 16) return 0;  // a caller asking for 16-row tiles gets the pair kernels
   if (!tiled_supported<float>(ctx)) return 0;
   if (classify_closures(p.mu, p.mob) == CL_GENERIC) return 0;
@@ -329,6 +419,10 @@ inline int ch_quad_tile(const pdeopt_ctx* ctx) {
 // whether the single-pass Cahn-Hilliard RK4 kernel covers the configured problem (the default where it applies;
 // PDEOPT_OPT_FUSE_STAGES = 1 keeps the stage pairs)
 inline bool ch_quad_supported(const pdeopt_ctx* ctx) { return ch_quad_tile(ctx) != 0; }
+// ... and does an RK4 substep of the configured problem run on it?
+inline bool ch_quad_chosen(const pdeopt_ctx* ctx) {
+  return (ctx->opt_fuse_stages == 0 || ctx->opt_fuse_stages == PDEOPT_CH_QUAD_FUSE) && ch_quad_supported(ctx);
+}
 
 template <typename G>
 int launch_ch_quad_g(pdeopt_ctx* ctx, const void* y, void* out, double dt) {
@@ -365,6 +459,19 @@ int launch_ch_quad_g(pdeopt_ctx* ctx, const void* y, void* out, double dt) {
     ctx->last_kernel = std::string(name) + (G::TX == 64 ? ",rows64>" : ",rows32>");
     return PDEOPT_OK;
   };
+  if (ctx->halo == 8) {
+    // decomposed field: halo cells from the gathered strips / the new strip out of the store epilogue (rk4_substep_h8)
+    if (ctx->pair_recv) {
+      s.recv = static_cast<const float*>(ctx->pair_recv);
+      for (int q = 0; q < 8; ++q) s.nbr[q] = ctx->pair_nbr[q];
+    }
+    s.strip = static_cast<float*>(ctx->pair_strip);
+    s.strip_env = 2LL * 8 * p.ny + 2LL * p.nx * 8 + 4LL * 64;
+    s.strip_rank = s.strip_env * p.batch;
+    if (cl == CL_LOGIT && p.mu.n <= 2) return go(ch_rk4_quad_kernel<CL_LOGIT1, G, true>, "rk4_quad<f32,CH,halo8,logit");
+    if (cl == CL_LOGIT) return go(ch_rk4_quad_kernel<CL_LOGIT, G, true>, "rk4_quad<f32,CH,halo8,logit");
+    return go(ch_rk4_quad_kernel<CL_POLY, G, true>, "rk4_quad<f32,CH,halo8,poly");
+  }
   if (cl == CL_LOGIT && p.mu.n <= 2) return go(ch_rk4_quad_kernel<CL_LOGIT1, G>, "rk4_quad<f32,CH,logit");
   if (cl == CL_LOGIT) return go(ch_rk4_quad_kernel<CL_LOGIT, G>, "rk4_quad<f32,CH,logit");
   return go(ch_rk4_quad_kernel<CL_POLY, G>, "rk4_quad<f32,CH,poly");

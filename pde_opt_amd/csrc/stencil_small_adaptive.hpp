@@ -226,6 +226,11 @@ __global__ __launch_bounds__(NTMAX) void small_tsit5_kernel(const SmallTsit5Args
         else y[j] = y1;
         k[0][j] = *reinterpret_cast<const Vec*>(sNext + tile.oc[j]);  // FSAL
       }
+      // A thread without a k-th vector of its own redoes the LAST vector (SmallTile::init) and, from two vectors per
+      // thread on, sits in another wave than that vector's owner: the next iteration's first store into sNext (the
+      // stage-2 input, into the slot k7 was just read from) must not overtake the owner's read.  `keep` is the same
+      // in every thread, so the barrier is uniform.  (One vector per thread: the duplicates share the owner's wave.)
+      if constexpr (KMAX >= 2) __syncthreads();
       t = t_new < a.t1 - 1e-14 * fmax(1.0, fabs(a.t1)) ? t_new : a.t1;
       prev_prev_inv = prev_inv;
       prev_inv = inv;

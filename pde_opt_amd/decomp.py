@@ -11,10 +11,13 @@ Every rank owns an (nx/px) x (ny/py) tile stored with a halo.  Per RK4 substep::
             backend.unpack(field, recv, grid.neighbours())     # 8 halo pieces from 8 neighbours
         backend.phase(phase, dt)                               # fused stencil + RK update kernel
 
-Two layouts.  **Halo 8** (default where the fused Cahn-Hilliard stage pairs run): ONE exchange per substep -- the
-first stage pair is evaluated on the tile + 4 ring (it reads the state on tile + 8), so the second pair finds its
-input there, and in the library's own loops the second pair's edge tiles write the new state's strip themselves (no
-pack launch): a substep is unpack + 2 stencil kernels + 1 collective.  **Halo 4**: one exchange per phase (2 per
+Two layouts.  **Halo 8** (default where the fused Cahn-Hilliard kernels run): ONE exchange per substep.  fp32 tiles that
+32 x 128 (or 64 x 64) cells divide run the WHOLE substep in one kernel (``csrc/stencil_fused_ch4.hpp``: its tile + 8
+input is exactly the 8-cell halo; plan ``[0]``): in the library's own loops the edge workgroups read the halo straight
+from the gathered strips and write the new state's strip themselves -- a substep is 1 stencil kernel + 1 collective.
+Otherwise (fp64, other tile shapes, ``PDEOPT_OPT_FUSE_STAGES = 1``; plan ``[0, -1]``) the first stage pair is evaluated on
+the tile + 4 ring (it reads the state on tile + 8), so the second pair finds its input there: 2 stencil kernels + 1
+collective.  **Halo 4**: one exchange per phase (2 per
 substep with fused pairs, 4 with per-stage kernels), the layout of the interior / edge overlap and graph drivers.
 
 The exchange is ONE all-gather of packed strips per phase (edges and corners together), the pattern
@@ -309,10 +312,11 @@ class HipTileBackend:
             self.engine.configure(dtype=dtype, batch=1, **prob)
             self.engine.set_halo_layout(0)  # the option only applies to the configure above
             self.halo = h
-            if h != 8 or self.engine.rk4_phase_plan() == [0, -1]:
+            # [0]: the whole substep in one kernel (fp32, tiles of 32 x 128 / 64 x 64 cells); [0, -1]: two stage pairs
+            if h != 8 or self.engine.rk4_phase_plan() in ([0], [0, -1]):
                 break
             if halo == 8:
-                raise ValueError("halo=8 needs the fused Cahn-Hilliard stage pairs (closure class, tile shape and "
+                raise ValueError("halo=8 needs the fused Cahn-Hilliard kernels (closure class, tile shape and "
                                  "PDEOPT_OPT_FUSE_STAGES decide); this problem runs one kernel per stage: use halo=4")
         self.strip_elems = self.engine.halo_strip_elems()
 

@@ -22,21 +22,24 @@ def _monolithic(eq, y0, dt, n, fuse):
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
-@pytest.mark.parametrize("fuse,halo", [(0, 8), (0, 4), (-1, 4)])
+@pytest.mark.parametrize("fuse,halo", [(0, 8), (1, 8), (0, 4), (-1, 4)])
 def test_single_rank_loopback_equals_periodic(dtype, fuse, halo):
     rng = np.random.default_rng(0)
     dom = std_domain(P, 64, 128)
     eq = P.CahnHilliard2DPeriodic(dom, 0.002, MU["regsol"], MOB["c1mc"])
     y0 = np.clip(0.5 + 0.05 * rng.standard_normal((64, 128)), 0.05, 0.95).astype(dtype)
     want, kern = _monolithic(eq, y0, 2e-7, 6, fuse)
-    assert ("pair" in kern or "rk4_quad" in kern) == (fuse == 0)  # fp32: the monolithic run is the whole-substep kernel
+    assert ("pair" in kern or "rk4_quad" in kern) == (fuse >= 0)  # fp32, fuse 0: the monolithic run is the whole-substep kernel
     backend = HipTileBackend(eq, (64, 128), dtype, halo=halo)
     backend.engine.set_fuse_stages(fuse)
     s = DecomposedSolver(eq, CartesianGrid(1, 1, 0), dtype=dtype, backend=backend)
     plan = backend.phase_plan()
-    assert plan == ([0, -1] if halo == 8 else ([0, 2] if fuse == 0 else [0, 1, 2, 1]))
+    # halo 8: the whole-substep kernel where it applies (fp32, not asked for the pairs), else the two stage pairs
+    quad = halo == 8 and fuse == 0 and dtype is np.float32
+    assert plan == ([0] if quad else [0, -1] if halo == 8 else ([0, 2] if fuse == 0 else [0, 1, 2, 1]))
     s.set_global_state(y0)
     s.advance(2e-7, 6)
+    assert ("rk4_quad<f32,CH,halo8" in backend.engine.last_kernel) == quad, backend.engine.last_kernel
     np.testing.assert_array_equal(s.local_state(), want)
     assert s.exchanges == 6 * sum(1 for f in plan if f >= 0)
 
@@ -57,7 +60,7 @@ def test_halo_layout_selection():
 
 
 @pytest.mark.parametrize("grid", [(2, 2), (2, 1), (1, 4)])
-@pytest.mark.parametrize("fuse,halo", [(0, 8), (0, 4), (-1, 4)])
+@pytest.mark.parametrize("fuse,halo", [(0, 8), (1, 8), (0, 4), (-1, 4)])
 def test_multi_tile_on_one_gpu_equals_monolithic(grid, fuse, halo):
     """px x py ranks played by px*py engines on one GPU; strips cross between engines through the
     same pack / unpack kernels and neighbour tables the RCCL path uses."""
@@ -165,8 +168,9 @@ def test_interior_plus_edge_launches_equal_one_launch(dtype, shape):
     np.testing.assert_array_equal(outs[0], want)
 
 
-@pytest.mark.parametrize("grid,tile,halo,fuse", [((2, 2), (64, 128), 8, 0), ((2, 2), (64, 128), 4, 0), ((2, 2), (64, 128), 4, -1),
-                                                 ((1, 2), (96, 256), 8, 0), ((4, 1), (32, 128), 8, 0), ((2, 3), (64, 128), 8, 0)])
+@pytest.mark.parametrize("grid,tile,halo,fuse", [((2, 2), (64, 128), 8, 0), ((2, 2), (64, 128), 8, 1), ((2, 2), (64, 128), 4, 0),
+                                                 ((2, 2), (64, 128), 4, -1), ((1, 2), (96, 256), 8, 0), ((4, 1), (32, 128), 8, 0),
+                                                 ((2, 3), (64, 128), 8, 0), ((2, 2), (64, 64), 8, 0), ((1, 2), (96, 256), 8, 1)])
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 def test_in_library_loop_with_virtual_ranks_equals_monolithic(grid, tile, halo, fuse, dtype):
     """pdeopt_rk4_decomposed_advance -- the substep loop in C with its neighbour table and rank offsets into the
@@ -198,6 +202,9 @@ def test_in_library_loop_with_virtual_ranks_equals_monolithic(grid, tile, halo, 
     got = np.empty_like(want)
     for s in solvers:
         assert s.mode == "local-group"
+        # halo 8, fp32, tiles of 32 x 128 or 64 x 64 cells: ONE kernel per substep (fused unpack in, fused pack out)
+        quad = halo == 8 and fuse == 0 and dtype is np.float32
+        assert ("rk4_quad<f32,CH,halo8" in s.backend.engine.last_kernel) == quad, s.backend.engine.last_kernel
         si, sj = s.grid.tile_slices(nx, ny)
         got[si, sj] = s.local_state()
     np.testing.assert_array_equal(got, want)
@@ -219,6 +226,48 @@ def test_local_group_misuse_is_an_error_not_a_hang():
         DecomposedSolver(eq, CartesianGrid(1, 1, 0), comm=comms[1], dtype=np.float32)
     s0.backend.engine.close()
     comms[0].group.close()
+
+
+def test_config5_full_size_virtual_ranks_vs_c_oracle():
+    """BASELINE config 5 at its real size: the 4096^2 field on 2 x 2 ranks of 2048^2 -- virtual ranks of this process
+    on one GPU running the library's decomposed loop (one whole-substep kernel + one exchange per substep) -- ALL FOUR
+    tiles against oracle/c_oracle.c on the whole periodic field (cahn_hilliard.py:89-109), and bitwise against the
+    monolithic GPU solve"""
+    from oracle import c_oracle as CO
+
+    n, nsub, dt = 4096, 7, 2e-7
+    rng = np.random.default_rng(0)
+    dom = std_domain(P, n, n)
+    eq = P.CahnHilliard2DPeriodic(dom, 0.002, MU["regsol"], MOB["c1mc"])
+    y0 = np.clip(0.5 + 0.01 * rng.standard_normal((n, n)), 0.05, 0.95).astype(np.float32)
+    comms = LocalGroupComm.create(4)
+    solvers = []
+    for r in range(4):
+        s = DecomposedSolver(eq, CartesianGrid(2, 2, r), comm=comms[r], dtype=np.float32)
+        s.set_global_state(y0)
+        solvers.append(s)
+    advance_group(solvers, dt, 4)
+    advance_group(solvers, dt, nsub - 4)
+    got = np.empty_like(y0)
+    for s in solvers:
+        assert "rk4_quad<f32,CH,halo8" in s.backend.engine.last_kernel, s.backend.engine.last_kernel
+        si, sj = s.grid.tile_slices(n, n)
+        got[si, sj] = s.local_state()
+        s.backend.engine.close()
+    comms[0].group.close()
+    hx, hy = dom.dx
+    regsol = CO.closure(0, 1, (3.0, -6.0))  # polynomial 3 - 6 c + the logit flag
+    c1mc = CO.closure(0, 0, (0.0, 1.0, -1.0))
+    ref = CO.rk4(0, y0, hx, hy, 0.002, regsol, c1mc, dt, nsub)
+    inc, inc_ref = got.astype(np.float64) - y0, ref.astype(np.float64) - y0
+    for r in range(4):  # every rank's tile on its own
+        si, sj = CartesianGrid(2, 2, r).tile_slices(n, n)
+        assert np.max(np.abs(got[si, sj] - ref[si, sj])) < 5e-7, (r, float(np.max(np.abs(got[si, sj] - ref[si, sj]))))
+        e = np.linalg.norm(inc[si, sj] - inc_ref[si, sj]) / np.linalg.norm(inc_ref[si, sj])
+        assert e < 5e-5, (r, e)
+    want, kern = _monolithic(eq, y0, dt, nsub, 0)
+    assert "rk4_quad" in kern
+    np.testing.assert_array_equal(got, want)
 
 
 def test_config5_tile_size_smoke():
