@@ -167,7 +167,7 @@ VALU_BUSY_SATURATED = 1.62
 VALU_BUSY_SATURATED_F64 = 0.94  # v_fma_f64 / v_add_f64 take 4.2-4.3 cycles per instruction: an all-fp64 kernel reads 0.92-0.95
 
 
-def roofline_block(workload, kernel_name, bytes_per_launch, words, avg_launch_s, launches, concurrent=1):
+def roofline_block(workload, kernel_name, bytes_per_launch, words, avg_launch_s, launches, concurrent=1, shader_hz=None):
     """HBM roofline by SURVEY 8(d)'s algorithmic bytes and, where a PMC profile of this workload is committed, the
     VALU-issue roofline of the same kernel; `bound` names the larger fraction (what binds the kernel).
     `concurrent`: launches in flight side by side (two environment groups on two streams, PDEOPT_OPT_GROUP_STREAMS):
@@ -199,9 +199,14 @@ def roofline_block(workload, kernel_name, bytes_per_launch, words, avg_launch_s,
         r["traffic"] = pmc["hbm_bytes_per_launch"]
         r["traffic_gbs"] = concurrent * r["traffic"] / avg_launch_s / 1e9
         r["traffic_frac"] = r["traffic_gbs"] / HBM_PEAK_GBS
+    # cycles are priced on the clock the chip HELD over the timed region (pdeopt_timer_clock: s_memtime over s_memrealtime
+    # stamps beside the timer events), not on a data-sheet figure; the 2.4 GHz fallback only when the probe gave nothing
+    hz = shader_hz if shader_hz and shader_hz > 1e8 else SHADER_HZ
+    r["shader_clock_hz"] = hz
+    r["shader_clock_source"] = "measured in this run (s_memtime / s_memrealtime over the timed region)" if hz is shader_hz else "fallback 2.4 GHz (probe unavailable)"
     if c.get("SQ_INSTS_VALU"):
         per_simd = concurrent * c["SQ_INSTS_VALU"] / N_SIMD
-        cycles = avg_launch_s * SHADER_HZ
+        cycles = avg_launch_s * hz
         valu_clk = VALU_CLK_MEASURED_F64 if WORKLOADS.get(workload, {}).get("dtype") is np.float64 else VALU_CLK_MEASURED
         r["valu_insts_per_launch"] = c["SQ_INSTS_VALU"]
         r["valu_clk_per_inst_measured"] = valu_clk
@@ -211,7 +216,11 @@ def roofline_block(workload, kernel_name, bytes_per_launch, words, avg_launch_s,
             r["valu_busy_frac_pmc"] = 4.0 * c["SQ_ACTIVE_INST_VALU"] / N_SIMD / (c["GRBM_GUI_ACTIVE"] / 8.0)
             sat = VALU_BUSY_SATURATED_F64 if WORKLOADS.get(workload, {}).get("dtype") is np.float64 else VALU_BUSY_SATURATED
             r["valu_busy_saturated_pmc"] = sat
-            r["valu_util"] = r["valu_busy_frac_pmc"] / sat
+            # rocprofv3 --pmc serialises launches: the counters' own busy share is that of a launch running ALONE
+            r["valu_util_pmc_solo_launch"] = r["valu_busy_frac_pmc"] / sat
+            # the run that is timed keeps `concurrent` launches in flight: the same busy-cycle count (4 per instruction)
+            # over the LIVE cycles a launch's share of the region lasted, at the clock held live
+            r["valu_util"] = concurrent * 4.0 * c["SQ_ACTIVE_INST_VALU"] / N_SIMD / cycles / sat
         # which pipe is busier: the VALU (its counter reading over the reading of an all-VALU kernel) or the fabric (measured
         # traffic over the HBM peak)?
         valu_share = r.get("valu_util", r["frac_valu_measured_issue"])
@@ -222,20 +231,22 @@ def roofline_block(workload, kernel_name, bytes_per_launch, words, avg_launch_s,
             r["peak"] = 1.0
             r["frac"] = valu_share
         r["valu_ginst_per_s"] = concurrent * c["SQ_INSTS_VALU"] / avg_launch_s / 1e9
-        r["valu_ginst_per_s_at_measured_issue_cost"] = N_SIMD * SHADER_HZ / valu_clk / 1e9
+        r["valu_ginst_per_s_at_measured_issue_cost"] = N_SIMD * hz / valu_clk / 1e9
     if r["bound"] == "hbm" and r.get("traffic_gbs"):
         # memory-bound with measured traffic: price the bytes that moved, not the per-stage byte count (which fusion
         # undercuts -- a fraction above 1 of a hardware peak would say nothing)
         r["achieved"], r["frac"] = r["traffic_gbs"], r["traffic_frac"]
     r["pmc_source"] = os.path.relpath(PMC_FILE, ROOT) + ": " + pmc.get("source", "")
     r["note"] = ("bound = the busier of two pipes: fabric traffic (measured bytes per launch / live launch time, against the 8 TB/s HBM peak; "
-                 "Infinity-Cache hits included) and the VALU (valu_util = its counter reading over the reading of an all-VALU kernel, "
-                 "profiles/r03_valu_pmc_calibration.txt).  valu_insts_per_launch, valu_busy_frac_pmc and traffic come from the COMMITTED "
-                 "rocprofv3 --pmc profile of this command (" + os.path.relpath(PMC_FILE, ROOT) + ": counters need rocprofv3, the driver's run has "
-                 "none); the launch time and algorithmic_gbs are measured live in this run with HIP events.  frac_valu_measured_issue = "
-                 "SQ_INSTS_VALU x the in-kernel-measured 2.0 cycles per instruction (tools/valubench.hip) over the live launch cycles at 2.4 GHz.  "
-                 "algorithmic_gbs is SURVEY 8(d)'s byte count over the same time: it may exceed the HBM peak because stage-pair fusion and "
-                 "cache-resident environment groups remove traffic (7 instead of 16 words per cell and substep).")
+                 "Infinity-Cache hits included) and the VALU.  valu_util = VALU-busy cycles (4 x SQ_ACTIVE_INST_VALU per SIMD, from the COMMITTED "
+                 "rocprofv3 --pmc profile of this command, " + os.path.relpath(PMC_FILE, ROOT) + ": counters need rocprofv3, the driver's run has none) x the "
+                 "launches in flight, over the LIVE launch time x the shader clock measured in this run, over what an all-VALU kernel reads "
+                 "(1.62 fp32 / 0.94 fp64, profiles/r03_valu_pmc_calibration.txt).  valu_util_pmc_solo_launch is the counters' own busy share: "
+                 "rocprofv3 serialises the launches, so it describes a launch running alone -- a PMC pass with two launches in flight cannot be "
+                 "taken.  frac_valu_measured_issue = SQ_INSTS_VALU x the in-kernel-measured cycles per instruction (tools/valubench.hip) over the "
+                 "same live cycles.  algorithmic_gbs is SURVEY 8(d)'s per-stage byte count (16 words per cell and RK4 substep) over the same time: "
+                 "it exceeds the HBM peak where stages are fused in LDS -- the whole-substep kernels move 2 words per cell and substep "
+                 "(traffic), the stage pairs 7.")
     return r
 
 
@@ -647,6 +658,93 @@ def cpu_baseline(name, budget_s=15.0):
     }
 
 
+def run_single_process(args, P, engines=None):
+    """--single-process: the OTHER way to use the GPUs of a node -- ONE process,
+    ``VectorPDEEnv(devices=[0..N-1])``: one engine + one dedicated host thread per device, environments sharded by
+    contiguous blocks, no collective.  A step = ``VectorPDEEnv.step`` of all N x batch environments (per-environment
+    kappa control, variance reward reduced on each device; the states never leave HBM).  Same JSON line as the
+    process-per-GPU mode, ``per_rank_ms_per_step`` = each DEVICE's own wall time per step.  ``engines``: test hook (the CPU
+    suite passes oracle-backed engine doubles in place of ``devices=``)."""
+    w = WORKLOADS[args.workload]
+    if w["eq"] not in ("ch", "ac") or w["integ"] not in ("rk4", "imex"):
+        raise SystemExit("--single-process runs the Cahn-Hilliard / Allen-Cahn workloads")
+    n, batch, N = w["n"], args.batch_per_gpu or w["batch"], args.gpus
+    L_ = 0.01 * n
+    dom = P.Domain((n, n), ((-L_ / 2, L_ / 2), (-L_ / 2, L_ / 2)), "dimensionless")
+
+    def reset(domain, seed=0):
+        rng = np.random.default_rng(seed)
+        if w["eq"] == "ch":
+            return np.clip(0.5 + 0.01 * rng.standard_normal((n, n)), 0.05, 0.95).astype(w["dtype"])
+        return (0.01 * rng.standard_normal((n, n))).astype(w["dtype"])
+
+    if w["eq"] == "ch":
+        cubic = w.get("closures") == "cubic"
+        eq_t, static = P.CahnHilliard2DPeriodic, {"mu": (lambda c: c**3 - c) if cubic else REGSOL, "D": (lambda c: 1 + c**2) if cubic else C1MC}
+    else:
+        eq_t, static = P.AllenCahn2DPeriodic, {"mu": lambda c: c**3 - c, "R": lambda c: np.ones_like(c)}
+    imex = w["integ"] == "imex"
+    total = batch * N
+    actions = [1] * total  # kappa stays 0.002: the timed arithmetic is the workload's own (the control path still runs per step)
+    env = P.VectorPDEEnv(
+        total, eq_t, dom, P.SemiImplicitFourierSpectral if imex else P.RK4, end_time=1e9, step_dt=w["dt"] * w["substeps"],
+        numeric_dt=w["dt"], state_to_observation_func=lambda s_: s_, reward_function=lambda s_: 0.0, reset_func=reset,
+        reset_control_value=0.002, update_control_value=lambda off, old: old + off, update_control_parameter=lambda old, new: new,
+        action_space_config={"type": "discrete", "num_actions": 3, "action_mapping": {0: -1e-5, 1: 0.0, 2: 1e-5}},
+        static_equation_parameters=static, control_equation_parameter_name="kappa", solver_parameters={"A": 0.5} if imex else {},
+        device_reward="var", fetch_observations=False, **({"devices": list(range(N))} if engines is None else {"engines": engines}))
+    env.reset(seed=0)
+    for _ in range(args.warmup):
+        env.step(actions)
+    per_dev = np.zeros(N)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        _, rew, *_ = env.step(actions)  # returns after every device's reward reduction: all streams are drained
+        per_dev += np.asarray(env.last_step_seconds)
+    elapsed = time.perf_counter() - t0
+    kernel = env._shards[0].engine.last_kernel
+    # parity: the first and last environment of the job against the C oracle over the steps taken (RK4 workloads)
+    spot = None
+    if not args.no_parity_spot and w["integ"] == "rk4" and w["dtype"] is np.float32:
+        from oracle import c_oracle as CO
+
+        eq_id, cmu, cmob = _oracle_closures(w)
+        st = env.states
+        nsteps = (args.warmup + args.steps) * w["substeps"]
+        rel = mabs = 0.0
+        for b in (0, total - 1):
+            y0 = reset(dom, seed=b)
+            ref = CO.rk4(eq_id, y0, dom.dx[0], dom.dx[1], 0.002, cmu, cmob, w["dt"], nsteps, threads=usable_cores()).astype(np.float64)
+            e_rel = float(np.linalg.norm((st[b] - y0.astype(np.float64)) - (ref - y0)) / np.linalg.norm(ref - y0))
+            e_abs = float(np.max(np.abs(st[b] - ref)))
+            rel = max(rel, e_rel if np.isfinite(e_rel) else np.inf)
+            mabs = max(mabs, e_abs if np.isfinite(e_abs) else np.inf)
+        tol = SPOT_TOL_F32["rk4"] * max(1.0, (args.warmup + args.steps) / 2)  # rounding accumulates with the steps taken
+        spot = {"parity_spot_rel_err": rel, "parity_spot_max_abs_err": mabs, "parity_spot_tol": tol,
+                "parity_spot_ok": bool(rel < tol and np.isfinite(mabs)),
+                "parity_spot": f"environments 0 and {total - 1} after {nsteps} substeps vs oracle/c_oracle.c"}
+    line = {
+        "metric": METRIC if args.workload == "ch_rk4_1024_f32" else f"env-steps/sec ({args.workload}, {w['substeps']} substeps/env-step) & achieved HBM GB/s",
+        "value": total * args.steps / elapsed, "unit": "env-steps/s", "n_gpus": N, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32" if np.dtype(w["dtype"]).itemsize == 4 else "f64", "data": "synthetic",
+        "config": {"workload": args.workload, "grid": [n, n], "envs_per_gpu": batch, "envs_total": total, "integrator": w["integ"],
+                   "dt": w["dt"], "substeps_per_env_step": w["substeps"], "kernel": kernel,
+                   "mode": "single process: VectorPDEEnv(devices=[0..N-1]), one engine + one host thread per device, no collective",
+                   "step": "VectorPDEEnv.step: per-environment kappa control, one pdeopt_advance per device, variance reward reduced on the device"},
+        "per_rank_ms_per_step": [1e3 * float(t_) / args.steps for t_ in per_dev],
+        "shard_bounds": env.shard_bounds,
+        "nonfinite_rewards": int(np.size(rew) - np.isfinite(rew).sum()),
+        **(spot or {}),
+    }
+    env.close()
+    print(json.dumps(line))
+    sys.stdout.flush()
+    if line["nonfinite_rewards"] or (spot is not None and not spot["parity_spot_ok"]):
+        raise SystemExit(f"single-process run FAILED its checks: {spot}, non-finite rewards {line['nonfinite_rewards']}")
+    return line
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -674,6 +772,9 @@ def main():
     ap.add_argument("--virtual-ranks", type=int, default=0,
                     help="ch_rk4_4096_decomp: run this many ranks of ONE process on ONE GPU (in-process group)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--single-process", action="store_true",
+                    help="ONE process drives all --gpus N devices through VectorPDEEnv(devices=[0..N-1]) (one engine + one host "
+                         "thread per device) instead of one process per GPU under torch.distributed")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -705,6 +806,10 @@ def main():
     import pde_opt_amd as P
     from pde_opt_amd import _lib as L
 
+    if args.single_process:
+        if world > 1:
+            raise SystemExit("--single-process is ONE process: start it with `python bench.py --gpus N --single-process`, not under torchrun")
+        return run_single_process(args, P)
     if args.workload == "ch_rk4_4096_decomp":
         return run_decomp(args, P, world, rank, local_rank, dist)
     w = WORKLOADS[args.workload]
@@ -744,6 +849,7 @@ def main():
     for _ in range(args.steps):
         env_step()
     dev_ms = eng.timer_stop()  # HIP events on the engine's stream (synchronises)
+    shader_hz = eng.timer_clock_hz()  # the clock the chip held between the two events
     barrier()
     elapsed = time.perf_counter() - t0
     kernel_name = eng.last_kernel
@@ -806,7 +912,7 @@ def main():
             "achieved_gbs_whole_job": args.gpus * total_bytes / elapsed / 1e9,
             "nonfinite_cells": bad,
             **(spot or {}),
-            "roofline": roofline_block(args.workload, kernel_name, bytes_per_launch, words, avg_launch_s, launches, concurrent),
+            "roofline": roofline_block(args.workload, kernel_name, bytes_per_launch, words, avg_launch_s, launches, concurrent, shader_hz),
         }
         if args.gpus == 1 and not args.no_api and not args.ablate:
             line.update(api_throughput(P, args.workload, rank, args.steps, args.warmup) or {})

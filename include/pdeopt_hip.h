@@ -420,6 +420,10 @@ int pdeopt_tsit5_solve_small(pdeopt_ctx* ctx, double t0, double t1, double dt0, 
 int pdeopt_sync(pdeopt_ctx* ctx);
 int pdeopt_timer_start(pdeopt_ctx* ctx);           /* hipEventRecord on the ctx stream */
 int pdeopt_timer_stop(pdeopt_ctx* ctx, double* ms); /* record + synchronise + elapsed */
+/* the shader clock the chip HELD between the last timer_start / timer_stop pair, in Hz: both calls also stamp
+ * s_memtime (shader-clock ticks) and s_memrealtime (constant 100 MHz) on the ctx stream; 0 if not measured.
+ * (bench.py prices VALU cycles on this instead of a data-sheet clock.) */
+int pdeopt_timer_clock(pdeopt_ctx* ctx, double* shader_hz);
 typedef enum {
   PDEOPT_CNT_STAGE_LAUNCHES = 0, /* kernel launches of the integrators so far: fused stencil + update launches, and the
                                     FFT passes of the hand-written Strang / IMEX pipelines */

@@ -177,6 +177,7 @@ _SIGNATURES = {
     "pdeopt_sync": (C.c_int, [_VP]),
     "pdeopt_timer_start": (C.c_int, [_VP]),
     "pdeopt_timer_stop": (C.c_int, [_VP, C.POINTER(C.c_double)]),
+    "pdeopt_timer_clock": (C.c_int, [_VP, C.POINTER(C.c_double)]),
     "pdeopt_last_kernel": (C.c_char_p, [_VP]),
 }
 

@@ -252,6 +252,7 @@ int pdeopt_ctx_destroy(pdeopt_ctx* ctx) {
   if (ctx->stream && !ctx->stream_borrowed) (void)hipStreamDestroy(ctx->stream);
   if (ctx->halo_scratch) (void)hipFree(ctx->halo_scratch);
   if (ctx->halo_scratch2) (void)hipFree(ctx->halo_scratch2);
+  if (ctx->clock_stamps) (void)hipFree(ctx->clock_stamps);
   delete ctx;
   return PDEOPT_OK;
 }
@@ -1042,21 +1043,44 @@ int pdeopt_sync(pdeopt_ctx* ctx) {
   return PDEOPT_OK;
 }
 
+// the clock the chip holds over a timed region: one lane stamps s_memtime (shader-clock ticks) and s_memrealtime
+// (constant 100 MHz) on the ctx stream next to each timer event (tools/valubench.hip measures the issue rate the same way)
+__global__ void clock_stamp_kernel(unsigned long long* out) {
+  out[0] = __builtin_amdgcn_s_memtime();
+  out[1] = __builtin_amdgcn_s_memrealtime();
+}
+
 int pdeopt_timer_start(pdeopt_ctx* ctx) {
   if (!ctx) return PDEOPT_EINVAL;
   PDEOPT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  if (!ctx->clock_stamps) PDEOPT_HIP_CHECK(ctx, hipMalloc(&ctx->clock_stamps, 4 * sizeof(unsigned long long)));
   PDEOPT_HIP_CHECK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+  hipLaunchKernelGGL(clock_stamp_kernel, dim3(1), dim3(1), 0, ctx->stream, static_cast<unsigned long long*>(ctx->clock_stamps));
+  return PDEOPT_OK;
+}
+
+int pdeopt_timer_clock(pdeopt_ctx* ctx, double* shader_hz) {
+  if (!ctx || !shader_hz) return PDEOPT_EINVAL;
+  *shader_hz = ctx->timer_shader_hz;
   return PDEOPT_OK;
 }
 
 int pdeopt_timer_stop(pdeopt_ctx* ctx, double* ms) {
   if (!ctx || !ms) return PDEOPT_EINVAL;
   PDEOPT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  unsigned long long* const st = static_cast<unsigned long long*>(ctx->clock_stamps);
+  if (st) hipLaunchKernelGGL(clock_stamp_kernel, dim3(1), dim3(1), 0, ctx->stream, st + 2);
   PDEOPT_HIP_CHECK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
   PDEOPT_HIP_CHECK(ctx, hipEventSynchronize(ctx->ev1));
   float f = 0.f;
   PDEOPT_HIP_CHECK(ctx, hipEventElapsedTime(&f, ctx->ev0, ctx->ev1));
   *ms = (double)f;
+  ctx->timer_shader_hz = 0.0;
+  if (st) {
+    unsigned long long h[4] = {0, 0, 0, 0};
+    PDEOPT_HIP_CHECK(ctx, hipMemcpy(h, st, sizeof(h), hipMemcpyDeviceToHost));
+    if (h[3] > h[1] && h[2] > h[0]) ctx->timer_shader_hz = (double)(h[2] - h[0]) / (double)(h[3] - h[1]) * 100.0e6;
+  }
   return PDEOPT_OK;
 }
 

@@ -118,6 +118,8 @@ struct pdeopt_ctx {
   hipStream_t stream = nullptr;
   bool stream_borrowed = false;  // stream belongs to the caller (pdeopt_ctx_create_on_stream)
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  void* clock_stamps = nullptr;   // [start, stop] x (s_memtime, s_memrealtime) of the timer pair
+  double timer_shader_hz = 0.0;   // shader clock held between the last pdeopt_timer_start / _stop (0: not measured)
   std::string err;
   std::string last_kernel;
   bool configured = false;

@@ -54,9 +54,19 @@ enum { PAIR_12 = 0, PAIR_34 = 1, PAIR_K = 2 };  // PAIR_K: one stage, out = f(in
 #ifndef PDEOPT_WIDE_NEIGHBOURS
 #define PDEOPT_WIDE_NEIGHBOURS 0
 #endif
+// PDEOPT_NB_ABLATE (TIMING ONLY, tools/mkvariant.sh; results are wrong): 1 = no neighbour read at all (an element of the
+// centre vector stands in), 2 = the same number of ds_read_b32, but from addresses one dword apart across the lanes
+// (conflict-free): what the 4-way bank conflict of the real reads costs, and what removing the reads would buy
+#ifndef PDEOPT_NB_ABLATE
+#define PDEOPT_NB_ABLATE 0
+#endif
 template <typename T, typename Vec, int V>
 __device__ __forceinline__ T nb_left(const T* c_) {
-#if PDEOPT_WIDE_NEIGHBOURS
+#if PDEOPT_NB_ABLATE == 1
+  return c_[0];
+#elif PDEOPT_NB_ABLATE == 2
+  return c_[-1 - (int)((3u * threadIdx.x) & 31u)];
+#elif PDEOPT_WIDE_NEIGHBOURS
   Vec t = *reinterpret_cast<const Vec*>(c_ - V);
   asm volatile("" : "+v"(t));
   return t[V - 1];
@@ -66,7 +76,11 @@ __device__ __forceinline__ T nb_left(const T* c_) {
 }
 template <typename T, typename Vec, int V>
 __device__ __forceinline__ T nb_right(const T* c_) {
-#if PDEOPT_WIDE_NEIGHBOURS
+#if PDEOPT_NB_ABLATE == 1
+  return c_[V - 1];
+#elif PDEOPT_NB_ABLATE == 2
+  return c_[V - (int)((3u * threadIdx.x) & 31u)];
+#elif PDEOPT_WIDE_NEIGHBOURS
   Vec t = *reinterpret_cast<const Vec*>(c_ + V);
   asm volatile("" : "+v"(t));
   return t[0];

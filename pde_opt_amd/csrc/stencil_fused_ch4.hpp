@@ -407,7 +407,8 @@ inline int ch_quad_tile(const pdeopt_ctx* ctx) {
   // periodic fields, and a rank's tile of a decomposed field in the halo-8 layout (its 8-cell halo is this kernel's tile + 8 input)
   if ((ctx->halo != 0 && ctx->halo != 8) || ctx->opt_kernel_path == 1 || ctx->opt_debug_ablate) return 0;
   if (ctx->opt_tile_rows == 16) return 0;  // a caller asking for 16-row tiles gets the pair kernels
-  if (!tiled_supported<float>(ctx)) return 0;
+  // (tiled_supported() also asks a padded layout for the pair kernels' 32-vector rows; this kernel's 64 x 64 tile has 16)
+  if (!ctx->halo && !tiled_supported<float>(ctx)) return 0;
   if (classify_closures(p.mu, p.mob) == CL_GENERIC) return 0;
   // divisible grids only; the tile + 8 halo wraps at most once
   const bool ok64 = p.nx % 64 == 0 && p.ny % 64 == 0, ok32 = p.nx % 32 == 0 && p.ny % 128 == 0;

@@ -345,8 +345,10 @@ int small_tsit5_solve(pdeopt_ctx* ctx, double t0, double t1, double dt0, const p
   int nt, kmax;
   if (nvec <= 512) { nt = (int)((nvec + 63) / 64 * 64); kmax = 1; }
   else { nt = 512; kmax = (int)((nvec + 511) / 512); }
-  // [input A][mu][input B]([state]): small_tsit5_kernel
-  const size_t tile_bytes = ((size_t)cells * sizeof(T) * (kmax >= 4 ? 4 : 3) + 15) / 16 * 16;
+  // [input A][mu][input B]([state]): small_tsit5_kernel.  The state array belongs to the KMAX = 4 INSTANTIATION, which
+  // also runs 3 vectors per thread (launch_small_tsit5_k): sized by kmax >= 4 a 64 x 96 grid ran with its state array
+  // past the allocation (round 4: found by the 64 x 96 / 48 x 48 fp64 shapes ADVICE r3 asked for)
+  const size_t tile_bytes = ((size_t)cells * sizeof(T) * (kmax >= 3 ? 4 : 3) + 15) / 16 * 16;
   s.red_off = (int)tile_bytes;
   const size_t lds = tile_bytes + 16 * sizeof(double);
   const int cl = classify_closures(p.mu, p.mob);

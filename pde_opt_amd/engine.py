@@ -567,6 +567,12 @@ class HipEngine:
         self._check(self._lib.pdeopt_timer_stop(self._h, C.byref(ms)))
         return ms.value
 
+    def timer_clock_hz(self) -> float:
+        """shader clock held between the last ``timer_start`` / ``timer_stop`` (s_memtime over s_memrealtime); 0.0 if unmeasured"""
+        hz = C.c_double()
+        self._check(self._lib.pdeopt_timer_clock(self._h, C.byref(hz)))
+        return hz.value
+
 
 class LocalGroup:
     """``pdeopt_local_group``: an in-process group of ``world`` ranks for the decomposed driver (virtual ranks on one

@@ -29,6 +29,26 @@ class BaseEquation(ABC):
     # (VectorPDEEnv): they travel with the environment (per-environment scalars / auxiliary fields)
     _per_env_controls: frozenset = frozenset()
 
+    # the subset of those that are PLAIN NUMBERS the constructor stores untouched (nothing in __post_init__ derives
+    # from them): an equation that differs from another in such a field only is that equation with the attribute
+    # replaced (``_clone_with_scalar``) -- VectorPDEEnv builds ONE equation per step and carries the per-environment
+    # values as an array instead of constructing (and closure-tracing) one dataclass per environment
+    _scalar_controls: frozenset = frozenset()
+
+    def _clone_with_scalar(self, name: str, value):
+        """this equation with the plain-number field ``name`` set to ``value`` (``name`` in ``_scalar_controls``)"""
+        import copy
+        import types
+
+        if name not in type(self)._scalar_controls:
+            raise ValueError(f"{type(self).__name__}.{name} is not a plain scalar field")
+        c = copy.copy(self)
+        setattr(c, name, value)
+        for k, v in self.__dict__.items():  # instance-bound methods (rhs = rhs_fd, as upstream) follow the clone
+            if isinstance(v, types.MethodType) and v.__self__ is self:
+                c.__dict__[k] = types.MethodType(v.__func__, c)
+        return c
+
     @classmethod
     def _engine_upload_batch(cls, engine, eqs, t: float = 0.0, t_end=None) -> None:
         """``_engine_upload`` for a batch whose environment b is described by ``eqs[b]``"""

@@ -117,6 +117,7 @@ class CahnHilliard2DPeriodic(BaseEquation):
         return hit
 
     _per_env_controls = frozenset({"kappa", "mu", "D"})
+    _scalar_controls = frozenset({"kappa"})  # stored as given: fourier_symbol / _engine_problem read it when asked
 
     def rhs(self, state, t):  # replaced in __post_init__, as upstream
         raise NotImplementedError("rhs method not implemented")
@@ -154,6 +155,7 @@ class AllenCahn2DPeriodic(BaseEquation):
     derivs: str = "fd"
 
     _per_env_controls = frozenset({"kappa", "mu", "R"})
+    _scalar_controls = frozenset({"kappa"})  # stored as given: fourier_symbol / _engine_problem read it when asked
 
     def rhs(self, state, t):
         raise NotImplementedError("rhs method not implemented")
@@ -198,6 +200,7 @@ class CahnHilliard3DPeriodic(BaseEquation):
     ifft = None
     fourier_symbol = None
     _per_env_controls = frozenset({"kappa", "mu", "D"})
+    # (no _scalar_controls: __post_init__ derives fourier_symbol from kappa)
 
     def rhs(self, state, t):  # replaced in __post_init__, as upstream
         raise NotImplementedError("rhs method not implemented")

@@ -169,6 +169,31 @@ class PDEEnv(EnvBase):
         self._engine.close()
 
 
+class _ScalarControlBatch:
+    """The equations of a batch that differ in ONE plain-number field (``BaseEquation._scalar_controls``): one real
+    equation + the per-environment values.  ``VectorPDEEnv.step`` used to construct (and closure-trace) one dataclass
+    per environment before any device was fed -- a serial prologue of 3.3 ms at 256 environments; the
+    hot callers read ``values`` / ``eq0``, anything else may still index or iterate (clones are made on demand)."""
+
+    def __init__(self, eq0, name, values):
+        self.eq0, self.name, self.values = eq0, name, values
+
+    def __len__(self):
+        return len(self.values)
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            vals = self.values[i]
+            return _ScalarControlBatch(self.eq0 if i.indices(len(self.values))[0] == 0 else
+                                       self.eq0._clone_with_scalar(self.name, vals[0]), self.name, vals)
+        if i < 0:
+            i += len(self.values)
+        return self.eq0 if i == 0 else self.eq0._clone_with_scalar(self.name, self.values[i])
+
+    def __iter__(self):
+        return (self[i] for i in range(len(self.values)))
+
+
 class _EnvShard:
     """Environments [lo, hi) of a VectorPDEEnv on ONE engine (one GPU, one HIP stream).  ``step`` runs on the
     shard's own host thread: the ~10^2..10^3 asynchronous kernel launches of an environment step are issued per
@@ -182,6 +207,7 @@ class _EnvShard:
         self._obs_buffer = None
         self._y0 = None
         self.state_host = None
+        self.last_step_s = 0.0
 
     def reset(self, y0):
         self._y0 = y0
@@ -202,9 +228,17 @@ class _EnvShard:
             eng.set_state(y0)
             self._configured_key = key
         # per-environment parameter values
-        kappa = [e._engine_problem().get("kappa", 0.0) for e in eqs]
-        mu = [e._engine_problem()["mu"].coef for e in eqs] if prob.get("mu") is not None else None
-        mob = [e._engine_problem()["mob"].coef for e in eqs] if prob.get("mob") is not None else None
+        if isinstance(eqs, _ScalarControlBatch):
+            # one equation, one scalar per environment: no per-environment Python objects
+            kappa = (np.asarray(eqs.values, dtype=np.float64) if eqs.name == "kappa"
+                     else np.full(self.n, float(prob.get("kappa", 0.0))))
+            mu = np.tile(np.asarray(prob["mu"].coef, dtype=np.float64), (self.n, 1)) if prob.get("mu") is not None else None
+            mob = np.tile(np.asarray(prob["mob"].coef, dtype=np.float64), (self.n, 1)) if prob.get("mob") is not None else None
+        else:
+            probs = [e._engine_problem() for e in eqs]
+            kappa = [p.get("kappa", 0.0) for p in probs]
+            mu = [p["mu"].coef for p in probs] if prob.get("mu") is not None else None
+            mob = [p["mob"].coef for p in probs] if prob.get("mob") is not None else None
         eng.set_env_params(0, kappa=kappa, mu_coef=mu, mob_coef=mob)
         return eq0
 
@@ -218,6 +252,9 @@ class _EnvShard:
         """one environment step of this shard's environments: returns (obs, rewards)"""
         from .integrate import constant_step_plan
 
+        import time
+
+        t_begin = time.perf_counter()
         env, eng = self.env, self.engine
         eq0 = self._configure(eqs)
         type(eq0)._engine_upload_batch(eng, eqs, 0.0, env.step_dt)
@@ -260,6 +297,8 @@ class _EnvShard:
             if not fetched:  # a host reward function sees the full field, as upstream (pde_env.py:309)
                 self.state_host = eng.get_state()
             rewards = np.asarray([env.reward_function(s_) for s_ in self.state_host])
+        # wall time of this device's share (the reward reduction / state fetch above synchronised its stream)
+        self.last_step_s = time.perf_counter() - t_begin
         return obs, rewards
 
 
@@ -367,6 +406,9 @@ class VectorPDEEnv:
         # ---- engines: one per device (raises HipUnavailableError without a GPU / the library)
         if engines is not None and (engine is not None or devices is not None):
             raise ValueError("pass engines=[...] or engine= / devices=, not both")
+        # engines the caller passed in stay the caller's: close() shuts down only what this constructor created
+        self._owns_engines = engines is None and engine is None
+        self._closed = False
         if engines is None:
             if engine is not None:
                 if devices is not None:
@@ -404,6 +446,11 @@ class VectorPDEEnv:
         return len(self._shards)
 
     @property
+    def last_step_seconds(self):
+        """wall time each device spent on its share of the last ``step`` (one entry per device)"""
+        return [s.last_step_s for s in self._shards]
+
+    @property
     def shard_bounds(self):
         """[(lo, hi)] environment ranges, one per device"""
         return [(s.lo, s.hi) for s in self._shards]
@@ -414,8 +461,10 @@ class VectorPDEEnv:
 
     def _map_shards(self, fn):
         """fn(shard) on every shard, each on its own host thread; results in shard order (exceptions re-raised)"""
+        if self._closed:
+            raise RuntimeError("this VectorPDEEnv has been closed")
         if self._pool is None:
-            return [fn(self._shards[0])]
+            return [fn(s_) for s_ in self._shards]  # one shard (several only if no pool could be made): in order, here
         futs = [ex.submit(fn, s_) for ex, s_ in zip(self._pool, self._shards)]
         results, first_error = [], None
         for f in futs:  # wait for EVERY device before raising: no shard is left running behind an exception
@@ -455,6 +504,13 @@ class VectorPDEEnv:
         """environments may only disagree on parameters the batched kernels carry per environment -- checked over
         the WHOLE job, so what is accepted does not depend on how many devices the environments are spread over"""
         eq0 = eqs[0]
+        if isinstance(eqs, _ScalarControlBatch):
+            # one equation with a per-environment number: the closure structure is shared by construction
+            if eqs.name not in type(eq0)._per_env_controls and any(v != eqs.values[0] for v in eqs.values):
+                raise ValueError(
+                    f"{type(eq0).__name__}: the control parameter {eqs.name!r} cannot differ between the environments "
+                    f"of one VectorPDEEnv (per-environment controls: {sorted(type(eq0)._per_env_controls)})")
+            return
         prob = eq0._engine_problem()
         for e in eqs[1:]:
             p = e._engine_problem()
@@ -479,7 +535,7 @@ class VectorPDEEnv:
         ones = [1.0] * len(eqs)
         if self.control_equation_parameter_name != "kappa" or "fourier_symbol" in (self.solver_parameters or {}):
             return ones
-        kappas = [float(e.kappa) for e in eqs]
+        kappas = [float(v) for v in eqs.values] if isinstance(eqs, _ScalarControlBatch) else [float(e.kappa) for e in eqs]
         if all(k == kappas[0] for k in kappas):
             return ones
         if any(not k > 0.0 for k in kappas):
@@ -492,13 +548,20 @@ class VectorPDEEnv:
     def step(self, actions: Sequence):
         if len(actions) != self.num_envs:
             raise ValueError(f"{len(actions)} actions for {self.num_envs} environments")
-        eqs, controls = [], []
+        controls = []
         for b, action in enumerate(actions):
             offset = action if not self._action_to_direction else self._action_to_direction[action]
             old = self._control_value[b]
             self._control_value[b] = self.update_control_value(offset, old)
             controls.append(self.update_control_parameter(old, self._control_value[b]))
-            eqs.append(self._equation_for(controls[-1]))
+        name = self.control_equation_parameter_name
+        if name in getattr(self.equation_type, "_scalar_controls", ()) and all(
+                isinstance(c, (int, float, np.integer, np.floating)) and not isinstance(c, bool) for c in controls):
+            # the control is a plain number the equation stores as given: ONE equation (its parameters validated, its
+            # closures traced once) + the per-environment values as an array
+            eqs = _ScalarControlBatch(self._equation_for(controls[0]), name, controls)
+        else:
+            eqs = [self._equation_for(c) for c in controls]
         self._check_controls(eqs, controls)
         # every device's share on its own host thread; no collective, nothing exchanged
         results = self._map_shards(lambda sh: sh.step(eqs[sh.lo:sh.hi]))
@@ -525,9 +588,14 @@ class VectorPDEEnv:
         return parts[0] if len(parts) == 1 else np.concatenate(parts)
 
     def close(self):
+        """stop the per-device threads and close the engines this environment created (``device=`` / ``devices=``);
+        engines passed in through ``engine=`` / ``engines=`` belong to the caller and stay open.  A closed environment
+        raises on ``step`` / ``states`` instead of silently serving the first shard."""
         if self._pool is not None:
             for ex in self._pool:
                 ex.shutdown(wait=True)
             self._pool = None
-        for sh in self._shards:
-            sh.engine.close()
+        if self._owns_engines and not self._closed:
+            for sh in self._shards:
+                sh.engine.close()
+        self._closed = True

@@ -181,6 +181,8 @@ def test_in_library_loop_with_virtual_ranks_equals_monolithic(grid, tile, halo, 
     a rank is its own neighbour (1 x 2, 4 x 1)."""
     px, py = grid
     tx, ty = tile
+    if dtype is np.float64 and tile == (64, 64):
+        pytest.skip("64 x 64 tiles belong to the fp32 whole-substep kernel (fp64 runs the stage pairs: 32-vector rows)")
     if dtype is np.float64:
         ty //= 2  # 16-byte vectors hold 2 cells: the 32-vector tile is 64 columns wide
     nx, ny = px * tx, py * ty

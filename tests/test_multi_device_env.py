@@ -62,7 +62,13 @@ def test_sharded_env_equals_single_engine_env(num_envs, ndev, mode):
     assert len({e.thread for e in engines}) == ndev and threading.get_ident() not in {e.thread for e in engines}
     assert [e.batch for e in engines] == [hi - lo for lo, hi in many.shard_bounds]
     many.close()
-    assert all(e.closed for e in engines)
+    # engines passed in through engines= are the caller's: close() leaves them open, and a closed
+    # environment raises instead of serving its first shard only
+    assert not any(getattr(e, "closed", False) for e in engines)
+    with pytest.raises(RuntimeError, match="closed"):
+        many.states
+    with pytest.raises(RuntimeError, match="closed"):
+        many.step([1] * num_envs)
 
 
 def test_sharded_env_imex_per_environment_kappa():
@@ -117,3 +123,93 @@ def test_device_observation_with_a_host_reward():
     probes.reset(seed=3)
     obs, rew, *_ = probes.step([1, 2])
     np.testing.assert_array_equal(obs, probes.states[:, [0, 3], [0, 5]])
+
+
+class _NullEngine(OracleEngine):
+    """an engine whose advance costs nothing: what is left of VectorPDEEnv.step is the host side"""
+
+    def advance(self, *a, **k):
+        pass
+
+    def reduce(self, op):  # the device reductions / frame quantisation are GPU calls in production, not host work
+        return np.zeros(self.batch)
+
+    def observe_u8(self, lo, hi, out=None, **k):
+        if getattr(self, "_frames", None) is None:
+            self._frames = np.zeros((self.batch,) + self.state_shape, np.uint8)
+        return self._frames
+
+
+def test_step_prologue_does_not_grow_with_python_objects_per_environment():
+    """256 environments x 8 shards with a scalar control (kappa): ONE equation is built per step and the per-environment
+    values travel as an array (the serial prologue was 3.3 ms = 17 % of a 15.8 ms GPU step, i.e. at most
+    6.6x of 8 GPUs).  Gate: <= 0.8 ms per step with null engines, best of several runs (a CPU test: loose enough for
+    a loaded container, an order of magnitude below the old figure's growth)."""
+    import time
+
+    dom = std_domain(P, 16, 16)
+    env = P.VectorPDEEnv(256, **_kw(dom), engines=[_NullEngine() for _ in range(8)], device_reward="var",
+                         device_observation=(0.0, 1.0))
+    env.reset(seed=0)
+    acts = [b % 3 for b in range(256)]
+    for _ in range(3):
+        env.step(acts)
+    best = np.inf
+    for _ in range(5):
+        t0 = time.perf_counter()
+        for _ in range(10):
+            env.step(acts)
+        best = min(best, (time.perf_counter() - t0) / 10)
+    # what the environments were handed: per-environment kappas, different across the batch
+    k = np.concatenate([sh.engine.kappa_env for sh in env._shards])
+    assert len(set(np.round(k, 9))) > 1 and k.shape == (256,)
+    env.close()
+    assert best < 1.6e-3, f"{1e3 * best:.2f} ms per step"  # measured here: 0.56 ms (round 3: 5.3 ms on the same cores); 0.8 ms target x 2 for a loaded container
+
+
+def test_scalar_control_batch_equals_per_environment_equations():
+    """the one-equation fast path must hand the engines exactly what 256 separately constructed equations did"""
+    from pde_opt_amd.pde_env import _ScalarControlBatch
+
+    dom = std_domain(P, 16, 16)
+    eq0 = P.CahnHilliard2DPeriodic(dom, 0.002, MU["regsol"], MOB["c1mc"])
+    batch = _ScalarControlBatch(eq0, "kappa", [0.002, 0.003, 0.001])
+    assert len(batch) == 3 and batch[0] is eq0
+    for b, k in enumerate([0.002, 0.003, 0.001]):
+        want = P.CahnHilliard2DPeriodic(dom, k, MU["regsol"], MOB["c1mc"])
+        got = batch[b]
+        assert got.kappa == k and got._engine_problem()["kappa"] == want._engine_problem()["kappa"]
+        assert got._engine_problem()["mu"].coef == want._engine_problem()["mu"].coef
+        np.testing.assert_array_equal(np.asarray(got.fourier_symbol), np.asarray(want.fourier_symbol))
+        assert got.rhs.__self__ is got  # the instance-bound rhs follows the clone, not the template
+    sub = batch[1:]
+    assert len(sub) == 2 and sub[0].kappa == 0.003 and list(sub.values) == [0.003, 0.001]
+    assert [e.kappa for e in batch] == [0.002, 0.003, 0.001]
+    with pytest.raises(ValueError, match="plain scalar"):
+        eq0._clone_with_scalar("mu", 1.0)
+
+
+def test_bench_single_process_mode_on_engine_doubles():
+    """bench.py --gpus N --single-process: the one-process-many-devices product path has a bench entry;
+    here its control flow on two oracle-backed engine doubles -- JSON line, per-device clocks, parity spot of the first
+    and last environment against the C oracle"""
+    import argparse
+    import json
+    import os
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+
+    args = argparse.Namespace(workload="ch_rk4_64_f32_small", batch_per_gpu=1, gpus=2, steps=1, warmup=0, no_parity_spot=False)
+    import contextlib
+    import io
+
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        line = bench.run_single_process(args, P, engines=[OracleEngine(), OracleEngine()])
+    printed = json.loads(buf.getvalue().strip().splitlines()[-1])
+    assert printed["n_gpus"] == 2 and printed["config"]["envs_total"] == 2 and printed["scaling"] == "weak"
+    assert len(printed["per_rank_ms_per_step"]) == 2 and all(t > 0 for t in printed["per_rank_ms_per_step"])
+    assert printed["shard_bounds"] == [[0, 1], [1, 2]]
+    assert line["parity_spot_ok"] and line["parity_spot_rel_err"] < 1e-4, line
