@@ -177,7 +177,8 @@ typedef enum {
                                  workgroup per environment, the state in registers (the sizes of the reference's own
                                  tests and notebooks, where a launch per stage pair is latency-bound): 0 = auto (grids
                                  up to 4096 cells, larger ones from 192 environments on), 1 = wherever it can run,
-                                 -1 = never */
+                                 -1 = never; 2 = as 1, and the adaptive solve prefers the multi-workgroup kernel
+                                 (stencil_coop_adaptive.hpp) also where the single-workgroup one would run */
   PDEOPT_OPT_GROUP_STREAMS = 9,/* explicit integrators running the batch in cache-resident groups: 0 = auto (two groups
                                   side by side on two HIP streams, each half the size, so that one group's launch
                                   fills the other's ramp and tail), 1 = one group at a time, 2 = force two */
@@ -263,6 +264,14 @@ int pdeopt_set_time_terms(pdeopt_ctx* ctx, pdeopt_time_fn fn, void* user, const 
  * advance of n substeps makes no host callback at all (one per stage otherwise: 400 Python calls per 100 RK4
  * substeps); other times still go to fn / constant.  n = 0 clears it; pdeopt_set_time_terms clears it too. */
 int pdeopt_set_time_table(pdeopt_ctx* ctx, int n, const double* times, const double* terms);
+/* The same two callables as POLYNOMIALS in t -- theta(t) = sum theta[i] t^i, flux(t) likewise, at most cubic -- for the
+ * code that chooses its own evaluation times on the device: the in-kernel adaptive solve (pdeopt_tsit5_solve_small)
+ * forms cos(theta(t)), cos(pi - theta(t)), flux(t) at every stage time itself.  Call it AFTER pdeopt_set_time_terms
+ * (which withdraws earlier polynomials); the callback / constants still serve every other path, so they must describe
+ * the same functions.  n_theta = 0 withdraws the polynomials (a callback without them keeps the adaptive solve on the
+ * host-driven path).  Reference: theta / flux fields of cahn_hilliard.py:232-235, allen_cahn.py:119-120;
+ * notebooks/smooth_boundary.ipynb:262 (a quadratic theta(t)). */
+int pdeopt_set_time_terms_poly(pdeopt_ctx* ctx, int n_theta, const double* theta, int n_flux, const double* flux);
 /* integrator parameters: IMEX A (solvers.py:43); Strang time_scale re/im and dx (solvers.py:86-89) */
 int pdeopt_set_integrator_params(pdeopt_ctx* ctx, double imex_A, double time_scale_re,
                                  double time_scale_im, double strang_dx);

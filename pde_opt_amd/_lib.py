@@ -139,6 +139,7 @@ _SIGNATURES = {
     "pdeopt_set_integrator_params": (C.c_int, [_VP, C.c_double, C.c_double, C.c_double, C.c_double]),
     "pdeopt_set_time_terms": (C.c_int, [_VP, TIME_FN, _VP, C.POINTER(C.c_double)]),
     "pdeopt_set_time_table": (C.c_int, [_VP, C.c_int, _VP, _VP]),
+    "pdeopt_set_time_terms_poly": (C.c_int, [_VP, C.c_int, _VP, C.c_int, _VP]),
     "pdeopt_snapshot": (C.c_int, [_VP]),
     "pdeopt_get_interpolated": (C.c_int, [_VP, C.c_double, C.c_int, C.c_int, _VP]),
     "pdeopt_reduce": (C.c_int, [_VP, C.c_int, _VP]),

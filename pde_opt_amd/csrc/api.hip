@@ -301,7 +301,7 @@ int pdeopt_set_option(pdeopt_ctx* ctx, int option, int64_t value) {
       ctx->opt_group_streams = value;
       return PDEOPT_OK;
     case PDEOPT_OPT_SMALL_PERSIST:
-      if (value < -1 || value > 1) return fail(ctx, PDEOPT_EINVAL, "small-persist option must be -1, 0 or 1");
+      if (value < -1 || value > 2) return fail(ctx, PDEOPT_EINVAL, "small-persist option must be -1, 0, 1 or 2");
       ctx->opt_small_persist = value;
       return PDEOPT_OK;
     default:
@@ -585,7 +585,20 @@ int pdeopt_set_time_terms(pdeopt_ctx* ctx, pdeopt_time_fn fn, void* user, const 
   for (int i = 0; i < 3; ++i) ctx->time_const[i] = constant ? constant[i] : 0.0;
   ctx->tt_times.clear();  // a table belongs to the source it was sampled from
   ctx->tt_terms.clear();
+  ctx->time_poly_valid = false;  // ... and so do polynomials: the caller states them again (pdeopt_set_time_terms_poly)
   ctx->tsit5_fsal_valid = false;
+  return PDEOPT_OK;
+}
+
+int pdeopt_set_time_terms_poly(pdeopt_ctx* ctx, int n_theta, const double* theta, int n_flux, const double* flux) {
+  if (!ctx) return PDEOPT_EINVAL;
+  if (n_theta < 0 || n_theta > 4 || n_flux < 0 || n_flux > 4 || (n_theta > 0 && !theta) || (n_flux > 0 && !flux))
+    return fail(ctx, PDEOPT_EINVAL, "pdeopt_set_time_terms_poly: 0..4 coefficients each (cubic polynomials in t)");
+  ctx->time_poly_valid = n_theta > 0;  // n_theta == 0 withdraws the polynomials
+  for (int i = 0; i < 4; ++i) {
+    ctx->time_theta[i] = i < n_theta ? theta[i] : 0.0;
+    ctx->time_flux[i] = i < n_flux ? flux[i] : 0.0;
+  }
   return PDEOPT_OK;
 }
 

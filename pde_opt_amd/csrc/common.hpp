@@ -148,6 +148,10 @@ struct pdeopt_ctx {
   pdeopt_time_fn time_fn = nullptr;
   void* time_user = nullptr;
   double time_const[3] = {0.0, 0.0, 0.0};
+  // pdeopt_set_time_terms_poly: theta(t), flux(t) of the smoothed-boundary forms as cubic polynomials in t -- what the
+  // in-kernel adaptive solve (stencil_coop_adaptive.hpp) evaluates at its own stage times
+  bool time_poly_valid = false;
+  double time_theta[4] = {0.0, 0.0, 0.0, 0.0}, time_flux[4] = {0.0, 0.0, 0.0, 0.0};
   // pdeopt_set_time_table: the three scalars at a list of evaluation times, looked up before the callback is asked
   std::vector<double> tt_times, tt_terms;
   size_t tt_cursor = 0;

@@ -17,6 +17,7 @@
 #include "stencil_fused_launch.hpp"
 #include "stencil_small.hpp"
 #include "stencil_small_adaptive.hpp"
+#include "stencil_coop_adaptive.hpp"
 #include "stencil_sbm_tiled.hpp"
 
 namespace pdeopt {
@@ -923,14 +924,26 @@ int tsit5_commit(pdeopt_ctx* ctx, int accept) {
   return PDEOPT_OK;
 }
 
-bool tsit5_solve_small_supported(const pdeopt_ctx* ctx) {
+// the in-kernel adaptive solve: one workgroup per environment (LDS-resident periodic Cahn-Hilliard / Allen-Cahn grids,
+// stencil_small_adaptive.hpp) or several cooperating workgroups per environment (larger grids, the smoothed-boundary
+// forms, advection-diffusion: stencil_coop_adaptive.hpp)
+static bool tsit5_single_wg(const pdeopt_ctx* ctx) {
   return ctx->prob.dtype == PDEOPT_F32 ? small_tsit5_supported<float>(ctx) : small_tsit5_supported<double>(ctx);
 }
+static bool tsit5_coop(const pdeopt_ctx* ctx) {
+  return ctx->prob.dtype == PDEOPT_F32 ? coop_tsit5_supported<float>(ctx) : coop_tsit5_supported<double>(ctx);
+}
+bool tsit5_solve_small_supported(const pdeopt_ctx* ctx) { return tsit5_single_wg(ctx) || tsit5_coop(ctx); }
 
 int tsit5_solve_small(pdeopt_ctx* ctx, double t0, double t1, double dt0, const pdeopt_pid* pid, int64_t max_steps, int n_save,
                       const double* save_ts, void* save_host, pdeopt_tsit5_stats* stats) {
-  if (!tsit5_solve_small_supported(ctx))
-    return fail(ctx, PDEOPT_EINVAL, "the in-kernel adaptive solve takes LDS-resident Cahn-Hilliard / Allen-Cahn FD problems only");
+  const bool single = tsit5_single_wg(ctx), coop = tsit5_coop(ctx);
+  if (!single && !coop)
+    return fail(ctx, PDEOPT_EINVAL, "the in-kernel adaptive solve takes periodic / smoothed-boundary Cahn-Hilliard and Allen-Cahn FD problems and "
+                                    "advection-diffusion with a steady velocity, on grids its tiles cover (pdeopt_tsit5_solve_small_supported)");
+  if (coop && (!single || ctx->opt_small_persist == 2))
+    return ctx->prob.dtype == PDEOPT_F32 ? coop_tsit5_solve<float>(ctx, t0, t1, dt0, pid, max_steps, n_save, save_ts, save_host, stats)
+                                         : coop_tsit5_solve<double>(ctx, t0, t1, dt0, pid, max_steps, n_save, save_ts, save_host, stats);
   return ctx->prob.dtype == PDEOPT_F32 ? small_tsit5_solve<float>(ctx, t0, t1, dt0, pid, max_steps, n_save, save_ts, save_host, stats)
                                        : small_tsit5_solve<double>(ctx, t0, t1, dt0, pid, max_steps, n_save, save_ts, save_host, stats);
 }

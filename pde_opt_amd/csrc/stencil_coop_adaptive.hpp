@@ -1,0 +1,709 @@
+// Adaptive Tsit5 + PID controller inside ONE launch for grids beyond one compute unit: SEVERAL workgroups (= compute
+// units) per environment, one exchange + one environment-wide barrier per trial step (round 4; SURVEY section 8 row f1,
+// f3, a15).
+//
+// What the reference runs through diffrax.diffeqsolve(..., Tsit5(), PIDController(rtol, atol)) and where:
+//   notebooks/smooth_boundary.ipynb:228,397   CahnHilliard2DSmoothedBoundary 100^2, 117 890 and 352 104 steps
+//                                             (equation: cahn_hilliard.py:204-289, shapes.py:67-77)
+//   notebooks/run_advection_diffusion.ipynb:84 advection-diffusion 64^2, 8 950 steps
+//   tests/test_solvers.py:81,263              Allen-Cahn / Cahn-Hilliard 256 x 1, 32^2 ... (the single-workgroup
+//                                             kernel of stencil_small_adaptive.hpp takes those)
+// Host-driven (pdeopt_tsit5_trial / commit) a trial step is 8 launches + a reduction + a device->host read: 66-88 us
+// whatever the grid.  The single-workgroup kernel stops at 2048 vectors (one CU's registers), and one CU's VALU needs
+// ~30 us for the seven smoothed-boundary right-hand sides of a 100^2 grid anyway.
+//
+// Here an environment is cut into px x py sub-tiles, one workgroup each, and a trial step needs NO exchange between its
+// seven stages: a workgroup holds its tile + H halo cells (H = 6 x the stencil radius of one right-hand side: 12 for the
+// Cahn-Hilliard forms, 6 for Allen-Cahn / advection-diffusion) and evaluates stage s on the tile + r (7 - s) ring --
+// the communication-avoiding form of the decomposed RK4 driver (comm.hip), here inside one CU's LDS:
+//
+//     k1 (FSAL) on T + 6r                  from the exchange of the previous accepted step
+//     w2 = y + h a21 k1 on T + 6r
+//     k_s = f(w_s) on T + r (7 - s), w_{s+1} = y + h sum_j a_{s+1,j} k_j there        s = 2 .. 6
+//     k7 = f(y1) on T, scaled error norm of the tile; y1 and k7 of the tile -> global exchange buffers (speculative)
+//     -- ONE barrier over the environment's workgroups (partial norms, fixed summation order: every workgroup holds the
+//        same double and runs the same controller arithmetic: stencil_small_adaptive.hpp) --
+//     accept: dense output of the tile at the save times passed; halo ring of y and k1 <- the neighbours' tiles
+//
+// Everything of a step lives in LDS (y, k1..k6, two stage-input buffers, mu / inner, the static fields psi,
+// |grad psi|/psi, mask or the face velocities): 9 - 13 arrays of (tile + 2H)^2; the host picks the tile grid that fits
+// 160 KB.  Redundant halo work (x2 at 25^2 tiles with H = 12) buys the absence of 6 cross-CU barriers per step (~1.5 us
+// each against ~0.5 us of arithmetic per stage and CU).  Cells in overlapping regions are computed by several
+// workgroups from the same inputs with the same code: same bits, so the copies never diverge.
+//
+// Cross-workgroup traffic goes through global memory with agent-scope release / acquire around the barrier (the
+// workgroups of one environment are mapped to ONE XCD -- block index mod 8 -- wherever they fit its 32 compute units, so
+// the data stays in that XCD's L2; small fp64 tiles may need two).
+// Exit conditions every wave reaches: t >= t1, max_steps, a stalled step, and an abort flag that any workgroup raises
+// when it has waited > 2 s at a barrier (a partner that never arrives): no wave can spin forever.
+#pragma once
+
+#include <type_traits>
+
+#include "stencil_small_adaptive.hpp"
+
+namespace pdeopt {
+
+template <typename T>
+struct CoopArgs {
+  T* y;  // [nenv][nx * ny] dense periodic states of this launch's environments (read at the start, written at the end)
+  int nx, ny, px, py, nenv;
+  int64_t bstride;
+  T rhx, rhy, rhx2, rhy2;  // 1 / hx, 1 / hy, 1 / hx^2, 1 / hy^2
+  const EnvParams<T>* ep;
+  ClosureSpec mu, mob, fe;
+  const T* s0;  // static fields [nx][ny]: smoothed boundary: psi, |grad psi| / psi, mask; advection-diffusion: vx, vy faces
+  const T* s1;
+  const T* s2;
+  int64_t sstride;  // elements between environments of the static fields (0: shared)
+  // time-dependent scalars of the smoothed-boundary forms: tmode 0: constants tw[3] = {cos theta on the mask, off it, flux};
+  // 1: theta(t), flux(t) polynomials in t, evaluated at every stage time in the kernel
+  int tmode;
+  double theta[4], flux[4], tw[3];
+  double t0, t1, dt0;
+  PidConsts pid;
+  int64_t max_steps;
+  int n_save;
+  const double* save_ts;
+  T* save_out;  // [n_save][batch][nx * ny], pre-offset to this launch's first environment
+  int64_t save_stride;
+  pdeopt_tsit5_stats* stats;  // [nenv]
+  T* xy[2];                   // exchange buffers [nenv][nx * ny]: candidate state / its slope, double-buffered
+  T* xk[2];
+  double* part;        // [2][nenv][px * py] partial error sums
+  unsigned* bar;       // [nenv][2]: arrivals, generation
+  unsigned* abort_flag;
+  int xs, wpx;         // XCDs an environment's workgroups are spread over (1, 2, 4, 8) and workgroups per XCD
+  int rows, pitch;     // LDS array geometry: (largest tile + 2 H) rows x pitch
+  int red_off;         // byte offset of the reduction / control scratch in LDS
+};
+
+// the fixed closure forms of stencil_sbm_tiled.hpp (FAST) or the run-time walk (closure_generic)
+template <typename T, bool FAST>
+__device__ __forceinline__ T coop_mu(const ClosureSpec& s, const T* __restrict__ cf, T c) {
+  if constexpr (!FAST) return closure_generic<T>(s, cf, c);
+  T r = ((cf[3] * c + cf[2]) * c + cf[1]) * c + cf[0];
+  if (s.flags & PDEOPT_CL_LOGIT_PRIOR) r += t_logit<T>(c);
+  return r;
+}
+template <typename T, bool FAST>
+__device__ __forceinline__ T coop_fe(const ClosureSpec& s, const T* __restrict__ cf, T c) {
+  if constexpr (!FAST) return closure_generic<T>(s, cf, c);
+  T r = ((cf[3] * c + cf[2]) * c + cf[1]) * c + cf[0];
+  if (s.flags & PDEOPT_CL_MIX_ENTROPY) r += c * t_log<T>(c) + (T(1) - c) * t_log<T>(T(1) - c);
+  return r;
+}
+template <typename T, bool FAST>
+__device__ __forceinline__ T coop_mob(const ClosureSpec& s, const T* __restrict__ cf, T c) {
+  if constexpr (!FAST) return closure_generic<T>(s, cf, c);
+  return (cf[2] * c + cf[1]) * c + cf[0];
+}
+inline bool coop_fast_closures(const pdeopt_problem& p, bool with_fe) {
+  const bool mu = p.mu.kind == PDEOPT_CL_POLY && p.mu.n <= 4 && (p.mu.flags & ~PDEOPT_CL_LOGIT_PRIOR) == 0;
+  const bool mob = p.mob.kind == PDEOPT_CL_POLY && p.mob.n <= 3 && p.mob.flags == 0;
+  const bool fe = !with_fe || (p.fe.kind == PDEOPT_CL_POLY && p.fe.n <= 4 && (p.fe.flags & ~PDEOPT_CL_MIX_ENTROPY) == 0);
+  return mu && mob && fe;
+}
+
+__device__ __forceinline__ int wrap1(int i, int n) {  // |offset| <= n: one conditional add / subtract
+  if (i < 0) i += n;
+  if (i >= n) i -= n;
+  return i;
+}
+
+constexpr unsigned long long kCoopTimeoutTicks = 200000000ull;  // 2 s of s_memrealtime (100 MHz)
+
+// Barrier over the nwg workgroups of one environment.  false: the solve was aborted (a partner did not arrive).
+__device__ __forceinline__ bool coop_env_barrier(unsigned* bar, unsigned* abort_flag, int nwg, unsigned* gen) {
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // this workgroup's exchange tile and partial sum: visible device-wide
+    const unsigned g = *gen;
+    if (__hip_atomic_fetch_add(&bar[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(nwg - 1)) {
+      __hip_atomic_store(&bar[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_add(&bar[1], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      const unsigned long long t_in = __builtin_amdgcn_s_memrealtime();
+      while (__hip_atomic_load(&bar[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == g) {
+        if (__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
+        if (__builtin_amdgcn_s_memrealtime() - t_in > kCoopTimeoutTicks) {
+          __hip_atomic_store(abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          break;
+        }
+        __builtin_amdgcn_s_sleep(2);
+      }
+    }
+  }
+  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // every wave: the partners' writes, not this CU's stale lines
+  *gen += 1u;
+  return __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u;
+}
+
+#ifndef PDEOPT_COOP_THREADS
+#define PDEOPT_COOP_THREADS 512  // 1024 threads cap a thread at 128 registers: the step loop's uniform doubles then spill (48-140 B fp32)
+#endif
+template <typename T, int EQ, bool FAST>
+__global__ __launch_bounds__(PDEOPT_COOP_THREADS) void tsit5_coop_kernel(const CoopArgs<T> a) {
+  constexpr int NT = PDEOPT_COOP_THREADS;
+  constexpr bool kTwoPass = EQ == PDEOPT_EQ_CAHN_HILLIARD || EQ == PDEOPT_EQ_CAHN_HILLIARD_SBM;  // mu / inner array
+  constexpr bool kSBM = EQ == PDEOPT_EQ_ALLEN_CAHN_SBM || EQ == PDEOPT_EQ_CAHN_HILLIARD_SBM;
+  constexpr bool kAD = EQ == PDEOPT_EQ_ADVECTION_DIFFUSION;
+  constexpr int R = kTwoPass ? 2 : 1;  // stencil radius of one right-hand side
+  constexpr int H = 6 * R;
+
+  // block -> (environment of this launch, tile).  Blocks are dealt round-robin over the 8 XCDs (block index mod 8): an
+  // environment's workgroups sit on a.xs neighbouring XCDs (1 wherever they fit one XCD's compute units: the exchange
+  // then stays in that XCD's L2), a.wpx of them per XCD
+  const int nwg = a.px * a.py;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int row = slot / a.wpx;
+  const int be = row * (8 / a.xs) + xcd / a.xs;
+  const int w = (slot - row * a.wpx) * a.xs + (xcd % a.xs);
+  if (be >= a.nenv || w >= nwg) return;  // the whole workgroup
+  const int wi = w / a.py, wj = w - wi * a.py;
+  const int nx = a.nx, ny = a.ny;
+  const int i0 = (int)((int64_t)wi * nx / a.px), i1 = (int)((int64_t)(wi + 1) * nx / a.px);
+  const int j0 = (int)((int64_t)wj * ny / a.py), j1 = (int)((int64_t)(wj + 1) * ny / a.py);
+  const int th = i1 - i0, tw = j1 - j0;
+  const int tid = threadIdx.x;
+  const int P = a.pitch;
+  const int FS = a.rows * P;
+
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  T* const sY = reinterpret_cast<T*>(smem_raw);
+  T* const sK = sY + FS;          // k1 .. k6: sK + j FS
+  T* sW = sK + 6 * FS;            // current stage input
+  T* sV = sW + FS;                // next stage input / k7
+  T* const sM = sV + FS;          // mu / inner (two-pass forms)
+  T* const sS = sM + (kTwoPass ? FS : 0);  // static fields: sS + j FS
+  double* const red = reinterpret_cast<double*>(smem_raw + a.red_off);  // [0..15] wave partials, [16..18] time terms
+
+  const EnvParams<T>& p = a.ep[be];
+  const T kap = p.kappa;
+  T* const yg = a.y + (int64_t)be * a.bstride;
+  const int64_t xoff = (int64_t)be * nx * ny;
+  unsigned* const bar = a.bar + 2 * be;
+  unsigned gen = 0;
+
+  // cells of the region T + e, local coordinates (r, c) relative to the tile origin: f(LDS offset, r, c)
+  auto region = [&](const int e, auto f) {
+    const int wd = tw + 2 * e, total = (th + 2 * e) * wd;
+    const float inv = 1.0f / (float)wd;
+    for (int idx = tid; idx < total; idx += NT) {
+      int rr = (int)(((float)idx + 0.5f) * inv);
+      int cc = idx - rr * wd;
+      if (cc < 0) { cc += wd; --rr; }
+      if (cc >= wd) { cc -= wd; ++rr; }
+      f((rr - e + H) * P + (cc - e + H), rr - e, cc - e);
+    }
+  };
+  auto gidx = [&](int r, int c) -> int64_t { return (int64_t)wrap1(i0 + r, nx) * ny + wrap1(j0 + c, ny); };
+
+  // ---- the state and the static fields on T + H
+  {
+    const T* const s0 = a.s0 ? a.s0 + be * a.sstride : nullptr;
+    const T* const s1 = a.s1 ? a.s1 + be * a.sstride : nullptr;
+    const T* const s2 = a.s2 ? a.s2 + be * a.sstride : nullptr;
+    region(H, [&](int o, int r, int c) {
+      const int64_t g = gidx(r, c);
+      sY[o] = yg[g];
+      if constexpr (kSBM || kAD) {
+        sS[o] = s0[g];
+        sS[FS + o] = s1[g];
+      }
+      if constexpr (kSBM) sS[2 * FS + o] = s2[g];
+    });
+  }
+  const T sqk = kSBM ? T(sqrt((double)kap)) : T(0);
+
+  // time terms of a right-hand-side evaluation at time ts: thread 0 -> red[16..18], read by everyone after a barrier
+  auto put_time_terms = [&](const double ts) {
+    if (kSBM && tid == 0) {
+      if (a.tmode == 0) {
+        red[16] = a.tw[0]; red[17] = a.tw[1]; red[18] = a.tw[2];
+      } else {
+        const double thv = ((a.theta[3] * ts + a.theta[2]) * ts + a.theta[1]) * ts + a.theta[0];
+        red[16] = cos(thv);
+        red[17] = cos(3.14159265358979323846 - thv);
+        red[18] = ((a.flux[3] * ts + a.flux[2]) * ts + a.flux[1]) * ts + a.flux[0];
+      }
+    }
+  };
+
+  // ---- right-hand side on a region.  pass1 (two-pass forms): mu / inner of `src` on T + e + 1 -> sM;
+  //      kcell: k at one cell of T + e from `src` (and sM).  Expressions: rhs_generic_point / sbm_tiled_kernel, term for term.
+  auto inner_at = [&](const T* src, int o, T twa, T twb) -> T {  // smoothed boundary: cahn_hilliard.py:262-279, allen_cahn.py:141-155
+    const T* q = sS;  // psi
+    const T c = src[o], xp = src[o + P], xm = src[o - P], yp = src[o + 1], ym = src[o - 1];
+    const T pc = q[o], pxp = q[o + P], pxm = q[o - P], pyp = q[o + 1], pym = q[o - 1];
+    const T m = sS[2 * FS + o];
+    const T wl = sqk * sS[FS + o] * (twa * m + twb * (T(1) - m));
+    const T dx_hi = (T(0.5) * (pc + pxp)) * ((xp - c) * a.rhx), dx_lo = (T(0.5) * (pxm + pc)) * ((c - xm) * a.rhx);
+    const T dy_hi = (T(0.5) * (pc + pyp)) * ((yp - c) * a.rhy), dy_lo = (T(0.5) * (pym + pc)) * ((c - ym) * a.rhy);
+    const T lap = (dx_hi - dx_lo) * a.rhx + (dy_hi - dy_lo) * a.rhy;
+    T rr = coop_mu<T, FAST>(a.mu, p.mu, c) - (kap * t_rcp<T>(pc)) * lap;
+    rr -= wl * t_sqrt<T>(T(2) * coop_fe<T, FAST>(a.fe, p.fe, c));
+    return rr;
+  };
+  auto pass1 = [&](const T* src, int e, T twa, T twb) {
+    if constexpr (kTwoPass) {
+      region(e + 1, [&](int o, int, int) {
+        if constexpr (EQ == PDEOPT_EQ_CAHN_HILLIARD) {
+          const T c = src[o];
+          sM[o] = coop_mu<T, FAST>(a.mu, p.mu, c) - kap * lap_at<T>(c, src[o + P], src[o - P], src[o + 1], src[o - 1], a.rhx2, a.rhy2);
+        } else {
+          sM[o] = inner_at(src, o, twa, twb);
+        }
+      });
+      __syncthreads();
+    }
+  };
+  auto kcell = [&](const T* src, int o, T twa, T twb, T tsrc) -> T {
+    if constexpr (EQ == PDEOPT_EQ_ALLEN_CAHN) {
+      const T c = src[o];
+      const T m = coop_mu<T, FAST>(a.mu, p.mu, c) - kap * lap_at<T>(c, src[o + P], src[o - P], src[o + 1], src[o - 1], a.rhx2, a.rhy2);
+      return -coop_mob<T, FAST>(a.mob, p.mob, c) * m;
+    } else if constexpr (EQ == PDEOPT_EQ_ALLEN_CAHN_SBM) {
+      return -coop_mob<T, FAST>(a.mob, p.mob, src[o]) * inner_at(src, o, twa, twb);
+    } else if constexpr (kAD) {
+      // -div(v u) + D lap u with face-averaged u and face velocities (stencil_generic.hpp)
+      const T* vx = sS;
+      const T* vy = sS + FS;
+      const T u00 = src[o], uxp = src[o + P], uxm = src[o - P], uyp = src[o + 1], uym = src[o - 1];
+      const T fx0 = vx[o] * (T(0.5) * (u00 + uxp)), fxm = vx[o - P] * (T(0.5) * (uxm + u00));
+      const T fy0 = vy[o] * (T(0.5) * (u00 + uyp)), fym = vy[o - 1] * (T(0.5) * (uym + u00));
+      return -((fx0 - fxm) * a.rhx + (fy0 - fym) * a.rhy) + kap * lap_at<T>(u00, uxp, uxm, uyp, uym, a.rhx2, a.rhy2);
+    } else {
+      const T m00 = sM[o], mxp = sM[o + P], mxm = sM[o - P], myp = sM[o + 1], mym = sM[o - 1];
+      const T d00 = coop_mob<T, FAST>(a.mob, p.mob, src[o]);
+      const T dxp = coop_mob<T, FAST>(a.mob, p.mob, src[o + P]), dxm = coop_mob<T, FAST>(a.mob, p.mob, src[o - P]);
+      const T dyp = coop_mob<T, FAST>(a.mob, p.mob, src[o + 1]), dym = coop_mob<T, FAST>(a.mob, p.mob, src[o - 1]);
+      if constexpr (EQ == PDEOPT_EQ_CAHN_HILLIARD) {
+        const T fx0 = (T(0.5) * (d00 + dxp)) * ((mxp - m00) * a.rhx), fxm = (T(0.5) * (dxm + d00)) * ((m00 - mxm) * a.rhx);
+        const T fy0 = (T(0.5) * (d00 + dyp)) * ((myp - m00) * a.rhy), fym = (T(0.5) * (dym + d00)) * ((m00 - mym) * a.rhy);
+        return (fx0 - fxm) * a.rhx + (fy0 - fym) * a.rhy;
+      } else {  // smoothed-boundary Cahn-Hilliard: cahn_hilliard.py:280-289
+        const T* q = sS;
+        const T p00 = q[o], pxp = q[o + P], pxm = q[o - P], pyp = q[o + 1], pym = q[o - 1];
+        const T fx0 = (T(0.5) * (p00 + pxp)) * (T(0.5) * (d00 + dxp)) * ((mxp - m00) * a.rhx);
+        const T fxm = (T(0.5) * (pxm + p00)) * (T(0.5) * (dxm + d00)) * ((m00 - mxm) * a.rhx);
+        const T fy0 = (T(0.5) * (p00 + pyp)) * (T(0.5) * (d00 + dyp)) * ((myp - m00) * a.rhy);
+        const T fym = (T(0.5) * (pym + p00)) * (T(0.5) * (dym + d00)) * ((m00 - mym) * a.rhy);
+        return ((fx0 - fxm) * a.rhx + (fy0 - fym) * a.rhy) * t_rcp<T>(p00) + sS[FS + o] * tsrc;
+      }
+    }
+  };
+  auto time_terms = [&](T* twa, T* twb, T* tsrc) {
+    *twa = kSBM ? T(red[16]) : T(0);
+    *twb = kSBM ? T(red[17]) : T(0);
+    *tsrc = kSBM ? T(red[18]) : T(0);
+  };
+  // halo ring (T + e minus T) of an LDS array <- the exchange buffer
+  auto load_ring = [&](T* dst, const T* src, int e) {
+    region(e, [&](int o, int r, int c) {
+      if (r < 0 || r >= th || c < 0 || c >= tw) dst[o] = src[gidx(r, c)];
+    });
+  };
+
+  // ---- k1 = f(t0, y0) on the tile; its halo through the exchange
+  put_time_terms(a.t0);
+  __syncthreads();  // sY, the static fields and the time terms are in place
+  {
+    T twa, twb, tsrc;
+    time_terms(&twa, &twb, &tsrc);
+    pass1(sY, 0, twa, twb);
+    T* const xk0 = a.xk[0] + xoff;
+    region(0, [&](int o, int r, int c) {
+      const T k = kcell(sY, o, twa, twb, tsrc);
+      sK[o] = k;
+      xk0[(int64_t)(i0 + r) * ny + (j0 + c)] = k;
+    });
+  }
+  if (!coop_env_barrier(bar, a.abort_flag, nwg, &gen)) return;
+  load_ring(sK, a.xk[0] + xoff, H);
+  int cur = 0;  // exchange buffer parity of the accepted state
+  __syncthreads();
+
+  const T rtol = T(a.pid.rtol), atol = T(a.pid.atol);
+  const double inv_cells = 1.0 / ((double)nx * (double)ny);
+  double t = a.t0, dt = a.dt0, prev_inv = 1.0, prev_prev_inv = 1.0;
+  int64_t accepted = 0, rejected = 0;
+  int qi = 0, status = PDEOPT_TSIT5_DONE;
+  unsigned step = 0;
+  while (t < a.t1) {
+    if (accepted + rejected >= a.max_steps) {
+      status = PDEOPT_TSIT5_MAX_STEPS;
+      break;
+    }
+    const double h = fmin(dt, a.t1 - t);
+    if (!(h > 0.0) || t + h == t) {
+      status = PDEOPT_TSIT5_STALLED;
+      break;
+    }
+    // stage 2 input on T + 6 R (where k1 lives)
+    {
+      const T c0 = T(h * kTsA[0][0]);
+      region(H, [&](int o, int, int) { sW[o] = sY[o] + c0 * sK[o]; });
+    }
+    put_time_terms(t + kTsC[0] * h);
+    __syncthreads();
+    // stages 2 .. 6 (slope index s = 1 .. 5): k on T + R (6 - s), with it the next stage's input there.  One instantiation
+    // per stage: the weights stay in registers (a run-time stage index would index them dynamically -> scratch)
+    auto stage = [&](auto s_c) {
+      constexpr int s = decltype(s_c)::value;
+      constexpr int e = R * (6 - s);
+      T cs[s + 1];
+#pragma unroll
+      for (int i = 0; i <= s; ++i) cs[i] = T(h * kTsA[s][i]);
+      T twa, twb, tsrc;
+      time_terms(&twa, &twb, &tsrc);
+      if constexpr (kSBM && !kTwoPass) __syncthreads();  // every wave has read this stage's terms before thread 0 posts the next
+      pass1(sW, e, twa, twb);
+      T* const ks = sK + s * FS;
+      region(e, [&](int o, int, int) {
+        const T k = kcell(sW, o, twa, twb, tsrc);
+        ks[o] = k;
+        T r = sY[o];
+#pragma unroll
+        for (int i = 0; i < s; ++i) r = r + cs[i] * sK[i * FS + o];
+        sV[o] = r + cs[s] * k;
+      });
+      put_time_terms(t + kTsC[s] * h);  // the NEXT stage's time (its reads come after the barrier)
+      __syncthreads();
+      T* const tmp = sW;
+      sW = sV;
+      sV = tmp;
+    };
+    stage(std::integral_constant<int, 1>{});
+    stage(std::integral_constant<int, 2>{});
+    stage(std::integral_constant<int, 3>{});
+    stage(std::integral_constant<int, 4>{});
+    stage(std::integral_constant<int, 5>{});
+    // stage 7 on the tile: k7 = f(y1), the scaled error, the speculative exchange write
+    double part = 0.0;
+    {
+      T ce[7];
+#pragma unroll
+      for (int i = 0; i < 7; ++i) ce[i] = T(h * kTsE[i]);
+      T twa, twb, tsrc;
+      time_terms(&twa, &twb, &tsrc);
+      pass1(sW, 0, twa, twb);  // (the next write of the time terms lies behind the environment barrier)
+      T* const xyn = a.xy[cur ^ 1] + xoff;
+      T* const xkn = a.xk[cur ^ 1] + xoff;
+      region(0, [&](int o, int r, int c) {
+        const T k7 = kcell(sW, o, twa, twb, tsrc);
+        sV[o] = k7;
+        T ev = T(0);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) ev = ev + ce[i] * sK[i * FS + o];
+        ev = ev + ce[6] * k7;
+        const T y0 = sY[o], y1 = sW[o];
+        const T sc = atol + rtol * fmax(fabs(y0), fabs(y1));
+        const double qv = (double)(ev / sc);
+        part += qv * qv;
+        const int64_t g = (int64_t)(i0 + r) * ny + (j0 + c);
+        xyn[g] = y1;
+        xkn[g] = k7;
+      });
+    }
+#pragma unroll
+    for (int sft = 32; sft > 0; sft >>= 1) part += __shfl_down(part, sft, 64);
+    if ((tid & 63) == 0) red[tid >> 6] = part;
+    __syncthreads();
+    double* const parts = a.part + ((size_t)(step & 1u) * a.nenv + be) * nwg;
+    if (tid == 0) {
+      double sum = 0.0;
+      for (int i = 0; i < NT / 64; ++i) sum += red[i];
+      parts[w] = sum;
+    }
+    if (!coop_env_barrier(bar, a.abort_flag, nwg, &gen)) return;
+    double sum = 0.0;
+    {
+      const volatile double* const pv = parts;  // (behind the acquire fence of the barrier)
+      for (int i = 0; i < nwg; ++i) sum += pv[i];  // one order for every workgroup: the same double everywhere
+    }
+    ++step;
+    const double err = sqrt(sum * inv_cells);  // diffrax rms_norm
+
+    const bool keep = err < 1.0;  // a NaN norm rejects
+    const double inv = (err > 0.0 && err < __builtin_inf()) ? 1.0 / err : (err == 0.0 ? __builtin_inf() : 0.0);
+    double f = pid_term(inv, a.pid.k1, a.pid) * pid_term(prev_inv, a.pid.k2, a.pid) * pid_term(prev_prev_inv, a.pid.k3, a.pid);
+    f = fmin(a.pid.factormax, fmax(a.pid.factormin, a.pid.safety * f));
+    if (!keep) f = fmin(1.0, f);
+    if (keep) {
+      ++accepted;
+      const double t_new = t + h;
+      while (qi < a.n_save) {
+        const double tq = a.save_ts[qi];
+        if (!(tq <= t_new + 1e-14 * fmax(1.0, fabs(t_new)))) break;
+        double bw[7];
+        tsit5_dense_weights(fmin(1.0, fmax(0.0, (tq - t) / h)), bw);
+        T cw[7];
+#pragma unroll
+        for (int i = 0; i < 7; ++i) cw[i] = T(h * bw[i]);
+        T* const out = a.save_out + (int64_t)qi * a.save_stride + xoff;
+        region(0, [&](int o, int r, int c) {
+          T rv = sY[o];
+#pragma unroll
+          for (int i = 0; i < 6; ++i) rv = rv + cw[i] * sK[i * FS + o];
+          rv = rv + cw[6] * sV[o];
+          out[(int64_t)(i0 + r) * ny + (j0 + c)] = rv;
+        });
+        ++qi;
+      }
+      // y <- y1, k1 <- k7 (FSAL): the tile from LDS, the halo ring from the neighbours' tiles
+      region(0, [&](int o, int, int) {
+        sY[o] = sW[o];
+        sK[o] = sV[o];
+      });
+      cur ^= 1;
+      load_ring(sY, a.xy[cur] + xoff, H);
+      load_ring(sK, a.xk[cur] + xoff, H);
+      t = t_new < a.t1 - 1e-14 * fmax(1.0, fabs(a.t1)) ? t_new : a.t1;
+      prev_prev_inv = prev_inv;
+      prev_inv = inv;
+    } else {
+      ++rejected;
+    }
+    dt = fmin(a.pid.dtmax, fmax(a.pid.dtmin, h * f));
+    __syncthreads();  // sY / sK complete before the next step's stage-2 input reads them
+  }
+  region(0, [&](int o, int r, int c) { yg[(int64_t)(i0 + r) * ny + (j0 + c)] = sY[o]; });
+  if (w == 0 && tid == 0) {
+    pdeopt_tsit5_stats st;
+    st.t = t;
+    st.dt = dt;
+    st.accepted = accepted;
+    st.rejected = rejected;
+    st.status = status;
+    st.saved = qi;
+    a.stats[be] = st;
+  }
+}
+
+// --------------------------------------------------------------------------------------------- host
+
+constexpr size_t kCoopLdsMax = 160 * 1024;
+
+struct CoopPlan {
+  int px = 0, py = 0, rows = 0, pitch = 0, nfields = 0, halo = 0;
+  size_t lds = 0;
+  int red_off = 0;
+};
+
+inline int coop_radius(int equation) {
+  return (equation == PDEOPT_EQ_CAHN_HILLIARD || equation == PDEOPT_EQ_CAHN_HILLIARD_SBM) ? 2 : 1;
+}
+
+// the tile grid: tiles of about 28 cells where that fits the LDS, smaller otherwise; at most `max_wg` workgroups
+template <typename T>
+bool coop_plan(const pdeopt_problem& p, int max_wg, CoopPlan* out) {
+  const int eq = p.equation;
+  const int R = coop_radius(eq), H = 6 * R;
+  const bool sbm = eq == PDEOPT_EQ_ALLEN_CAHN_SBM || eq == PDEOPT_EQ_CAHN_HILLIARD_SBM;
+  const int nstatic = sbm ? 3 : (eq == PDEOPT_EQ_ADVECTION_DIFFUSION ? 2 : 0);
+  const int nf = 1 + 6 + 2 + (R == 2 ? 1 : 0) + nstatic;
+  if (p.nx < H || p.ny < H) return false;
+  auto fits = [&](int px, int py, CoopPlan* pl) {
+    const int tx = (p.nx + px - 1) / px, ty = (p.ny + py - 1) / py;
+    const int rows = tx + 2 * H;
+    int pitch = ty + 2 * H;
+    if (pitch % 2 == 0) ++pitch;  // odd pitch: vertically adjacent cells on different banks
+    const size_t field = (size_t)rows * pitch * sizeof(T);
+    const size_t arrays = (nf * field + 15) / 16 * 16;
+    const size_t lds = arrays + 24 * sizeof(double);
+    if (lds > kCoopLdsMax) return false;
+    pl->px = px; pl->py = py; pl->rows = rows; pl->pitch = pitch; pl->nfields = nf; pl->halo = H; pl->lds = lds; pl->red_off = (int)arrays;
+    return true;
+  };
+  // start from ~28-cell tiles (R = 2) / ~24 (R = 1) and split the longer side until the arrays fit
+  const int target = R == 2 ? 28 : 24;
+  int px = std::max(1, (p.nx + target - 1) / target), py = std::max(1, (p.ny + target - 1) / target);
+  for (int it = 0; it < 64; ++it) {
+    if (px > p.nx || py > p.ny || px * py > max_wg) return false;
+    if (fits(px, py, out)) return true;
+    if ((p.nx + px - 1) / px >= (p.ny + py - 1) / py) ++px; else ++py;
+  }
+  return false;
+}
+
+template <typename T>
+bool coop_tsit5_supported(const pdeopt_ctx* ctx) {
+  const pdeopt_problem& p = ctx->prob;
+  if (ctx->opt_small_persist < 0 || ctx->opt_kernel_path == 1 || ctx->opt_debug_ablate) return false;
+  if (ctx->halo || p.nz > 1) return false;
+  const int eq = p.equation;
+  const bool sbm = eq == PDEOPT_EQ_ALLEN_CAHN_SBM || eq == PDEOPT_EQ_CAHN_HILLIARD_SBM;
+  if (eq != PDEOPT_EQ_CAHN_HILLIARD && eq != PDEOPT_EQ_ALLEN_CAHN && !sbm && eq != PDEOPT_EQ_ADVECTION_DIFFUSION) return false;
+  if (eq != PDEOPT_EQ_ADVECTION_DIFFUSION && p.derivs != PDEOPT_DERIVS_FD) return false;
+  if (sbm) {
+    // the kernel evaluates theta(t) / flux(t) itself: constants or polynomials (pdeopt_set_time_terms_poly); a host
+    // callback per stage time cannot be asked from inside a launch
+    if (ctx->time_fn && !ctx->time_poly_valid) return false;
+    if (!ctx->aux[PDEOPT_AUX_SBM_PSI].dev || !ctx->aux[PDEOPT_AUX_SBM_NORM_GRAD].dev || !ctx->aux[PDEOPT_AUX_SBM_MASK].dev) return false;
+  }
+  if (eq == PDEOPT_EQ_ADVECTION_DIFFUSION) {
+    if (has_time_aux(ctx, PDEOPT_AUX_VX_FACE) || has_time_aux(ctx, PDEOPT_AUX_VY_FACE)) return false;  // velocity_fn(t, .) varies
+    if (!ctx->aux[PDEOPT_AUX_VX_FACE].dev || !ctx->aux[PDEOPT_AUX_VY_FACE].dev) return false;
+  }
+  CoopPlan pl;
+  return coop_plan<T>(p, ctx->num_cus, &pl);
+}
+
+template <typename T>
+int coop_tsit5_solve(pdeopt_ctx* ctx, double t0, double t1, double dt0, const pdeopt_pid* pid, int64_t max_steps, int n_save,
+                     const double* save_ts, void* save_host, pdeopt_tsit5_stats* stats_host) {
+  const pdeopt_problem& p = ctx->prob;
+  const int batch = p.batch;
+  const int64_t cells = (int64_t)p.nx * p.ny;
+  CoopPlan pl;
+  if (!coop_plan<T>(p, ctx->num_cus, &pl)) return fail(ctx, PDEOPT_EINVAL, "the multi-workgroup adaptive kernel does not cover this problem");
+  const int nwg = pl.px * pl.py;
+  const int eq = p.equation;
+  const bool sbm = eq == PDEOPT_EQ_ALLEN_CAHN_SBM || eq == PDEOPT_EQ_CAHN_HILLIARD_SBM;
+  int rc;
+  // exchange buffers: the integrators' work fields
+  if ((rc = ensure_buffer(ctx, &ctx->TA, ctx->total_bytes))) return rc;
+  if ((rc = ensure_buffer(ctx, &ctx->TB, ctx->total_bytes))) return rc;
+  if ((rc = ensure_buffer(ctx, &ctx->ACC, ctx->total_bytes))) return rc;
+  if ((rc = ensure_buffer(ctx, &ctx->KS, ctx->total_bytes))) return rc;
+
+  CoopArgs<T> s{};
+  s.nx = p.nx; s.ny = p.ny; s.px = pl.px; s.py = pl.py;
+  s.bstride = make_geo(ctx).bstride;
+  s.rhx = T(1.0 / p.hx); s.rhy = T(1.0 / p.hy);
+  s.rhx2 = T(1.0 / (p.hx * p.hx)); s.rhy2 = T(1.0 / (p.hy * p.hy));
+  s.mu = ClosureSpec{p.mu.kind, p.mu.flags, p.mu.n};
+  s.mob = ClosureSpec{p.mob.kind, p.mob.flags, p.mob.n};
+  s.fe = ClosureSpec{p.fe.kind, p.fe.flags, p.fe.n};
+  s.t0 = t0; s.t1 = t1; s.dt0 = dt0;
+  const double order = 5.0;
+  s.pid.rtol = pid->rtol; s.pid.atol = pid->atol;
+  s.pid.k1 = (pid->icoeff + pid->pcoeff + pid->dcoeff) / order;
+  s.pid.k2 = -(pid->pcoeff + 2 * pid->dcoeff) / order;
+  s.pid.k3 = pid->dcoeff / order;
+  s.pid.factormin = pid->factormin; s.pid.factormax = pid->factormax; s.pid.safety = pid->safety;
+  s.pid.dtmin = pid->dtmin; s.pid.dtmax = pid->dtmax;
+  s.max_steps = max_steps;
+  s.n_save = n_save;
+  s.save_stride = (int64_t)batch * cells;
+  s.rows = pl.rows; s.pitch = pl.pitch; s.red_off = pl.red_off;
+  if (sbm) {
+    if (ctx->time_poly_valid) {
+      s.tmode = 1;
+      for (int i = 0; i < 4; ++i) { s.theta[i] = ctx->time_theta[i]; s.flux[i] = ctx->time_flux[i]; }
+    } else {
+      s.tmode = 0;
+      for (int i = 0; i < 3; ++i) s.tw[i] = ctx->time_const[i];
+    }
+  }
+
+  // one device block: save times, statistics, barrier words + abort flag, partial sums, save slots
+  const size_t ts_bytes = ((size_t)n_save * sizeof(double) + 255) / 256 * 256;
+  const size_t st_bytes = ((size_t)batch * sizeof(pdeopt_tsit5_stats) + 255) / 256 * 256;
+  const size_t bar_bytes = ((size_t)(2 * batch + 1) * sizeof(unsigned) + 255) / 256 * 256;
+  const size_t part_bytes = ((size_t)2 * batch * nwg * sizeof(double) + 255) / 256 * 256;
+  const size_t out_bytes = (size_t)n_save * batch * cells * sizeof(T);
+  const size_t need = ts_bytes + st_bytes + bar_bytes + part_bytes + out_bytes + 256;
+  if (ctx->adaptive_cap < need) {
+    if (ctx->adaptive_blk) {
+      PDEOPT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+      (void)hipFree(ctx->adaptive_blk);
+      ctx->adaptive_blk = nullptr;
+      ctx->adaptive_cap = 0;
+    }
+    PDEOPT_HIP_CHECK(ctx, hipMalloc(&ctx->adaptive_blk, need));
+    ctx->adaptive_cap = need;
+  }
+  char* const blk = static_cast<char*>(ctx->adaptive_blk);
+  s.save_ts = reinterpret_cast<const double*>(blk);
+  pdeopt_tsit5_stats* const stats_dev = reinterpret_cast<pdeopt_tsit5_stats*>(blk + ts_bytes);
+  unsigned* const bar_dev = reinterpret_cast<unsigned*>(blk + ts_bytes + st_bytes);
+  double* const part_dev = reinterpret_cast<double*>(blk + ts_bytes + st_bytes + bar_bytes);
+  T* const out_dev = reinterpret_cast<T*>(blk + ts_bytes + st_bytes + bar_bytes + part_bytes);
+  if (n_save) {
+    PDEOPT_HIP_CHECK(ctx, hipMemcpyAsync(blk, save_ts, (size_t)n_save * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    PDEOPT_HIP_CHECK(ctx, hipMemsetAsync(out_dev, 0xFF, out_bytes, ctx->stream));  // NaN fill
+  }
+  PDEOPT_HIP_CHECK(ctx, hipMemsetAsync(stats_dev, 0, st_bytes + bar_bytes + part_bytes, ctx->stream));
+
+  char name[112];
+  const char* eqn = eq == PDEOPT_EQ_CAHN_HILLIARD ? "CH" : eq == PDEOPT_EQ_ALLEN_CAHN ? "AC" : eq == PDEOPT_EQ_CAHN_HILLIARD_SBM ? "CH-SBM"
+                    : eq == PDEOPT_EQ_ALLEN_CAHN_SBM ? "AC-SBM" : "AD";
+  const bool fast = eq == PDEOPT_EQ_ADVECTION_DIFFUSION || coop_fast_closures(p, sbm);
+  snprintf(name, sizeof(name), "tsit5_coop<%s,%s,%s,%dx%d workgroups>", sizeof(T) == 4 ? "f32" : "f64", eqn, fast ? "fixed closures" : "generic closures",
+           pl.px, pl.py);
+  ctx->last_kernel = name;
+  ctx->tsit5_pending = false;
+  ctx->tsit5_fsal_valid = false;
+
+  auto kern = [&]() -> const void* {
+#define PDEOPT_COOP_K(EQV) (fast ? reinterpret_cast<const void*>(tsit5_coop_kernel<T, EQV, true>) : reinterpret_cast<const void*>(tsit5_coop_kernel<T, EQV, false>))
+    switch (eq) {
+      case PDEOPT_EQ_CAHN_HILLIARD: return PDEOPT_COOP_K(PDEOPT_EQ_CAHN_HILLIARD);
+      case PDEOPT_EQ_ALLEN_CAHN: return PDEOPT_COOP_K(PDEOPT_EQ_ALLEN_CAHN);
+      case PDEOPT_EQ_CAHN_HILLIARD_SBM: return PDEOPT_COOP_K(PDEOPT_EQ_CAHN_HILLIARD_SBM);
+      case PDEOPT_EQ_ALLEN_CAHN_SBM: return PDEOPT_COOP_K(PDEOPT_EQ_ALLEN_CAHN_SBM);
+      default: return reinterpret_cast<const void*>(tsit5_coop_kernel<T, PDEOPT_EQ_ADVECTION_DIFFUSION, true>);
+    }
+#undef PDEOPT_COOP_K
+  }();
+  PDEOPT_HIP_CHECK(ctx, hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds));
+  // Every workgroup of a launch must be resident at once (they wait for each other): one workgroup per compute unit,
+  // an environment's workgroups on one XCD (blocks are dealt round-robin over the 8 XCDs of 32 CUs each)
+  const int cus_per_xcd = std::max(1, ctx->num_cus / 8);
+  int xs = 1;
+  while (xs < 8 && (nwg + xs - 1) / xs > cus_per_xcd) xs *= 2;  // fp64 tiles are small: an environment may need two XCDs
+  const int wpx = (nwg + xs - 1) / xs;
+  if (wpx > cus_per_xcd) return fail(ctx, PDEOPT_EINVAL, "%d workgroups per environment exceed the device's %d compute units", nwg, ctx->num_cus);
+  const int rows_per_launch = cus_per_xcd / wpx;
+  const int envs_per_launch = rows_per_launch * (8 / xs);
+  s.xs = xs;
+  s.wpx = wpx;
+
+  const T* s0 = nullptr; const T* s1 = nullptr; const T* s2 = nullptr;
+  int64_t sstride = 0;
+  if (sbm) {
+    s0 = static_cast<const T*>(ctx->aux[PDEOPT_AUX_SBM_PSI].dev);
+    s1 = static_cast<const T*>(ctx->aux[PDEOPT_AUX_SBM_NORM_GRAD].dev);
+    s2 = static_cast<const T*>(ctx->aux[PDEOPT_AUX_SBM_MASK].dev);
+  } else if (eq == PDEOPT_EQ_ADVECTION_DIFFUSION) {
+    s0 = static_cast<const T*>(ctx->aux[PDEOPT_AUX_VX_FACE].dev);
+    s1 = static_cast<const T*>(ctx->aux[PDEOPT_AUX_VY_FACE].dev);
+    sstride = ctx->aux[PDEOPT_AUX_VX_FACE].per_env ? cells : 0;
+  }
+  for (int e0 = 0; e0 < batch; e0 += envs_per_launch) {
+    const int ne = std::min(envs_per_launch, batch - e0);
+    CoopArgs<T> c = s;
+    c.nenv = ne;
+    c.y = static_cast<T*>(ctx->Y) + (int64_t)e0 * s.bstride;
+    c.ep = static_cast<const EnvParams<T>*>(ctx->env_params_dev) + e0;
+    c.s0 = s0 ? s0 + (int64_t)e0 * sstride : nullptr;
+    c.s1 = s1 ? s1 + (int64_t)e0 * sstride : nullptr;
+    c.s2 = s2;
+    c.sstride = sstride;
+    c.save_out = out_dev + (int64_t)e0 * cells;
+    c.stats = stats_dev + e0;
+    c.xy[0] = static_cast<T*>(ctx->TA) + (int64_t)e0 * cells; c.xy[1] = static_cast<T*>(ctx->TB) + (int64_t)e0 * cells;
+    c.xk[0] = static_cast<T*>(ctx->ACC) + (int64_t)e0 * cells; c.xk[1] = static_cast<T*>(ctx->KS) + (int64_t)e0 * cells;
+    c.part = part_dev + (size_t)2 * e0 * nwg;
+    c.bar = bar_dev + 2 * e0;
+    c.abort_flag = bar_dev + 2 * batch;
+    const int rows_used = (ne + 8 / xs - 1) / (8 / xs);
+    void* params[] = {&c};
+    PDEOPT_HIP_CHECK(ctx, hipLaunchKernel(kern, dim3(8 * rows_used * wpx), dim3(PDEOPT_COOP_THREADS), params, pl.lds, ctx->stream));
+    ctx->n_stage_launches++;
+  }
+  unsigned aborted = 0;
+  PDEOPT_HIP_CHECK(ctx, hipMemcpyAsync(stats_host, stats_dev, (size_t)batch * sizeof(pdeopt_tsit5_stats), hipMemcpyDeviceToHost, ctx->stream));
+  PDEOPT_HIP_CHECK(ctx, hipMemcpyAsync(&aborted, bar_dev + 2 * batch, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
+  if (n_save) PDEOPT_HIP_CHECK(ctx, hipMemcpyAsync(save_host, out_dev, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+  PDEOPT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  if (aborted)
+    return fail(ctx, PDEOPT_ESTATE, "the multi-workgroup adaptive solve was aborted: a workgroup waited more than 2 s for its partners "
+                                    "(the launch's workgroups were not all resident, or the device was shared)");
+  return PDEOPT_OK;
+}
+
+}  // namespace pdeopt

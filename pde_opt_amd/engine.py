@@ -262,16 +262,27 @@ class HipEngine:
             self._lib.pdeopt_set_integrator_params(self._h, float(imex_A), ts.real, ts.imag, float(strang_dx))
         )
 
-    def set_time_terms(self, fn=None, constant=(0.0, 0.0, 0.0)):
+    def set_time_terms(self, fn=None, constant=(0.0, 0.0, 0.0), theta_poly=None, flux_poly=None):
         """Smoothed-boundary scalars per RHS evaluation time: ``fn(t) -> (cos theta on the mask,
         cos off the mask, flux)`` is called by the library at every stage; ``fn=None`` uses
-        ``constant``.  The ctypes thunk is kept alive on the engine."""
+        ``constant``.  The ctypes thunk is kept alive on the engine.  ``theta_poly`` / ``flux_poly``: ascending
+        coefficients of theta(t) and flux(t) when both are polynomials of degree <= 3 (``closures.poly_in_t``) --
+        the in-kernel adaptive solve evaluates them at its own stage times (``pdeopt_set_time_terms_poly``); without
+        them a callback keeps an adaptive solve on the host-driven path."""
         const = (C.c_double * 3)(*[float(v) for v in constant])
         self._time_terms_fn = fn
         if fn is None:
             self._time_thunk = None
             self._check(self._lib.pdeopt_set_time_terms(self._h, L.TIME_FN(0), None, const))
             return
+        self._set_time_thunk(fn, const)
+        if theta_poly is not None and flux_poly is not None:
+            th = np.ascontiguousarray(np.asarray(theta_poly, dtype=np.float64))
+            fl = np.ascontiguousarray(np.asarray(flux_poly, dtype=np.float64))
+            self._check(self._lib.pdeopt_set_time_terms_poly(self._h, len(th), th.ctypes.data_as(C.c_void_p), len(fl),
+                                                             fl.ctypes.data_as(C.c_void_p)))
+
+    def _set_time_thunk(self, fn, const):
 
         def thunk(t, out, _user):
             a, b, f = fn(t)

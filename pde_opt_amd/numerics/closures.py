@@ -258,3 +258,45 @@ def _as_closure_uncached(fn) -> ClosureDesc:
     if isinstance(out, np.ndarray) and out.ndim == 0:
         return constant(float(out))
     raise UnsupportedClosureError(f"closure returned {type(out).__name__}, expected an array expression")
+
+
+def poly_in_t(fn, samples=(0.0, 0.37, 1.9), max_degree: int = 3):
+    """Ascending coefficients of ``fn(t)`` if it is a polynomial in t of degree <= ``max_degree`` (a number, or a
+    callable built from operators on t -- the ``theta(t)`` / ``flux(t)`` fields of the smoothed-boundary equations,
+    cahn_hilliard.py:232-235; notebooks/smooth_boundary.ipynb:262 is a quadratic), else ``None``.  The traced
+    polynomial is checked against the callable itself at a few times before it is trusted: the in-kernel adaptive
+    solve evaluates it at stage times of its own choosing (``pdeopt_set_time_terms_poly``)."""
+    if isinstance(fn, numbers.Real):
+        return [float(fn)]
+    if not callable(fn):
+        return None
+    import sympy as sp
+
+    t = sp.Symbol("t", real=True)
+    try:
+        out = fn(_Sym(t))
+    except Exception:
+        return None
+    if isinstance(out, _Sym):
+        try:
+            poly = sp.Poly(sp.expand(out.e), t)
+        except Exception:
+            return None
+        if poly.degree() > max_degree or any(not c.is_number for c in poly.all_coeffs()):
+            return None
+        coef = [float(c) for c in reversed(poly.all_coeffs())]
+    elif isinstance(out, numbers.Real) or (isinstance(out, np.ndarray) and out.ndim == 0):
+        coef = [float(out)]
+    else:
+        return None
+    if not all(np.isfinite(coef)):
+        return None
+    for ts in samples:  # the callable has the last word
+        try:
+            want = float(fn(float(ts)))
+        except Exception:
+            return None
+        got = sum(c * ts**i for i, c in enumerate(coef))
+        if not abs(got - want) <= 1e-12 * max(1.0, abs(want)):
+            return None
+    return coef

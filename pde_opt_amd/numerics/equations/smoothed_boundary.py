@@ -76,7 +76,15 @@ class _SmoothedBoundary(BaseEquation):
         engine.set_aux(L.AUX_SBM_PSI, self.psi)
         engine.set_aux(L.AUX_SBM_NORM_GRAD, self.norm_grad_psi)
         engine.set_aux(L.AUX_SBM_MASK, self.left_half)
-        engine.set_time_terms(self._time_terms)
+        # theta(t), flux(t) as polynomials where they are ones (constants included): the in-kernel adaptive solve
+        # chooses its stage times on the device and evaluates them there
+        from ..closures import poly_in_t
+
+        th, fl = poly_in_t(self.theta), poly_in_t(self.flux)
+        if th is not None and fl is not None:
+            engine.set_time_terms(self._time_terms, theta_poly=th, flux_poly=fl)
+        else:
+            engine.set_time_terms(self._time_terms)
 
     def _time_dependent_rhs(self, t0: float = 0.0, t1=None) -> bool:
         return True  # theta(t) / flux(t) are evaluated at every stage time

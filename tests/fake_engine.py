@@ -95,7 +95,7 @@ class OracleEngine:
             kappa = np.atleast_1d(np.asarray(kappa, dtype=float))
             self.kappa_env[env_first:env_first + len(kappa)] = kappa
 
-    def set_time_terms(self, fn=None, constant=(0.0, 0.0, 0.0)):
+    def set_time_terms(self, fn=None, constant=(0.0, 0.0, 0.0), theta_poly=None, flux_poly=None):
         self.time_fn = fn if fn is not None else (lambda t: constant)
 
     def set_integrator_params(self, imex_A=0.5, time_scale=1.0, strang_dx=1.0):
