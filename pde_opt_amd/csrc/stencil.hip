@@ -941,7 +941,12 @@ int tsit5_solve_small(pdeopt_ctx* ctx, double t0, double t1, double dt0, const p
   if (!single && !coop)
     return fail(ctx, PDEOPT_EINVAL, "the in-kernel adaptive solve takes periodic / smoothed-boundary Cahn-Hilliard and Allen-Cahn FD problems and "
                                     "advection-diffusion with a steady velocity, on grids its tiles cover (pdeopt_tsit5_solve_small_supported)");
-  if (coop && (!single || ctx->opt_small_persist == 2))
+  // both apply: one workgroup up to two vectors per thread (64^2 fp32: 18 us per trial step against 21 on 32 workgroups);
+  // from three vectors per thread on (its state then lives in LDS: 64^2 fp64 33 us) the multi-workgroup kernel (25 us)
+  constexpr int kV32 = 4, kV64 = 2;
+  const int64_t nvec = (int64_t)ctx->prob.nx * ctx->prob.ny / (ctx->prob.dtype == PDEOPT_F32 ? kV32 : kV64);
+  const bool prefer_coop = ctx->opt_small_persist == 2 || (ctx->opt_small_persist == 0 && nvec > 1024);
+  if (coop && (!single || prefer_coop))
     return ctx->prob.dtype == PDEOPT_F32 ? coop_tsit5_solve<float>(ctx, t0, t1, dt0, pid, max_steps, n_save, save_ts, save_host, stats)
                                          : coop_tsit5_solve<double>(ctx, t0, t1, dt0, pid, max_steps, n_save, save_ts, save_host, stats);
   return ctx->prob.dtype == PDEOPT_F32 ? small_tsit5_solve<float>(ctx, t0, t1, dt0, pid, max_steps, n_save, save_ts, save_host, stats)

@@ -38,6 +38,7 @@
 // when it has waited > 2 s at a barrier (a partner that never arrives): no wave can spin forever.
 #pragma once
 
+#include <cstdlib>
 #include <type_traits>
 
 #include "stencil_small_adaptive.hpp"
@@ -114,10 +115,14 @@ __device__ __forceinline__ int wrap1(int i, int n) {  // |offset| <= n: one cond
 constexpr unsigned long long kCoopTimeoutTicks = 200000000ull;  // 2 s of s_memrealtime (100 MHz)
 
 // Barrier over the nwg workgroups of one environment.  false: the solve was aborted (a partner did not arrive).
-__device__ __forceinline__ bool coop_env_barrier(unsigned* bar, unsigned* abort_flag, int nwg, unsigned* gen) {
-  __syncthreads();
+// one_xcd: the environment's workgroups share one XCD's L2 -- the exchange data is written and read with agent-scope
+// (L1-bypassing) accesses (xstore / xload below) and the barrier needs no cache maintenance; otherwise agent-scope
+// release / acquire fences write the L2 back and invalidate it (measured on the 100^2 smoothed-boundary solve: 6.5 us per
+// barrier with the fences; profiles/r04_coop_adaptive.txt).
+__device__ __forceinline__ bool coop_env_barrier(unsigned* bar, unsigned* abort_flag, int nwg, unsigned* gen, bool one_xcd) {
+  __syncthreads();  // every wave's stores have been acknowledged (s_waitcnt vmcnt(0) precedes the s_barrier)
   if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // this workgroup's exchange tile and partial sum: visible device-wide
+    if (!one_xcd) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     const unsigned g = *gen;
     if (__hip_atomic_fetch_add(&bar[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(nwg - 1)) {
       __hip_atomic_store(&bar[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -130,15 +135,20 @@ __device__ __forceinline__ bool coop_env_barrier(unsigned* bar, unsigned* abort_
           __hip_atomic_store(abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           break;
         }
-        __builtin_amdgcn_s_sleep(2);
+        __builtin_amdgcn_s_sleep(1);
       }
     }
   }
   __syncthreads();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // every wave: the partners' writes, not this CU's stale lines
+  if (!one_xcd) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // every wave: the partners' writes, not this CU's stale lines
   *gen += 1u;
   return __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u;
 }
+// exchange data: agent-scope accesses (sc1: past the per-CU vector cache, to the L2 the partners share)
+template <typename T>
+__device__ __forceinline__ T xload(const T* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <typename T>
+__device__ __forceinline__ void xstore(T* p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 #ifndef PDEOPT_COOP_THREADS
 #define PDEOPT_COOP_THREADS 512  // 1024 threads cap a thread at 128 registers: the step loop's uniform doubles then spill (48-140 B fp32)
@@ -177,25 +187,63 @@ __global__ __launch_bounds__(PDEOPT_COOP_THREADS) void tsit5_coop_kernel(const C
   T* sV = sW + FS;                // next stage input / k7
   T* const sM = sV + FS;          // mu / inner (two-pass forms)
   T* const sS = sM + (kTwoPass ? FS : 0);  // static fields: sS + j FS
-  double* const red = reinterpret_cast<double*>(smem_raw + a.red_off);  // [0..15] wave partials, [16..18] time terms
+  double* const red = reinterpret_cast<double*>(smem_raw + a.red_off);  // [0..15] wave partials, [16..18] time terms, [19..21] controller, [24..] partners' sums
 
-  const EnvParams<T>& p = a.ep[be];
-  const T kap = p.kappa;
+  // this environment's closure coefficients.  Fixed forms: copied into registers once -- read through the pointer inside
+  // the cell loops the compiler re-loaded the coefficient arrays from memory in every trip (two global_load_dwordx4 per
+  // cell).  Run-time closure walk: through the pointer (its loops index the arrays dynamically).
+  struct CoefRegs {
+    T mu[4], mob[4], fe[4];
+  };
+  struct CoefPtrs {
+    const T *mu, *mob, *fe;
+  };
+  std::conditional_t<FAST, CoefRegs, CoefPtrs> p;
+  {
+    const EnvParams<T>& pe = a.ep[be];
+    if constexpr (FAST) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        p.mu[i] = pe.mu[i];
+        p.mob[i] = pe.mob[i];
+        p.fe[i] = pe.fe[i];
+      }
+    } else {
+      p.mu = pe.mu;
+      p.mob = pe.mob;
+      p.fe = pe.fe;
+    }
+  }
+  const T kap = a.ep[be].kappa;
   T* const yg = a.y + (int64_t)be * a.bstride;
   const int64_t xoff = (int64_t)be * nx * ny;
   unsigned* const bar = a.bar + 2 * be;
   unsigned gen = 0;
+  const bool one_xcd = a.xs == 1;
 
   // cells of the region T + e, local coordinates (r, c) relative to the tile origin: f(LDS offset, r, c)
   auto region = [&](const int e, auto f) {
+    // (row, column) of a thread's cells are carried from one trip to the next: idx += NT is rr += NT / wd, cc += NT % wd
+    // with one carry -- a division per trip was ~12 of the ~110 instructions a cell costs
     const int wd = tw + 2 * e, total = (th + 2 * e) * wd;
     const float inv = 1.0f / (float)wd;
+    int rr = (int)(((float)tid + 0.5f) * inv);
+    int cc = tid - rr * wd;
+    if (cc < 0) { cc += wd; --rr; }
+    if (cc >= wd) { cc -= wd; ++rr; }
+    const int dr = (int)(((float)NT + 0.5f) * inv), dc = NT - dr * wd;  // NT = dr wd + dc, 0 <= dc < wd (wd <= NT + ...: see below)
+    int o = (rr - e + H) * P + (cc - e + H);
+    const int dO = dr * P + dc;
     for (int idx = tid; idx < total; idx += NT) {
-      int rr = (int)(((float)idx + 0.5f) * inv);
-      int cc = idx - rr * wd;
-      if (cc < 0) { cc += wd; --rr; }
-      if (cc >= wd) { cc -= wd; ++rr; }
-      f((rr - e + H) * P + (cc - e + H), rr - e, cc - e);
+      f(o, rr - e, cc - e);
+      rr += dr;
+      cc += dc;
+      o += dO;
+      if (cc >= wd) {
+        cc -= wd;
+        ++rr;
+        o += P - wd;
+      }
     }
   };
   auto gidx = [&](int r, int c) -> int64_t { return (int64_t)wrap1(i0 + r, nx) * ny + wrap1(j0 + c, ny); };
@@ -225,7 +273,8 @@ __global__ __launch_bounds__(PDEOPT_COOP_THREADS) void tsit5_coop_kernel(const C
       } else {
         const double thv = ((a.theta[3] * ts + a.theta[2]) * ts + a.theta[1]) * ts + a.theta[0];
         red[16] = cos(thv);
-        red[17] = cos(3.14159265358979323846 - thv);
+        // Cahn-Hilliard: cos(pi - theta) off the mask (cahn_hilliard.py:271-272); Allen-Cahn: nothing there (allen_cahn.py:150)
+        red[17] = EQ == PDEOPT_EQ_ALLEN_CAHN_SBM ? 0.0 : cos(3.14159265358979323846 - thv);
         red[18] = ((a.flux[3] * ts + a.flux[2]) * ts + a.flux[1]) * ts + a.flux[0];
       }
     }
@@ -299,11 +348,32 @@ __global__ __launch_bounds__(PDEOPT_COOP_THREADS) void tsit5_coop_kernel(const C
     *twb = kSBM ? T(red[17]) : T(0);
     *tsrc = kSBM ? T(red[18]) : T(0);
   };
-  // halo ring (T + e minus T) of an LDS array <- the exchange buffer
-  auto load_ring = [&](T* dst, const T* src, int e) {
-    region(e, [&](int o, int r, int c) {
-      if (r < 0 || r >= th || c < 0 || c >= tw) dst[o] = src[gidx(r, c)];
-    });
+  // the halo ring (T + H minus T) of y and k1 <- the exchange buffers: ring cells only (2 H full rows above and below,
+  // H columns left and right of every tile row), both fields' loads of a cell issued together
+  auto load_rings = [&](const T* srcy, const T* srck) {
+    const int wd = tw + 2 * H, top = 2 * H * wd, total = top + 2 * H * th;
+    const float inv = 1.0f / (float)wd;
+    for (int idx = tid; idx < total; idx += NT) {
+      int r, c;
+      if (idx < top) {
+        int rr = (int)(((float)idx + 0.5f) * inv);
+        int cc = idx - rr * wd;
+        if (cc < 0) { cc += wd; --rr; }
+        if (cc >= wd) { cc -= wd; ++rr; }
+        r = rr < H ? rr - H : th + rr - H;
+        c = cc - H;
+      } else {
+        const int i2 = idx - top;
+        const int rr = i2 / (2 * H), s2 = i2 - rr * (2 * H);
+        r = rr;
+        c = s2 < H ? s2 - H : tw + s2 - H;
+      }
+      const int64_t g = gidx(r, c);
+      const T vy = srcy ? xload(&srcy[g]) : T(0), vk = xload(&srck[g]);
+      const int o = (r + H) * P + (c + H);
+      if (srcy) sY[o] = vy;
+      sK[o] = vk;
+    }
   };
 
   // ---- k1 = f(t0, y0) on the tile; its halo through the exchange
@@ -317,14 +387,20 @@ __global__ __launch_bounds__(PDEOPT_COOP_THREADS) void tsit5_coop_kernel(const C
     region(0, [&](int o, int r, int c) {
       const T k = kcell(sY, o, twa, twb, tsrc);
       sK[o] = k;
-      xk0[(int64_t)(i0 + r) * ny + (j0 + c)] = k;
+      xstore(&xk0[(int64_t)(i0 + r) * ny + (j0 + c)], k);
     });
   }
-  if (!coop_env_barrier(bar, a.abort_flag, nwg, &gen)) return;
-  load_ring(sK, a.xk[0] + xoff, H);
+  if (!coop_env_barrier(bar, a.abort_flag, nwg, &gen, one_xcd)) return;
+  load_rings(nullptr, a.xk[0] + xoff);
   int cur = 0;  // exchange buffer parity of the accepted state
   __syncthreads();
 
+#ifdef PDEOPT_COOP_PROF  // TIMING ONLY (tools/mkvariant.sh): shader-clock ticks per phase, printed by the first workgroup at exit
+  unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pt = __builtin_amdgcn_s_memtime();
+#define PDEOPT_COOP_TICK(i) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); prof[i] += n_ - pt; pt = n_; } while (0)
+#else
+#define PDEOPT_COOP_TICK(i) do { } while (0)
+#endif
   const T rtol = T(a.pid.rtol), atol = T(a.pid.atol);
   const double inv_cells = 1.0 / ((double)nx * (double)ny);
   double t = a.t0, dt = a.dt0, prev_inv = 1.0, prev_prev_inv = 1.0;
@@ -336,7 +412,9 @@ __global__ __launch_bounds__(PDEOPT_COOP_THREADS) void tsit5_coop_kernel(const C
       status = PDEOPT_TSIT5_MAX_STEPS;
       break;
     }
-    const double h = fmin(dt, a.t1 - t);
+    // (the controller's state is the same in every lane: kept in scalar registers -- readfirstlane -- so that the step
+    // loop's doubles do not occupy vector registers across the stages)
+    const double h = uniform_f(fmin(dt, a.t1 - t));
     if (!(h > 0.0) || t + h == t) {
       status = PDEOPT_TSIT5_STALLED;
       break;
@@ -348,6 +426,7 @@ __global__ __launch_bounds__(PDEOPT_COOP_THREADS) void tsit5_coop_kernel(const C
     }
     put_time_terms(t + kTsC[0] * h);
     __syncthreads();
+    PDEOPT_COOP_TICK(0);
     // stages 2 .. 6 (slope index s = 1 .. 5): k on T + R (6 - s), with it the next stage's input there.  One instantiation
     // per stage: the weights stay in registers (a run-time stage index would index them dynamically -> scratch)
     auto stage = [&](auto s_c) {
@@ -380,6 +459,7 @@ __global__ __launch_bounds__(PDEOPT_COOP_THREADS) void tsit5_coop_kernel(const C
     stage(std::integral_constant<int, 3>{});
     stage(std::integral_constant<int, 4>{});
     stage(std::integral_constant<int, 5>{});
+    PDEOPT_COOP_TICK(1);
     // stage 7 on the tile: k7 = f(y1), the scaled error, the speculative exchange write
     double part = 0.0;
     {
@@ -403,34 +483,48 @@ __global__ __launch_bounds__(PDEOPT_COOP_THREADS) void tsit5_coop_kernel(const C
         const double qv = (double)(ev / sc);
         part += qv * qv;
         const int64_t g = (int64_t)(i0 + r) * ny + (j0 + c);
-        xyn[g] = y1;
-        xkn[g] = k7;
+        xstore(&xyn[g], y1);
+        xstore(&xkn[g], k7);
       });
     }
 #pragma unroll
     for (int sft = 32; sft > 0; sft >>= 1) part += __shfl_down(part, sft, 64);
     if ((tid & 63) == 0) red[tid >> 6] = part;
     __syncthreads();
+    PDEOPT_COOP_TICK(2);
     double* const parts = a.part + ((size_t)(step & 1u) * a.nenv + be) * nwg;
     if (tid == 0) {
       double sum = 0.0;
       for (int i = 0; i < NT / 64; ++i) sum += red[i];
-      parts[w] = sum;
+      xstore(&parts[w], sum);
     }
-    if (!coop_env_barrier(bar, a.abort_flag, nwg, &gen)) return;
-    double sum = 0.0;
-    {
-      const volatile double* const pv = parts;  // (behind the acquire fence of the barrier)
-      for (int i = 0; i < nwg; ++i) sum += pv[i];  // one order for every workgroup: the same double everywhere
-    }
+    if (!coop_env_barrier(bar, a.abort_flag, nwg, &gen, one_xcd)) return;
+    PDEOPT_COOP_TICK(3);
     ++step;
-    const double err = sqrt(sum * inv_cells);  // diffrax rms_norm
-
-    const bool keep = err < 1.0;  // a NaN norm rejects
-    const double inv = (err > 0.0 && err < __builtin_inf()) ? 1.0 / err : (err == 0.0 ? __builtin_inf() : 0.0);
-    double f = pid_term(inv, a.pid.k1, a.pid) * pid_term(prev_inv, a.pid.k2, a.pid) * pid_term(prev_prev_inv, a.pid.k3, a.pid);
-    f = fmin(a.pid.factormax, fmax(a.pid.factormin, a.pid.safety * f));
-    if (!keep) f = fmin(1.0, f);
+    // The controller: ONE lane per workgroup (the same arithmetic on the same partial sums in the same order in every
+    // workgroup: one decision for the environment), broadcast through LDS -- all waves running the double-precision
+    // pow / sqrt / divisions redundantly cost 6 us per step (14 k ticks), a lone lane ~1
+    if (tid < 64) {  // wave 0: the partners' partial sums, one lane each (the loads overlap), staged in LDS
+      for (int i = tid; i < nwg; i += 64) red[24 + i] = xload(&parts[i]);
+    }
+    if (tid == 0) {
+      double sum = 0.0;
+      for (int i = 0; i < nwg; ++i) sum += red[24 + i];  // one order in every workgroup: the same double everywhere
+      const double err = sqrt(sum * inv_cells);  // diffrax rms_norm
+      const bool keep_ = err < 1.0;              // a NaN norm rejects
+      const double inv_ = (err > 0.0 && err < __builtin_inf()) ? 1.0 / err : (err == 0.0 ? __builtin_inf() : 0.0);
+      double f_ = pid_term(inv_, a.pid.k1, a.pid) * pid_term(prev_inv, a.pid.k2, a.pid) * pid_term(prev_prev_inv, a.pid.k3, a.pid);
+      f_ = fmin(a.pid.factormax, fmax(a.pid.factormin, a.pid.safety * f_));
+      if (!keep_) f_ = fmin(1.0, f_);
+      red[19] = keep_ ? 1.0 : 0.0;
+      red[20] = inv_;
+      red[21] = f_;
+    }
+    __syncthreads();
+    const bool keep = red[19] != 0.0;
+    const double inv = red[20];
+    const double f = red[21];
+    PDEOPT_COOP_TICK(4);
     if (keep) {
       ++accepted;
       const double t_new = t + h;
@@ -458,17 +552,23 @@ __global__ __launch_bounds__(PDEOPT_COOP_THREADS) void tsit5_coop_kernel(const C
         sK[o] = sV[o];
       });
       cur ^= 1;
-      load_ring(sY, a.xy[cur] + xoff, H);
-      load_ring(sK, a.xk[cur] + xoff, H);
-      t = t_new < a.t1 - 1e-14 * fmax(1.0, fabs(a.t1)) ? t_new : a.t1;
+      load_rings(a.xy[cur] + xoff, a.xk[cur] + xoff);
+      t = uniform_f(t_new < a.t1 - 1e-14 * fmax(1.0, fabs(a.t1)) ? t_new : a.t1);
       prev_prev_inv = prev_inv;
-      prev_inv = inv;
+      prev_inv = uniform_f(inv);
     } else {
       ++rejected;
     }
-    dt = fmin(a.pid.dtmax, fmax(a.pid.dtmin, h * f));
+    dt = uniform_f(fmin(a.pid.dtmax, fmax(a.pid.dtmin, h * f)));
     __syncthreads();  // sY / sK complete before the next step's stage-2 input reads them
+    PDEOPT_COOP_TICK(5);
   }
+#ifdef PDEOPT_COOP_PROF
+  if (blockIdx.x == 0 && tid == 0)
+    printf("coop prof (ticks/step over %lld steps): w2 %llu | stages2-6 %llu | stage7+reduce %llu | env barrier %llu | controller %llu | accept+ring %llu\n",
+           (long long)(accepted + rejected), prof[0] / (accepted + rejected), prof[1] / (accepted + rejected), prof[2] / (accepted + rejected),
+           prof[3] / (accepted + rejected), prof[4] / (accepted + rejected), prof[5] / (accepted + rejected));
+#endif
   region(0, [&](int o, int r, int c) { yg[(int64_t)(i0 + r) * ny + (j0 + c)] = sY[o]; });
   if (w == 0 && tid == 0) {
     pdeopt_tsit5_stats st;
@@ -496,9 +596,13 @@ inline int coop_radius(int equation) {
   return (equation == PDEOPT_EQ_CAHN_HILLIARD || equation == PDEOPT_EQ_CAHN_HILLIARD_SBM) ? 2 : 1;
 }
 
-// the tile grid: tiles of about 28 cells where that fits the LDS, smaller otherwise; at most `max_wg` workgroups
+// The tile grid.  Among the px x py splits whose arrays fit the LDS, the one with the least arithmetic per workgroup (the
+// sum over the stages of the largest tile's region sizes) -- first among those with at most one XCD's worth of
+// workgroups (the exchange then stays in one L2 and the barrier needs no cache maintenance: 2 us against 15 us per step,
+// profiles/r04_coop_adaptive.txt), only then among larger grids (fp64 with many static fields: small tiles).
+// Measured on the 100^2 smoothed-boundary solve: 4 x 4 tiles 23 us per trial step, 5 x 5 19.5, 7 x 7 (two XCDs) 39.
 template <typename T>
-bool coop_plan(const pdeopt_problem& p, int max_wg, CoopPlan* out) {
+bool coop_plan(const pdeopt_problem& p, int num_cus, CoopPlan* out) {
   const int eq = p.equation;
   const int R = coop_radius(eq), H = 6 * R;
   const bool sbm = eq == PDEOPT_EQ_ALLEN_CAHN_SBM || eq == PDEOPT_EQ_CAHN_HILLIARD_SBM;
@@ -512,18 +616,38 @@ bool coop_plan(const pdeopt_problem& p, int max_wg, CoopPlan* out) {
     if (pitch % 2 == 0) ++pitch;  // odd pitch: vertically adjacent cells on different banks
     const size_t field = (size_t)rows * pitch * sizeof(T);
     const size_t arrays = (nf * field + 15) / 16 * 16;
-    const size_t lds = arrays + 24 * sizeof(double);
+    const size_t lds = arrays + (24 + 256) * sizeof(double);  // wave partials, time terms, controller broadcast, partial-sum staging
     if (lds > kCoopLdsMax) return false;
     pl->px = px; pl->py = py; pl->rows = rows; pl->pitch = pitch; pl->nfields = nf; pl->halo = H; pl->lds = lds; pl->red_off = (int)arrays;
     return true;
   };
-  // start from ~28-cell tiles (R = 2) / ~24 (R = 1) and split the longer side until the arrays fit
-  const int target = R == 2 ? 28 : 24;
-  int px = std::max(1, (p.nx + target - 1) / target), py = std::max(1, (p.ny + target - 1) / target);
-  for (int it = 0; it < 64; ++it) {
-    if (px > p.nx || py > p.ny || px * py > max_wg) return false;
-    if (fits(px, py, out)) return true;
-    if ((p.nx + px - 1) / px >= (p.ny + py - 1) / py) ++px; else ++py;
+  auto work = [&](int px, int py) {
+    const int tx = (p.nx + px - 1) / px, ty = (p.ny + py - 1) / py;
+    int64_t wk = 0;
+    for (int s = 1; s <= 6; ++s) wk += (int64_t)(tx + 2 * R * (6 - s) + (R == 2 ? 1 : 0)) * (ty + 2 * R * (6 - s) + (R == 2 ? 1 : 0));
+    return wk + 150 * (int64_t)px * py / 8;  // + a little for every partner the barrier waits for
+  };
+  int forced = 0;
+  if (const char* ev = getenv("PDEOPT_COOP_TILE")) {  // tuning knob (tools/adaptive_coop_bench.py): tile edge in cells
+    const int v = atoi(ev);
+    if (v >= 4 && v <= 128) forced = v;
+  }
+  if (forced) return fits(std::max(1, (p.nx + forced - 1) / forced), std::max(1, (p.ny + forced - 1) / forced), out) && out->px * out->py <= num_cus;
+  const int per_xcd = std::max(1, num_cus / 8);
+  for (const int cap : {per_xcd, num_cus}) {
+    int64_t best = -1;
+    for (int px = 1; px <= std::min(p.nx / 4, cap); ++px)
+      for (int py = 1; py <= std::min(p.ny / 4, cap / px); ++py) {
+        CoopPlan pl;
+        if (!fits(px, py, &pl)) continue;
+        // beyond one XCD the barrier (L2 write-back + invalidate per partner set) outweighs the arithmetic: fewest workgroups first
+        const int64_t wk = cap == per_xcd ? work(px, py) : (int64_t)px * py * 1000000 + work(px, py);
+        if (best < 0 || wk < best) {
+          best = wk;
+          *out = pl;
+        }
+      }
+    if (best >= 0) return true;
   }
   return false;
 }
@@ -590,7 +714,14 @@ int coop_tsit5_solve(pdeopt_ctx* ctx, double t0, double t1, double dt0, const pd
   s.save_stride = (int64_t)batch * cells;
   s.rows = pl.rows; s.pitch = pl.pitch; s.red_off = pl.red_off;
   if (sbm) {
-    if (ctx->time_poly_valid) {
+    const bool poly_const = ctx->time_poly_valid && ctx->time_theta[1] == 0.0 && ctx->time_theta[2] == 0.0 && ctx->time_theta[3] == 0.0 &&
+                            ctx->time_flux[1] == 0.0 && ctx->time_flux[2] == 0.0 && ctx->time_flux[3] == 0.0;
+    if (poly_const) {  // theta, flux constant (the notebook's first solve): the cosines once, here
+      s.tmode = 0;
+      s.tw[0] = cos(ctx->time_theta[0]);
+      s.tw[1] = eq == PDEOPT_EQ_ALLEN_CAHN_SBM ? 0.0 : cos(3.14159265358979323846 - ctx->time_theta[0]);
+      s.tw[2] = ctx->time_flux[0];
+    } else if (ctx->time_poly_valid) {
       s.tmode = 1;
       for (int i = 0; i < 4; ++i) { s.theta[i] = ctx->time_theta[i]; s.flux[i] = ctx->time_flux[i]; }
     } else {

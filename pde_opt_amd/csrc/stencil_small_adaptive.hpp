@@ -219,6 +219,10 @@ __global__ __launch_bounds__(NTMAX) void small_tsit5_kernel(const SmallTsit5Args
         }
         ++qi;
       }
+      // (state in LDS: a thread that redoes the last vector -- every thread, when the vector count is 3 x 512 -- must not
+      // overwrite that vector's y with y1 while another wave still reads y for the dense output above: round 4, found
+      // by the 64 x 96 shape as wrong SAVED values in the last four cells)
+      if constexpr (Y_LDS) __syncthreads();
 #pragma unroll
       for (int j = 0; j < KMAX; ++j) {
         const Vec y1 = *reinterpret_cast<const Vec*>(tile.sU + tile.oc[j]);

@@ -80,7 +80,7 @@ class _SmoothedBoundary(BaseEquation):
         # chooses its stage times on the device and evaluates them there
         from ..closures import poly_in_t
 
-        th, fl = poly_in_t(self.theta), poly_in_t(self.flux)
+        th, fl = poly_in_t(self.theta), poly_in_t(getattr(self, "flux", 0.0))  # (Allen-Cahn has no boundary flux)
         if th is not None and fl is not None:
             engine.set_time_terms(self._time_terms, theta_poly=th, flux_poly=fl)
         else:

@@ -51,6 +51,7 @@ def test_in_kernel_solve_vs_oracle_driven_loop(shape, dtype, kind):
     ts = [0.0, 0.11 * t1, 0.5 * t1, 0.52 * t1, t1]
     ctl = P.PIDController(rtol=1e-4, atol=1e-6) if dtype is np.float32 else P.PIDController(rtol=1e-6, atol=1e-9, pcoeff=0.3, icoeff=0.4)
     eng = P.HipEngine()
+    eng.set_small_persist(1)  # THIS kernel (auto hands grids of three or more vectors per thread to the multi-workgroup one)
     got = P.diffeqsolve(eq, P.Tsit5(), 0.0, t1, dt0, y0, saveat=P.SaveAt(t0=True, ts=ts, t1=True), stepsize_controller=ctl, engine=eng)
     eng.close()
     assert got.stats["kernel"].startswith("small_tsit5"), got.stats["kernel"]
@@ -83,7 +84,7 @@ def test_in_kernel_solve_vs_host_driven_loop_on_the_gpu(dtype, kind, shape):
     ts = np.linspace(0.0, t1, 9)
     ctl = P.PIDController(rtol=1e-4, atol=1e-6)
     out = []
-    for opt in (0, -1):
+    for opt in (1, -1):  # the single-workgroup kernel wherever it runs; the host-driven loop
         eng = P.HipEngine()
         eng.set_small_persist(opt)
         out.append(P.diffeqsolve(eq, P.Tsit5(), 0.0, t1, dt0, y0, saveat=P.SaveAt(ts=ts), stepsize_controller=ctl, engine=eng))
@@ -150,6 +151,7 @@ def test_step_budget():
     ts = list(np.linspace(0.0, t1, 6))
     ctl = P.PIDController(rtol=1e-6, atol=1e-9)
     eng = P.HipEngine()
+    eng.set_small_persist(1)
     with pytest.raises(RuntimeError, match="max_steps=7"):
         P.diffeqsolve(eq, P.Tsit5(), 0.0, t1, dt0, y0, saveat=P.SaveAt(ts=ts), stepsize_controller=ctl, max_steps=7, engine=eng)
     got = P.diffeqsolve(eq, P.Tsit5(), 0.0, t1, dt0, y0, saveat=P.SaveAt(ts=ts, t1=True), stepsize_controller=ctl, max_steps=7,
@@ -209,12 +211,19 @@ def test_c_abi_argument_checks_and_unsupported_problems():
     assert stats[0]["status"] == 0 and stats[0]["t"] == t1 and stats[0]["saved"] == 2
     np.testing.assert_allclose(saves[1, 0], eng.get_state()[0], rtol=0, atol=1e-6)  # theta = 1: b_i(1) are the 5th-order weights
     eng.close()
-    # 128^2 in fp32 is 4096 vectors; Fourier derivatives and the generic closure class have no LDS-resident kernel
+    # 128^2 in fp32 is 4096 vectors: beyond one workgroup, taken by the multi-workgroup kernel since round 4
+    # (stencil_coop_adaptive.hpp); Fourier derivatives have no in-kernel adaptive solve
     eng = P.HipEngine()
     dom = std_domain(P, 128, 128)
     big = P.AllenCahn2DPeriodic(dom, 0.002, MU["cubic"], MOB["one"])
     eng.configure(dtype=np.float32, batch=1, **big._engine_problem())
+    assert eng.tsit5_solve_small_supported()
+    eng.set_small_persist(-1)  # ... unless the caller rules the whole-solve kernels out
     assert not eng.tsit5_solve_small_supported()
-    with pytest.raises(ValueError, match="LDS-resident"):
+    eng.set_small_persist(0)
+    fourier = P.AllenCahn2DPeriodic(dom, 0.002, MU["cubic"], MOB["one"], derivs="fourier")
+    eng.configure(dtype=np.float32, batch=1, **fourier._engine_problem())
+    assert not eng.tsit5_solve_small_supported()
+    with pytest.raises(ValueError, match="in-kernel adaptive solve"):
         eng.tsit5_solve_small(0.0, t1, dt0, ctl, 100)
     eng.close()

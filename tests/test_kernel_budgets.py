@@ -29,11 +29,13 @@ def _pick(res, prefix):
 # Six slopes of four vectors are 96 registers before the stencil's own ~100; with the state, k7 and the stage input
 # moved to LDS what is left over the 256 of a 512-thread workgroup is <= 42 dwords of rarely touched controller
 # state.  The alternatives measured worse on paper: 256 threads x 8 vectors runs one wave per SIMD.
-# The multi-workgroup adaptive kernel (stencil_coop_adaptive.hpp): its fixed-closure instantiations carry at most the
-# 68-byte frame of the controller's pow() call (no scratch instruction in the step loop); the run-time closure walk
-# (Legendre recurrences in a loop, fp64) is the rare path and may spill.
-SCRATCH_ALLOWED = [("small_tsit5_kernel<", ", 4, 512>", 192), ("tsit5_coop_kernel<", ", true>", 96),
-                   ("tsit5_coop_kernel<float, ", ", false>", 96), ("tsit5_coop_kernel<double, ", ", false>", 1024)]
+# The multi-workgroup adaptive kernel (stencil_coop_adaptive.hpp; 512 threads, 256 registers each): the fp32 fixed-closure
+# instantiations -- the notebook workloads -- hold everything in registers; the fp64 smoothed-boundary forms spill a
+# little (five stage bodies with their hoisted constants in one kernel), the run-time closure walk (Legendre recurrences
+# in a loop, fp64) is the rare path and may spill more.
+SCRATCH_ALLOWED = [("small_tsit5_kernel<", ", 4, 512>", 192), ("tsit5_coop_kernel<float, ", ", true>", 0),
+                   ("tsit5_coop_kernel<float, ", ", false>", 96), ("tsit5_coop_kernel<double, ", ", true>", 256),
+                   ("tsit5_coop_kernel<double, ", ", false>", 1280)]
 
 
 def test_no_kernel_spills(res):
