@@ -79,7 +79,13 @@ typedef enum {
  *     f(c)  = s(c) [+ log(c / (1 - c)) if LOGIT_PRIOR] [+ c log c + (1-c) log(1-c) if MIX_ENTROPY]
  *             then  exp(.) if EXP_WRAP                                                        */
 #define PDEOPT_CLOSURE_MAX_COEF 16
-typedef enum { PDEOPT_CL_POLY = 0, PDEOPT_CL_LEGENDRE = 1 } pdeopt_closure_kind;
+typedef enum {
+  PDEOPT_CL_POLY = 0,
+  PDEOPT_CL_LEGENDRE = 1,
+  PDEOPT_CL_JIT = 2 /* a callable outside the family: its C function body was handed over with pdeopt_set_jit_closures and
+                       is compiled at run time (hiprtc) into the generic Cahn-Hilliard / Allen-Cahn stencil kernel; no
+                       coefficients (constants are part of the body).  2-D periodic / padded FD problems only. */
+} pdeopt_closure_kind;
 #define PDEOPT_CL_LOGIT_PRIOR 1
 #define PDEOPT_CL_EXP_WRAP 2
 #define PDEOPT_CL_MIX_ENTROPY 4  /* + c log c + (1 - c) log(1 - c): ideal mixing entropy of the regular-
@@ -255,6 +261,17 @@ int pdeopt_rhs(pdeopt_ctx* ctx, double t, void* host_out);
 /* n_substeps of size dt starting at local time t0:  the body of diffeqsolve's while-loop
  * under ConstantStepSize.  Asynchronous. */
 int pdeopt_advance(pdeopt_ctx* ctx, int integrator, double t0, double dt, int64_t n_substeps);
+/* Closures outside the in-kernel family (the reference accepts any pointwise callable: cahn_hilliard.py:51-54,
+ * allen_cahn.py:47-50, functions/legendre.py:56-74 prior_fn): mu_body / mob_body are C function BODIES -- one line of
+ * statements ending in `return <expression>;`, the argument is `c`, the scalar type is `T`, literals are written T(1.5),
+ * available: + - * / exp log tanh sqrt pow jit_powi(x, n) -- for the closures whose kind is PDEOPT_CL_JIT in the NEXT
+ * pdeopt_configure (NULL for a role that stays in the family).  The host mirror emits them from the traced sympy
+ * expression of the callable (a vetted node set, never user text).  Compiled once per distinct (bodies, dtype) on first
+ * use; a body that does not compile makes that call fail with the compiler's message. */
+int pdeopt_set_jit_closures(pdeopt_ctx* ctx, const char* mu_body, const char* mob_body);
+/* do these two bodies compile (hiprtc, for gfx950; no device is needed)?  0 = yes; the compiler's log (warnings, or the
+ * errors) is copied into log[0 .. log_cap).  What pdeopt_configure + the first launch would find out on the GPU box. */
+int pdeopt_jit_check(int dtype, const char* mu_body, const char* mob_body, char* log, int log_cap);
 /* Smoothed-boundary equations: fn is called on the calling thread, once per RHS evaluation, from
  * inside pdeopt_rhs / pdeopt_advance / pdeopt_tsit5_trial; fn == NULL uses constant[3] instead.  */
 int pdeopt_set_time_terms(pdeopt_ctx* ctx, pdeopt_time_fn fn, void* user, const double constant[3]);

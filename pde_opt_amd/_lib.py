@@ -26,7 +26,7 @@ EQ_ALLEN_CAHN_SBM, EQ_CAHN_HILLIARD_SBM = 4, 5
 EQ_CAHN_HILLIARD_3D = 6
 EQ_SHAPE_SMOOTH = 7  # Shape.smooth_shape (shapes.py:39-64)
 INT_EULER, INT_RK4, INT_IMEX, INT_STRANG, INT_TSIT5 = 0, 1, 2, 3, 4
-CL_POLY, CL_LEGENDRE = 0, 1
+CL_POLY, CL_LEGENDRE, CL_JIT = 0, 1, 2
 CL_LOGIT_PRIOR, CL_EXP_WRAP = 1, 2
 AUX_VX_FACE, AUX_VY_FACE, AUX_IMEX_SYMBOL, AUX_GPE_A_TERM, AUX_GPE_POTENTIAL = 0, 1, 2, 3, 4
 AUX_SBM_PSI, AUX_SBM_NORM_GRAD, AUX_SBM_MASK = 5, 6, 7
@@ -137,6 +137,8 @@ _SIGNATURES = {
     "pdeopt_rhs": (C.c_int, [_VP, C.c_double, _VP]),
     "pdeopt_advance": (C.c_int, [_VP, C.c_int, C.c_double, C.c_double, C.c_int64]),
     "pdeopt_set_integrator_params": (C.c_int, [_VP, C.c_double, C.c_double, C.c_double, C.c_double]),
+    "pdeopt_set_jit_closures": (C.c_int, [_VP, C.c_char_p, C.c_char_p]),
+    "pdeopt_jit_check": (C.c_int, [C.c_int, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int]),
     "pdeopt_set_time_terms": (C.c_int, [_VP, TIME_FN, _VP, C.POINTER(C.c_double)]),
     "pdeopt_set_time_table": (C.c_int, [_VP, C.c_int, _VP, _VP]),
     "pdeopt_set_time_terms_poly": (C.c_int, [_VP, C.c_int, _VP, C.c_int, _VP]),

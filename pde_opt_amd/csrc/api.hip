@@ -70,7 +70,12 @@ void free_fields(pdeopt_ctx* ctx) {
   ctx->configured = false;
 }
 
-int check_closure(pdeopt_ctx* ctx, const pdeopt_closure& c, const char* name) {
+int check_closure(pdeopt_ctx* ctx, const pdeopt_closure& c, const char* name, const std::string* jit_body = nullptr) {
+  if (c.kind == PDEOPT_CL_JIT) {  // compiled at run time from the body handed over by pdeopt_set_jit_closures
+    if (!jit_body || jit_body->empty())
+      return fail(ctx, PDEOPT_EINVAL, "closure %s has kind PDEOPT_CL_JIT but pdeopt_set_jit_closures gave no body for it", name);
+    return PDEOPT_OK;
+  }
   if (c.kind != PDEOPT_CL_POLY && c.kind != PDEOPT_CL_LEGENDRE)
     return fail(ctx, PDEOPT_EINVAL, "closure %s: unknown kind %d", name, c.kind);
   if (c.n < 1 || c.n > kMaxCoef)
@@ -339,9 +344,16 @@ int pdeopt_configure(pdeopt_ctx* ctx, const pdeopt_problem* pr) {
   }
   if (pr->equation == PDEOPT_EQ_CAHN_HILLIARD || pr->equation == PDEOPT_EQ_ALLEN_CAHN || sbm || is3d) {
     int rc;
-    if ((rc = check_closure(ctx, pr->mu, "mu"))) return rc;
-    if ((rc = check_closure(ctx, pr->mob, "mob"))) return rc;
+    const bool plain2d = pr->equation == PDEOPT_EQ_CAHN_HILLIARD || pr->equation == PDEOPT_EQ_ALLEN_CAHN;
+    if ((rc = check_closure(ctx, pr->mu, "mu", plain2d ? &ctx->jit_src[0] : nullptr))) return rc;
+    if ((rc = check_closure(ctx, pr->mob, "mob", plain2d ? &ctx->jit_src[1] : nullptr))) return rc;
     if (sbm && (rc = check_closure(ctx, pr->fe, "f"))) return rc;
+    if ((pr->mu.kind == PDEOPT_CL_JIT || pr->mob.kind == PDEOPT_CL_JIT) && pr->derivs != PDEOPT_DERIVS_FD)
+      return fail(ctx, PDEOPT_EINVAL, "run-time-compiled closures run the finite-difference kernels only (derivs = \"fd\")");
+    // a role that is NOT compiled at run time while the other is: its family member is evaluated by ... the same
+    // compiled kernel, which has no closure_generic: the host emits a body for both roles whenever one needs it
+    if ((pr->mu.kind == PDEOPT_CL_JIT) != (pr->mob.kind == PDEOPT_CL_JIT))
+      return fail(ctx, PDEOPT_EINVAL, "run-time-compiled closures: hand over bodies for mu AND the mobility (kind PDEOPT_CL_JIT for both)");
   }
   if (pr->equation == PDEOPT_EQ_SHAPE_SMOOTH && !(pr->gpe_k > 0))
     return fail(ctx, PDEOPT_EINVAL, "shape smoothing needs smooth_epsilon (gpe_k) > 0");
@@ -576,6 +588,21 @@ int pdeopt_rhs(pdeopt_ctx* ctx, double t, void* host_out) {
     PDEOPT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   }
   return PDEOPT_OK;
+}
+
+int pdeopt_set_jit_closures(pdeopt_ctx* ctx, const char* mu_body, const char* mob_body) {
+  if (!ctx) return PDEOPT_EINVAL;
+  for (const char* b : {mu_body, mob_body})
+    if (b && (strchr(b, '\n') || strlen(b) > 16000 || !strstr(b, "return")))
+      return fail(ctx, PDEOPT_EINVAL, "a closure body is one line of statements ending in `return ...;`");
+  ctx->jit_src[0] = mu_body ? mu_body : "";
+  ctx->jit_src[1] = mob_body ? mob_body : "";
+  return PDEOPT_OK;
+}
+
+int pdeopt_jit_check(int dtype, const char* mu_body, const char* mob_body, char* log, int log_cap) {
+  if (!mu_body || !mob_body || (dtype != PDEOPT_F32 && dtype != PDEOPT_F64)) return PDEOPT_EINVAL;
+  return pdeopt::jit_check(dtype, mu_body, mob_body, log, log_cap);
 }
 
 int pdeopt_set_time_terms(pdeopt_ctx* ctx, pdeopt_time_fn fn, void* user, const double constant[3]) {

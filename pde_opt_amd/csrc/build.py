@@ -24,7 +24,19 @@ ROOT = os.path.dirname(PKG)
 LIB = os.path.join(PKG, "libpdeopt_hip.so")
 OBJ_DIR = os.path.join(HERE, "build")
 
-SOURCES = ["api.hip", "stencil.hip", "reduce.hip", "spectral.hip", "halo.hip", "strang_fused.hip", "comm.hip"]
+SOURCES = ["api.hip", "stencil.hip", "reduce.hip", "spectral.hip", "halo.hip", "strang_fused.hip", "comm.hip", "jit.hip"]
+
+
+def _embed_jit_source() -> None:
+    """csrc/jit_device.hpp -- the device source hiprtc compiles at run time for closures outside the in-kernel family
+    (jit.hip) -- as a C++ raw string literal under build/, #included by jit.hip"""
+    src = open(os.path.join(HERE, "jit_device.hpp")).read()
+    assert ')PDEOPTJIT"' not in src
+    out = os.path.join(OBJ_DIR, "jit_device_source.inc")
+    text = 'R"PDEOPTJIT(' + src + ')PDEOPTJIT"\n'
+    if not os.path.exists(out) or open(out).read() != text:
+        with open(out, "w") as f:
+            f.write(text)
 
 
 def _headers() -> list[str]:
@@ -118,6 +130,7 @@ def kernel_resources(extra_flags: list[str] | None = None) -> dict:
     """{demangled kernel name: {vgpr, sgpr, scratch, occupancy, lds_static}} of the library as built with these
     flags (builds what is stale)"""
     os.makedirs(OBJ_DIR, exist_ok=True)
+    _embed_jit_source()
     extra = list(extra_flags or [])
     merged = {}
     for src in SOURCES:
@@ -131,9 +144,10 @@ def kernel_resources(extra_flags: list[str] | None = None) -> dict:
 
 def build(force: bool = False, verbose: bool = True, extra_flags: list[str] | None = None) -> str:
     os.makedirs(OBJ_DIR, exist_ok=True)
+    _embed_jit_source()
     extra = list(extra_flags or [])
     LAST_BUILD.update(compiled=[], reused=[], linked=False)
-    with ThreadPoolExecutor(max_workers=min(7, len(SOURCES))) as ex:
+    with ThreadPoolExecutor(max_workers=min(8, len(SOURCES))) as ex:
         objs = list(ex.map(lambda s: _compile(s, force, extra), SOURCES))
     # the link stamp records which objects (flag sets included) the library was made of
     stamp = os.path.join(OBJ_DIR, "link.stamp")

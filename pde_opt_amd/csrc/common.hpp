@@ -159,6 +159,7 @@ struct pdeopt_ctx {
   void* env_params_dev = nullptr;
   std::vector<char> env_params_host;
   pdeopt::AuxField aux[pdeopt::kNumAux];
+  std::string jit_src[2];  // pdeopt_set_jit_closures: C function bodies of mu / mobility (closure kind PDEOPT_CL_JIT)
   int64_t opt_kernel_path = 0;
   int64_t opt_tile_rows = 0;  // 0 auto, 16 or 32
   int64_t opt_group_envs = 0; // explicit integrators: envs per cache-resident group (0 auto, <0 whole batch)
@@ -311,6 +312,8 @@ int rhs_fourier(pdeopt_ctx* ctx, const void* in, void* out);
 int advance_strang(pdeopt_ctx* ctx, double t0, double dt, int64_t n);
 void spectral_destroy(pdeopt_ctx* ctx);
 void spectral_invalidate(pdeopt_ctx* ctx);
+// jit.hip: do these closure bodies compile (hiprtc, gfx950)?
+int jit_check(int dtype, const char* mu_body, const char* mob_body, char* log_out, int log_cap);
 // strang_fused.hip
 bool strang_fused_supported(const pdeopt_ctx* ctx);
 int advance_strang_fused(pdeopt_ctx* ctx, double t0, double dt, int64_t n);

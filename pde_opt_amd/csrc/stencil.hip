@@ -94,6 +94,7 @@ int launch_generic(pdeopt_ctx* ctx, const StageArgs<T>& s) {
   if (grid.y > 65535u || grid.z > 65535u)
     return fail(ctx, PDEOPT_EINVAL, "grid too large for the generic kernel (nx=%d batch=%d)", p.nx,
                 p.batch);
+  if (jit_closures_active(ctx)) return launch_jit_stage<T>(ctx, s);  // closures compiled at run time (jit.hip)
   if (p.equation == PDEOPT_EQ_CAHN_HILLIARD_3D) {
     // two passes: chemical potential into the work field, then the flux divergence + stage update
     const int nz = s.g.nz;

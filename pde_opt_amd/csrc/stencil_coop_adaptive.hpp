@@ -657,6 +657,7 @@ bool coop_tsit5_supported(const pdeopt_ctx* ctx) {
   const pdeopt_problem& p = ctx->prob;
   if (ctx->opt_small_persist < 0 || ctx->opt_kernel_path == 1 || ctx->opt_debug_ablate) return false;
   if (ctx->halo || p.nz > 1) return false;
+  if (p.mu.kind == PDEOPT_CL_JIT || p.mob.kind == PDEOPT_CL_JIT) return false;  // run-time-compiled closures live in the generic stage kernel
   const int eq = p.equation;
   const bool sbm = eq == PDEOPT_EQ_ALLEN_CAHN_SBM || eq == PDEOPT_EQ_CAHN_HILLIARD_SBM;
   if (eq != PDEOPT_EQ_CAHN_HILLIARD && eq != PDEOPT_EQ_ALLEN_CAHN && !sbm && eq != PDEOPT_EQ_ADVECTION_DIFFUSION) return false;

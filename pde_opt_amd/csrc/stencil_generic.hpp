@@ -393,4 +393,9 @@ __global__ __launch_bounds__(256) void ch3d_stage_kernel(const StageArgs<T> a) {
   stage_update<T>(a, base + c0, kk);
 }
 
+// jit.hip: closures compiled at run time (PDEOPT_CL_JIT; pdeopt_set_jit_closures)
+bool jit_closures_active(const pdeopt_ctx* ctx);
+template <typename T>
+int launch_jit_stage(pdeopt_ctx* ctx, const StageArgs<T>& s);
+
 }  // namespace pdeopt

@@ -313,6 +313,7 @@ bool tiled_supported(const pdeopt_ctx* ctx) {
   constexpr int V = VecOf<T>::V;
   const pdeopt_problem& p = ctx->prob;
   if (p.equation != PDEOPT_EQ_CAHN_HILLIARD && p.equation != PDEOPT_EQ_ALLEN_CAHN) return false;
+  if (p.mu.kind == PDEOPT_CL_JIT || p.mob.kind == PDEOPT_CL_JIT) return false;  // run-time-compiled closures: the generic kernel only (jit.hip)
   // 16-byte vectors need ny % V == 0.  Grids that the tiles do not divide run ragged tiles (periodic
   // layout only); degenerate extents (a single row / column, the 256 x 1 "1-D" runs) stay generic.
   if (p.ny % V != 0 || p.nx < 8 || p.ny < 4 * V) return false;

@@ -138,6 +138,15 @@ class HipEngine:
         p.nx, p.ny, p.batch = int(nx), int(ny), int(batch)
         p.hx, p.hy, p.kappa, p.gpe_k = float(hx), float(hy), float(kappa), float(gpe_k)
         p.mu, p.mob = _closure_struct(mu), _closure_struct(mob)
+        # a closure outside the in-kernel family (kind JIT): both roles travel as C function bodies and the generic
+        # stage kernel is compiled with them at run time (csrc/jit.hip)
+        if any(d is not None and d.kind == L.CL_JIT for d in (mu, mob)):
+            from .numerics.closures import jit_body_of
+
+            if mu is None or mob is None:
+                raise ValueError("run-time-compiled closures need both mu and the mobility")
+            p.mu.kind = p.mob.kind = L.CL_JIT
+            self._check(self._lib.pdeopt_set_jit_closures(self._h, jit_body_of(mu).encode(), jit_body_of(mob).encode()))
         old = self.problem
         if old is None or (old.equation, old.dtype, old.nx, old.ny, old.nz, old.batch) != (p.equation, p.dtype, p.nx, p.ny, p.nz, p.batch):
             self._aux_keys.clear()  # a new shape frees the library's auxiliary fields
@@ -158,6 +167,14 @@ class HipEngine:
 
     def set_env_params(self, env_first: int, kappa=None, mu_coef=None, mob_coef=None):
         """Per-environment control parameters (kappa and closure coefficient VALUES)."""
+        if self.problem is not None and L.CL_JIT in (self.problem.mu.kind, self.problem.mob.kind):
+            # run-time-compiled closures carry their constants in the compiled body: no per-environment coefficients
+            for arr in (mu_coef, mob_coef):
+                if arr is not None:
+                    a = np.atleast_2d(np.asarray(arr, dtype=np.float64))
+                    if np.any(a != a[0]):
+                        raise ValueError("closures compiled at run time (outside the in-kernel family) cannot differ between the "
+                                         "environments of one batch: per-environment closure coefficients need a family member")
         count = None
         bufs = []
         for arr, width in ((kappa, None), (mu_coef, L.MAX_COEF), (mob_coef, L.MAX_COEF)):

@@ -20,7 +20,7 @@ from typing import Callable, Sequence
 
 import numpy as np
 
-POLY, LEGENDRE = 0, 1
+POLY, LEGENDRE, JIT = 0, 1, 2
 LOGIT_PRIOR, EXP_WRAP, MIX_ENTROPY = 1, 2, 4
 MAX_COEF = 16
 
@@ -36,6 +36,10 @@ class ClosureDesc:
     kind: int = POLY
     flags: int = 0
     coef: tuple = (0.0,)
+    # kind == JIT (a callable outside the family, compiled at run time: csrc/jit.hip): the C function body emitted from
+    # the traced expression, and a host evaluator of the same expression
+    source: str = ""
+    host_fn: object = dataclasses.field(default=None, compare=False, repr=False)
 
     def __post_init__(self):
         if not 1 <= len(self.coef) <= MAX_COEF:
@@ -45,6 +49,8 @@ class ClosureDesc:
 
     def __call__(self, c):
         c = np.asarray(c)
+        if self.kind == JIT:
+            return self.host_fn(c)
         if self.kind == POLY:
             r = np.zeros_like(c) + self.coef[-1]
             for a in self.coef[-2::-1]:
@@ -127,7 +133,7 @@ class _Sym:
             "square": lambda x: x**2, "sqrt": lambda x: sp.sqrt(x), "positive": lambda x: x,
             "add": lambda x, y: x + y, "subtract": lambda x, y: x - y, "multiply": lambda x, y: x * y,
             "divide": lambda x, y: x / y, "true_divide": lambda x, y: x / y, "power": lambda x, y: x**y,
-            "reciprocal": lambda x: 1 / x,
+            "reciprocal": lambda x: 1 / x, "tanh": lambda x: sp.tanh(x),
         }
         if name not in table:
             raise UnsupportedClosureError(f"numpy.{name} is outside the supported closure family")
@@ -177,11 +183,86 @@ def _match(expr, c):
                     f"polynomial degree {len(coef) - 1} exceeds the in-kernel limit {MAX_COEF - 1}"
                 )
             return ClosureDesc(POLY, flags | candidate_flags, tuple(coef))
+    # outside the family: a pointwise expression of a vetted node set is compiled at run time (csrc/jit.hip)
+    return jit_closure(sp.sympify(expr), c)
+
+
+# ----------------------------------------------------------------------------------------------
+# closures outside the family: C function bodies for run-time compilation (csrc/jit.hip, jit_device.hpp)
+# ----------------------------------------------------------------------------------------------
+def _emit_c(e, c) -> str:
+    """C expression (scalar type T, argument c) of a sympy expression built from + * pow exp log tanh sqrt and
+    rational constants -- every node is checked; anything else raises (the kernel source is never user text)"""
+    import sympy as sp
+
+    if e == c:
+        return "c"
+    if e.is_Number:
+        v = float(e)
+        if not np.isfinite(v):
+            raise UnsupportedClosureError(f"non-finite constant {e} in a closure")
+        return f"T({v!r})"
+    if isinstance(e, sp.Add):
+        return "(" + " + ".join(_emit_c(a, c) for a in e.args) + ")"
+    if isinstance(e, sp.Mul):
+        return "(" + " * ".join(_emit_c(a, c) for a in e.args) + ")"
+    if isinstance(e, sp.Pow):
+        base, ex = e.args
+        b = _emit_c(base, c)
+        if ex.is_Integer:
+            n = int(ex)
+            if 1 <= n <= 16:
+                return f"jit_powi({b}, {n})"
+            if -16 <= n <= -1:
+                return f"(T(1) / jit_powi({b}, {-n}))"
+        if ex == sp.Rational(1, 2):
+            return f"sqrt({b})"
+        if ex == sp.Rational(-1, 2):
+            return f"(T(1) / sqrt({b}))"
+        return f"pow({b}, {_emit_c(ex, c)})"
+    for fn, name in ((sp.exp, "exp"), (sp.log, "log"), (sp.tanh, "tanh")):
+        if isinstance(e, fn):
+            return f"{name}({_emit_c(e.args[0], c)})"
     raise UnsupportedClosureError(
-        "closure is outside the in-kernel family  f(c) = poly(c) [+ log(c/(1-c))] [exp]  /  "
-        f"Legendre series; traced expression: {expr}.  Pass a ClosureDesc, a Legendre closure "
-        "object, or restructure the callable (non-pointwise closures such as CNNs are out of scope)."
-    )
+        f"closure is outside the in-kernel family and uses {type(e).__name__}, which the run-time compiler does not take "
+        "(+, *, powers, exp, log, tanh, sqrt, constants); non-pointwise closures such as CNNs are out of scope")
+
+
+def jit_closure(expr, c, prelude: str = "") -> ClosureDesc:
+    """``ClosureDesc(kind=JIT)`` of a traced pointwise expression: the body ``[prelude] return <expr>;`` for the run-time
+    compiler and a numpy evaluator for host-side use (oracle comparisons, ``ClosureDesc.__call__``)"""
+    import sympy as sp
+
+    if expr.free_symbols - {c}:
+        raise UnsupportedClosureError(f"closure depends on {expr.free_symbols - {c}}, not on the field alone")
+    body = prelude + "return " + _emit_c(expr, c) + ";"
+    if "\n" in body or len(body) > 16000:
+        raise UnsupportedClosureError("closure expression too large for the run-time compiler")
+    return ClosureDesc(JIT, 0, (0.0,), source=body, host_fn=sp.lambdify(c, expr, "numpy"))
+
+
+def jit_body_of(desc: ClosureDesc) -> str:
+    """C function body of ANY closure: a JIT closure's own, or the family member spelled out (when one role of a
+    problem is compiled at run time the kernel is, and it has no table-driven evaluator: both roles get a body)"""
+    if desc.kind == JIT:
+        return desc.source
+    co = [repr(float(v)) for v in desc.coef]
+    if desc.kind == POLY:
+        s = f"T r = T({co[-1]});" + "".join(f" r = r * c + T({a});" for a in co[-2::-1])
+    else:  # the forward three-term recurrence of closures.hpp: series_generic
+        s = f"const T x = T(2) * c - T(1); T r = T({co[0]});"
+        if len(co) > 1:
+            s += f" r += T({co[1]}) * x;"
+        s += " T pm = T(1), pc = x;"
+        for k in range(2, len(co)):
+            s += f" {{ const T pn = (T({2 * k - 1}) * x * pc - T({k - 1}) * pm) / T({k}); r += T({co[k]}) * pn; pm = pc; pc = pn; }}"
+    if desc.flags & LOGIT_PRIOR:
+        s += " r += log(c / (T(1) - c));"
+    if desc.flags & MIX_ENTROPY:
+        s += " r += c * log(c) + (T(1) - c) * log(T(1) - c);"
+    if desc.flags & EXP_WRAP:
+        s += " r = exp(r);"
+    return s + " return r;"
 
 
 _trace_cache: dict = {}

@@ -70,16 +70,25 @@ class ChemicalPotentialLegendrePolynomials:
         from numpy.polynomial import legendre as Lg
         from numpy.polynomial import polynomial as Pn
 
-        from ..closures import POLY
+        from ..closures import JIT, POLY, jit_body_of
 
         params = np.array(self.expansion.params, dtype=np.float64)
         flags = 0
         if self.prior_fn is not None:
             prior = as_closure(self.prior_fn)
-            if prior.kind != POLY or (prior.flags & ~LOGIT_PRIOR):
-                raise UnsupportedClosureError(
-                    "a Legendre chemical potential can carry a polynomial prior, the logit prior log(c/(1-c)), or "
-                    "their sum in-kernel; this prior_fn is neither")
+            if prior.kind == JIT or prior.kind != POLY or (prior.flags & ~LOGIT_PRIOR):
+                # any other POINTWISE prior (tanh, exp, sqrt ...: legendre.py:56-74 takes any callable): the series by its
+                # three-term recurrence + the prior's traced expression, compiled at run time (csrc/jit.hip);
+                # non-pointwise callables (a CNN) fail in as_closure above
+                series = jit_body_of(ClosureDesc(LEGENDRE, 0, tuple(float(v) for v in params)))
+                assert series.endswith(" return r;")
+                pbody = jit_body_of(prior)
+                if not pbody.startswith("return "):  # a family prior spelled out as statements: wrap it
+                    raise UnsupportedClosureError("this prior_fn combines forms the kernels do not take together")
+                body = series[: -len(" return r;")] + " r += " + pbody[len("return "):-1] + "; return r;"
+                expansion, pfn = self.expansion, prior
+                return ClosureDesc(JIT, 0, (0.0,), source=body,
+                                   host_fn=lambda c: expansion(2.0 * np.asarray(c) - 1.0) + pfn(np.asarray(c)))
             flags = prior.flags & LOGIT_PRIOR
             a = np.asarray(prior.coef, dtype=np.float64)
             if np.any(a != 0.0):

@@ -516,7 +516,8 @@ class VectorPDEEnv:
             p = e._engine_problem()
             for name in ("mu", "mob"):
                 a, b = prob.get(name), p.get(name)
-                if (a is None) != (b is None) or (a is not None and (a.kind, a.flags, len(a.coef)) != (b.kind, b.flags, len(b.coef))):
+                if (a is None) != (b is None) or (a is not None and (a.kind, a.flags, len(a.coef), getattr(a, "source", "")) !=
+                                                  (b.kind, b.flags, len(b.coef), getattr(b, "source", ""))):
                     raise ValueError("all environments of a VectorPDEEnv must share the closure structure")
         if all(self._same(c, controls[0]) for c in controls[1:]):
             return

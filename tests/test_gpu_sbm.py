@@ -194,14 +194,17 @@ def test_time_terms_are_sampled_once_per_advance_not_per_stage():
     y0 = np.clip(0.5 + 0.1 * rng.standard_normal(psi.shape), 0.1, 0.9)
     eng = P.HipEngine()
     sol = P.diffeqsolve(eq, P.RK4(), 0.03, 0.03 + 50 * 2e-3, 2e-3, y0, engine=eng)
-    n_table = len(calls)
-    assert n_table <= 151  # 50 substeps x {t, t + dt/2, t + dt}, duplicates merged -- sampled before the launch loop
+    # (the upload also probes theta for being a polynomial in t -- closures.poly_in_t: a symbol and the times 0, 0.37, 1.9,
+    # outside this run's stage times -- for the in-kernel adaptive solve; not counted here)
+    stage_calls = lambda: [t for t in calls if isinstance(t, float) and 0.03 <= t <= 0.1301]  # noqa: E731
+    n_table = len(stage_calls())
+    assert 0 < n_table <= 151  # 50 substeps x {t, t + dt/2, t + dt}, duplicates merged -- sampled before the launch loop
     calls.clear()
     # the callback path (table cleared by hand): 4 calls per substep, same bits
     eng2 = P.HipEngine()
     eng2._upload_time_table = lambda *a, **k: None
     sol2 = P.diffeqsolve(eq, P.RK4(), 0.03, 0.03 + 50 * 2e-3, 2e-3, y0, engine=eng2)
-    assert len(calls) == 200
+    assert len(stage_calls()) == 200
     np.testing.assert_array_equal(sol.ys[-1], sol2.ys[-1])
     eng.close()
     eng2.close()

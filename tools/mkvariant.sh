@@ -11,7 +11,7 @@ C=$ROOT/pde_opt_amd/csrc
 hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-gpu-rdc -fno-slp-vectorize -Wno-unused-function -I/opt/rocm/include "$@" -c $C/$SRC.hip -o $ROOT/variants/${SRC}_$NAME.o
 TAG=$(cd $ROOT && python -c "from pde_opt_amd.csrc.build import _flags_tag; print(_flags_tag([]))")
 OBJS=""
-for o in api stencil reduce spectral halo strang_fused comm; do
+for o in api stencil reduce spectral halo strang_fused comm jit; do
   if [ $o = $SRC ]; then OBJS="$OBJS $ROOT/variants/${SRC}_$NAME.o"; else OBJS="$OBJS $C/build/$o.$TAG.o"; fi
 done
 hipcc -shared -fPIC --offload-arch=gfx950 -fno-gpu-rdc -o $ROOT/variants/lib_$NAME.so $OBJS -L/opt/rocm/lib -lrocfft -ldl -Wl,-rpath,/opt/rocm/lib
