@@ -143,9 +143,8 @@ class _NullEngine(OracleEngine):
 def test_step_prologue_does_not_grow_with_python_objects_per_environment():
     """256 environments x 8 shards with a scalar control (kappa): ONE equation is built per step and the per-environment
     values travel as an array (the serial prologue was 3.3 ms = 17 % of a 15.8 ms GPU step, i.e. at most
-    6.6x of 8 GPUs).  Structural gate: one equation construction per step, not 256.  Timing gate, relative so that a
-    loaded container does not decide it: a whole step with null engines costs less than constructing the 256 equations
-    the old prologue built (measured here: 0.56 ms against 2.4 ms; the target was <= 0.8 ms)."""
+    6.6x of 8 GPUs; target <= 0.8 ms, measured 0.56 ms in an idle container).  Gates that a loaded container cannot
+    flip: one equation construction per step, not 256, and the number of Python calls the calling thread makes."""
     import time
 
     dom = std_domain(P, 16, 16)
@@ -164,24 +163,29 @@ def test_step_prologue_does_not_grow_with_python_objects_per_environment():
     for _ in range(3):
         env.step(acts)
     built.clear()
-    best = np.inf
-    for _ in range(5):
-        t0 = time.perf_counter()
-        for _ in range(10):
-            env.step(acts)
-        best = min(best, (time.perf_counter() - t0) / 10)
-    assert len(built) == 50, len(built)  # one per step
+    # load-independent measure of the serial prologue: Python-level calls made by the CALLING thread per step (the
+    # shard threads' work runs beside it).  Round 3: ~10 700 per step at 256 environments (one dataclass construction,
+    # two closure traces and three _engine_problem() dicts per environment); now ~1 500, independent of the device count.
+    import cProfile
+    import pstats
+
+    pr = cProfile.Profile()
+    pr.enable()
+    for _ in range(10):
+        env.step(acts)
+    pr.disable()
+    calls_per_step = pstats.Stats(pr).total_calls / 10
+    assert len(built) == 10, len(built)  # one equation per step
+    assert calls_per_step < 3000, calls_per_step
     # what the environments were handed: per-environment kappas, different across the batch
     k = np.concatenate([sh.engine.kappa_env for sh in env._shards])
     assert len(set(np.round(k, 9))) > 1 and k.shape == (256,)
+    # wall time, for the record (printed with -s; 0.56 ms here when the container is otherwise idle, 5.3 ms in round 3)
+    t0 = time.perf_counter()
+    for _ in range(10):
+        env.step(acts)
+    print(f"VectorPDEEnv.step, 256 environments x 8 null engines: {1e2 * (time.perf_counter() - t0):.2f} ms per step")
     env.close()
-    old = np.inf
-    for _ in range(5):
-        t0 = time.perf_counter()
-        for b in range(256):
-            P.CahnHilliard2DPeriodic(dom, 0.002 + 1e-6 * b, kw["static_equation_parameters"]["mu"], kw["static_equation_parameters"]["D"])
-        old = min(old, time.perf_counter() - t0)
-    assert best < old, f"{1e3 * best:.2f} ms per step against {1e3 * old:.2f} ms for the 256 constructions alone"
 
 
 def test_scalar_control_batch_equals_per_environment_equations():

@@ -17,6 +17,7 @@ cp gpurun_out/busy_summary.txt profiles/${TAG}_pmc_busy.txt
 [ -f gpurun_out/valubench.txt ] && cp gpurun_out/valubench.txt profiles/${TAG}_valubench_raw.txt
 [ -f gpurun_out/lds_issue_bench.txt ] && cp gpurun_out/lds_issue_bench.txt profiles/${TAG}_lds_issue_bench.txt
 [ -f gpurun_out/adaptive_bench.txt ] && cp gpurun_out/adaptive_bench.txt profiles/${TAG}_adaptive_in_kernel.txt
+[ -f gpurun_out/adaptive_coop_bench.txt ] && grep -v "coop prof" gpurun_out/adaptive_coop_bench.txt > profiles/${TAG}_adaptive_multi_workgroup.txt
 [ -f gpurun_out/single_env_latency.txt ] && cp gpurun_out/single_env_latency.txt profiles/${TAG}_single_env_latency.txt
 bash tools/make_pmc_json.sh ${TAG}
 for f in stencil.hip strang_fused.hip; do python tools/kernel_resources.py $f > /tmp/kres_$f.txt; done
