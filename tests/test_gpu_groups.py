@@ -227,7 +227,7 @@ def _ch_ic(n, seed, dtype=np.float32):
 def test_config3_rk4_headline_batch_vs_c_oracle():
     """ch_rk4_1024_f32 exactly as bench.py runs it: 32 environments, auto grouping -> 4 groups of 8, two side by
     side on two streams (256 MiB resident), the whole-substep kernel on 32 x 128 tiles with the XCD-aware block map.  First / last
-    environment of each group against oracle/c_oracle.c (fp32 state to 5e-7 absolute, increment to 5e-4 relative)."""
+    environment of each group against oracle/c_oracle.c (fp32 state to 5e-7 absolute, increment to 5e-5 relative)."""
     n, batch, nsub, dt = 1024, 32, 4, 2e-7
     dom = std_domain(P, n, n)
     eq = P.CahnHilliard2DPeriodic(dom, 0.002, MU["regsol"], MOB["c1mc"])
@@ -240,7 +240,7 @@ def test_config3_rk4_headline_batch_vs_c_oracle():
         ref = CO.rk4(0, y0[b], hx, hy, 0.002, REGSOL_C, C1MC_C, dt, nsub, threads=8)
         assert np.max(np.abs(out[b] - ref)) < 5e-7, (b, np.max(np.abs(out[b] - ref)))
         inc, inc_ref = out[b].astype(np.float64) - y0[b], ref.astype(np.float64) - y0[b]
-        assert rel_l2(inc, inc_ref) < 5e-4, (b, rel_l2(inc, inc_ref))
+        assert rel_l2(inc, inc_ref) < 5e-5, (b, rel_l2(inc, inc_ref))
     # environments in between are not copies of their neighbours
     assert np.any(out[1] != out[0]) and np.any(out[17] != out[16])
 
@@ -297,7 +297,7 @@ def test_config3_imex_batch32_vs_oracle():
         for i in range(nsub):
             ref = O.imex_step(rhs, i * dt, ref, dt, 0.5, sym)
         inc, inc_ref = out[b].astype(np.float64) - y0[b], ref - y0[b]
-        assert rel_l2(inc, inc_ref) < 5e-4, (b, rel_l2(inc, inc_ref))
+        assert rel_l2(inc, inc_ref) < 5e-5, (b, rel_l2(inc, inc_ref))
         assert np.max(np.abs(out[b] - ref)) < 5e-7
 
 
