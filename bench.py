@@ -362,7 +362,7 @@ def run_decomp(args, P, world, rank, local_rank, dist, make_solver=None):
     code path without a second GPU.  A step = 100 substeps of the one field; strong scaling (the field is fixed).
     ``make_solver(eq, grid)``: test hook (tests/test_dist_cpu.py drives this function's control flow -- which rank
     runs which collective -- under gloo with an oracle-backed tile)."""
-    from pde_opt_amd.decomp import (CartesianGrid, DecomposedSolver, LocalGroupComm, NativeComm, TorchComm,
+    from pde_opt_amd.decomp import (CartesianGrid, DecomposedSolver, LocalGroupComm, NativeComm, PeerMappedComm, TorchComm,
                                     advance_group)
 
     n, dt, substeps = args.decomp_grid, 2e-7, args.decomp_substeps
@@ -390,7 +390,7 @@ def run_decomp(args, P, world, rank, local_rank, dist, make_solver=None):
         sols = [DecomposedSolver(eq, CartesianGrid(px, py, r), comm=comms[r], dtype=np.float32, device=local_rank, halo=halo)
                 for r in range(vranks)]
     else:
-        comm = None if dist is None else (NativeComm() if native else TorchComm())
+        comm = None if dist is None else (PeerMappedComm() if args.decomp_mode == "peer" else NativeComm() if native else TorchComm())
         sols = [DecomposedSolver(eq, CartesianGrid(px, py, rank), comm=comm, dtype=np.float32, device=local_rank, halo=halo)]
     for sol in sols:
         sol.use_overlap = args.decomp_mode in ("native-overlap", "overlap", "graph")
@@ -761,9 +761,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity-spot", action="store_true")
     ap.add_argument("--no-api", action="store_true", help="skip the VectorPDEEnv.step throughput leg")
-    ap.add_argument("--decomp-mode", default="auto", choices=["auto", "native", "native-overlap", "plain", "overlap", "graph"],
+    ap.add_argument("--decomp-mode", default="auto", choices=["auto", "native", "native-overlap", "peer", "plain", "overlap", "graph"],
                     help="ch_rk4_4096_decomp: driver path (auto = native: the library's own RCCL communicator, substep "
                          "loop in C; native-overlap: + collective on a second stream under the interior tiles; "
+                         "peer = no collective: neighbours' strips read in place through hipIpc-mapped buffers; "
                          "plain / overlap / graph = torch all-gather drivers)")
     ap.add_argument("--decomp-grid", type=int, default=4096, help="ch_rk4_4096_decomp: cells per side of the one field")
     ap.add_argument("--decomp-substeps", type=int, default=100, help="ch_rk4_4096_decomp: substeps per step")
@@ -849,9 +850,9 @@ def main():
     for _ in range(args.steps):
         env_step()
     dev_ms = eng.timer_stop()  # HIP events on the engine's stream (synchronises)
-    shader_hz = eng.timer_clock_hz()  # the clock the chip held between the two events
     barrier()
     elapsed = time.perf_counter() - t0
+    shader_hz = eng.timer_clock_hz()  # the clock the chip held between the two events (fetched outside the timed region)
     kernel_name = eng.last_kernel
     launches = eng.stage_launches() - launches0  # fused stencil(+update) launches in the timed region
 

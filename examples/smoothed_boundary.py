@@ -36,7 +36,7 @@ t_final = 2.0 if quick else 50.0
 solution = diffeqsolve(eq, Tsit5(), t0=0.0, t1=t_final, dt0=1e-3, y0=u0,
                        stepsize_controller=PIDController(rtol=1e-4, atol=1e-6),
                        saveat=SaveAt(ts=np.linspace(0.0, t_final, 20)), max_steps=1000000)
-print(solution.stats)
+print(solution.stats)  # kernel: tsit5_coop<...>: the whole adaptive solve in one launch, several workgroups per environment
 m0, m1 = np.sum(psi * solution.ys[0]), np.sum(psi * solution.ys[-1])
 print("psi-weighted mass at t0 / t1:", m0, m1)
 assert abs(m1 - m0) < 1e-5 * abs(m0)  # no boundary flux: the mass inside the shape is conserved

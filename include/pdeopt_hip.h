@@ -373,6 +373,17 @@ typedef struct pdeopt_local_group pdeopt_local_group;
 int pdeopt_local_group_create(int world, pdeopt_local_group** out);
 int pdeopt_local_group_destroy(pdeopt_local_group* group);
 int pdeopt_comm_init_local(pdeopt_ctx* ctx, pdeopt_local_group* group, int rank);
+/* The same loop with NO collective ("P2P stores into peer-mapped halo buffers"): one process per GPU as
+ * under RCCL; every rank allocates its two strip buffers + three counters once (pdeopt_comm_ipc_export, after the tile
+ * has been configured in the halo-8 layout: returns the 64-byte hipIpc handle of the block), the host language carries
+ * the handles between the processes (any transport), and pdeopt_comm_ipc_attach(all world x 64 bytes, rank-major) maps
+ * every other rank's block.  In pdeopt_rk4_decomposed_advance a rank's stencil kernel then reads its 8 neighbours'
+ * strips IN PLACE through the mapped pointers and writes its own next strip; two monotone counters per rank (published
+ * by a one-lane kernel behind the stencil kernel, polled by a wait kernel in front of it) order the exchanges.  A
+ * neighbour that does not publish within 2 s fails the call instead of hanging.  Processes sharing one GPU work too
+ * (that is how the test-suite runs it). */
+int pdeopt_comm_ipc_export(pdeopt_ctx* ctx, int world, int rank, void* handle64);
+int pdeopt_comm_ipc_attach(pdeopt_ctx* ctx, const void* handles /* [world][64] */);
 int pdeopt_rk4_decomposed_advance(pdeopt_ctx* ctx, double dt, int64_t n_substeps, const int* neighbours /* [8] */,
                                   int overlap);
 /* ctx whose work is ordered on a caller-owned HIP stream (e.g. torch's current stream, so RCCL

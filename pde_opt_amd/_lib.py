@@ -169,6 +169,8 @@ _SIGNATURES = {
     "pdeopt_local_group_create": (C.c_int, [C.c_int, C.POINTER(_VP)]),
     "pdeopt_local_group_destroy": (C.c_int, [_VP]),
     "pdeopt_comm_init_local": (C.c_int, [_VP, _VP, C.c_int]),
+    "pdeopt_comm_ipc_export": (C.c_int, [_VP, C.c_int, C.c_int, _VP]),
+    "pdeopt_comm_ipc_attach": (C.c_int, [_VP, _VP]),
     "pdeopt_rk4_decomposed_advance": (C.c_int, [_VP, C.c_double, C.c_int64, C.POINTER(C.c_int), C.c_int]),
     "pdeopt_ctx_create_on_stream": (C.c_int, [C.c_int, _VP, C.POINTER(_VP)]),
     "pdeopt_host_alloc": (C.c_int, [_VP, C.c_int64, C.POINTER(_VP)]),

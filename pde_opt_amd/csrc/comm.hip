@@ -97,6 +97,14 @@ struct CommState {
   pdeopt_local_group* group = nullptr;
   void* send2 = nullptr;                  // second send buffer (parity 1)
   uint64_t seq = 0;                       // exchanges done so far
+  // peer-mapped backend (pdeopt_comm_ipc_export / _attach): every rank's strip buffers are mapped into every process
+  // (hipIpc), a rank's fused-pack epilogue writes its own strip, its neighbours' fused unpack reads it in place; two
+  // monotone counters per rank order the exchanges, no collective
+  bool ipc = false;
+  void* ipc_block = nullptr;              // this rank: [strip parity 0][strip parity 1][flags: ready, consumed, error]
+  size_t ipc_strip_bytes = 0;
+  std::vector<void*> peer_block;          // every rank's block as mapped here (own: ipc_block)
+  unsigned* ipc_err_dev = nullptr;        // time-out flag of the wait kernel (in the own block)
   bool local() const { return group != nullptr; }
   void* send_buf() const { return local() && (seq & 1) ? send2 : send; }  // where the NEXT exchange's strip goes
 };
@@ -200,6 +208,11 @@ void comm_destroy(pdeopt_ctx* ctx) {
   CommState* c = ctx->comm;
   if (!c) return;
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  if (c->ipc) {
+    for (size_t r = 0; r < c->peer_block.size(); ++r)
+      if (c->peer_block[r] && c->peer_block[r] != c->ipc_block) (void)hipIpcCloseMemHandle(c->peer_block[r]);
+    if (c->ipc_block) (void)hipFree(c->ipc_block);
+  }
   if (c->cstream) (void)hipStreamSynchronize(c->cstream);
   if (c->comm) (void)c->comm_destroy(c->comm);
   if (c->group) {
@@ -309,12 +322,143 @@ void local_group_delete(pdeopt_local_group* g) {
   delete g;
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Peer-mapped exchange ("P2P stores into peer-mapped halo buffers").  One process per
+// GPU as under RCCL, but no collective in the substep: every rank allocates [strip 0][strip 1][flags] once, the host
+// language carries the 64-byte hipIpc handles between the processes (any transport: torch.distributed, a pipe), and
+// every rank maps every other rank's block.  Exchange e lives in strip parity e & 1:
+//     the kernel K_e of a rank reads strip e of its 8 neighbours IN PLACE (fused unpack through the mapped pointers) and
+//     writes its own strip e + 1 (fused pack); a one-lane kernel behind it publishes  consumed = e + 1, ready = e + 2;
+//     before K_e a wait kernel polls the neighbours' ready >= e + 1.
+// A neighbour's ready >= e + 1 also says it has finished reading this rank's strip e - 1 (the buffer strip e + 1 goes
+// into): it publishes both counters when the kernel that did both completes.  At the start of a call the first strip
+// comes from the pack kernel; before it the neighbours' consumed >= e0 - 1.  The wait kernel gives up after 2 s
+// (a neighbour that never arrives) and the call fails instead of hanging.
+namespace {
+constexpr size_t kIpcFlagBytes = 256;
+struct IpcWaitArgs {
+  const unsigned* flags[8];  // neighbours' flag words: [0] ready, [1] consumed
+  unsigned ready_min, consumed_min;
+  unsigned* err;
+};
+__global__ void ipc_wait_kernel(const IpcWaitArgs a) {
+  const int q = threadIdx.x;
+  if (q >= 8) return;
+  const unsigned long long t_in = __builtin_amdgcn_s_memrealtime();
+  const unsigned* f = a.flags[q];
+  while (__hip_atomic_load(&f[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < a.ready_min ||
+         __hip_atomic_load(&f[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < a.consumed_min) {
+    if (__builtin_amdgcn_s_memrealtime() - t_in > 200000000ull) {  // 2 s of the 100 MHz clock
+      __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      break;
+    }
+    __builtin_amdgcn_s_sleep(8);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");  // system scope: the strips behind the counters
+}
+__global__ void ipc_publish_kernel(unsigned* flags, unsigned ready, unsigned consumed) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");  // (the stream already ordered the stencil kernel before this one)
+  __hip_atomic_store(&flags[1], consumed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __hip_atomic_store(&flags[0], ready, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+}  // namespace
+
+int comm_ipc_export(pdeopt_ctx* ctx, int world, int rank, void* handle64) {
+  if (world < 1 || rank < 0 || rank >= world) return fail(ctx, PDEOPT_EINVAL, "rank %d outside a world of %d", rank, world);
+  if (ctx->halo != 8) return fail(ctx, PDEOPT_EINVAL, "the peer-mapped exchange runs the halo-8 layout (one exchange per substep, fused pack / unpack)");
+  if (!ctx->comm) ctx->comm = new CommState();
+  CommState& c = *ctx->comm;
+  if (c.comm || c.group || c.ipc) return fail(ctx, PDEOPT_ESTATE, "this ctx already has a communicator");
+  c.ipc_strip_bytes = halo_strip_elems(ctx) * ctx->esize;
+  const size_t strip_pad = (c.ipc_strip_bytes + 255) / 256 * 256;
+  PDEOPT_HIP_CHECK(ctx, hipMalloc(&c.ipc_block, 2 * strip_pad + kIpcFlagBytes));
+  PDEOPT_HIP_CHECK(ctx, hipMemsetAsync(c.ipc_block, 0, 2 * strip_pad + kIpcFlagBytes, ctx->stream));
+  PDEOPT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  hipIpcMemHandle_t h;
+  PDEOPT_HIP_CHECK(ctx, hipIpcGetMemHandle(&h, c.ipc_block));
+  static_assert(sizeof(h) == 64, "hipIpcMemHandle_t is 64 bytes");
+  memcpy(handle64, &h, sizeof(h));
+  c.world = world;
+  c.rank = rank;
+  c.seq = 0;
+  return PDEOPT_OK;
+}
+
+int comm_ipc_attach(pdeopt_ctx* ctx, const void* handles) {
+  CommState* cp = ctx->comm;
+  if (!cp || !cp->ipc_block || cp->ipc) return fail(ctx, PDEOPT_ESTATE, "pdeopt_comm_ipc_export first (once per ctx)");
+  CommState& c = *cp;
+  c.peer_block.assign((size_t)c.world, nullptr);
+  for (int r = 0; r < c.world; ++r) {
+    if (r == c.rank) {
+      c.peer_block[r] = c.ipc_block;
+      continue;
+    }
+    hipIpcMemHandle_t h;
+    memcpy(&h, static_cast<const char*>(handles) + (size_t)r * sizeof(h), sizeof(h));
+    PDEOPT_HIP_CHECK(ctx, hipIpcOpenMemHandle(&c.peer_block[r], h, hipIpcMemLazyEnablePeerAccess));
+  }
+  const size_t strip_pad = (c.ipc_strip_bytes + 255) / 256 * 256;
+  c.ipc_err_dev = reinterpret_cast<unsigned*>(static_cast<char*>(c.ipc_block) + 2 * strip_pad) + 2;
+  c.ipc = true;
+  return PDEOPT_OK;
+}
+
+namespace {
+int rk4_ipc_advance(pdeopt_ctx* ctx, CommState& c, double dt, int64_t n, const int* nbr) {
+  if (ctx->halo != 8) return fail(ctx, PDEOPT_EINVAL, "the peer-mapped exchange runs the halo-8 layout");
+  if (halo_strip_elems(ctx) * ctx->esize != c.ipc_strip_bytes)
+    return fail(ctx, PDEOPT_ESTATE, "the problem was reconfigured with another strip size after pdeopt_comm_ipc_export");
+  int fields[4], nph = 0;
+  rk4_phase_plan(ctx, fields, &nph);
+  if (nph > 2) return fail(ctx, PDEOPT_EINVAL, "the peer-mapped exchange needs the fused Cahn-Hilliard kernels (one exchange per substep)");
+  if (n <= 0) return PDEOPT_OK;
+  const size_t strip_pad = (c.ipc_strip_bytes + 255) / 256 * 256;
+  auto strip_of = [&](int rank, unsigned e) { return static_cast<char*>(c.peer_block[(size_t)rank]) + (size_t)(e & 1u) * strip_pad; };
+  auto flags_of = [&](int rank) { return reinterpret_cast<unsigned*>(static_cast<char*>(c.peer_block[(size_t)rank]) + 2 * strip_pad); };
+  IpcWaitArgs w{};
+  for (int q = 0; q < 8; ++q) w.flags[q] = flags_of(nbr[q]);
+  w.err = c.ipc_err_dev;
+  unsigned e = (unsigned)c.seq;  // index of the exchange the next kernel consumes
+  int rc;
+  // the first strip of this call: packed from the state as it stands, into the buffer strip e - 2 lived in
+  w.ready_min = 0;
+  w.consumed_min = e >= 1 ? e - 1 : 0;
+  hipLaunchKernelGGL(ipc_wait_kernel, dim3(1), dim3(64), 0, ctx->stream, w);
+  if ((rc = halo_pack(ctx, 0, strip_of(c.rank, e)))) return rc;
+  hipLaunchKernelGGL(ipc_publish_kernel, dim3(1), dim3(1), 0, ctx->stream, flags_of(c.rank), e + 1, e);
+  for (int64_t s = 0; s < n; ++s, ++e) {
+    const bool more = s + 1 < n;
+    w.ready_min = e + 1;
+    w.consumed_min = 0;
+    hipLaunchKernelGGL(ipc_wait_kernel, dim3(1), dim3(64), 0, ctx->stream, w);
+    const void* peer[8];
+    for (int q = 0; q < 8; ++q) peer[q] = strip_of(nbr[q], e);
+    if ((rc = rk4_substep_h8_peer(ctx, dt, more ? strip_of(c.rank, e + 1) : nullptr, peer))) return rc;
+    hipLaunchKernelGGL(ipc_publish_kernel, dim3(1), dim3(1), 0, ctx->stream, flags_of(c.rank), more ? e + 2 : e + 1, e + 1);
+  }
+  PDEOPT_HIP_CHECK(ctx, hipGetLastError());
+  c.seq = e;
+  // a neighbour that never arrived: the wait kernel gave up and raised the flag (the state is then garbage)
+  unsigned err = 0;
+  PDEOPT_HIP_CHECK(ctx, hipMemcpyAsync(&err, c.ipc_err_dev, sizeof(err), hipMemcpyDeviceToHost, ctx->stream));
+  PDEOPT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  if (err) return fail(ctx, PDEOPT_ESTATE, "peer-mapped exchange: a neighbour rank did not publish its strip within 2 s");
+  return PDEOPT_OK;
+}
+}  // namespace
+
 // n RK4 substeps of this rank's tile; nbr[8] = ranks of {up, down, left, right, UL, UR, DL, DR}
 int rk4_decomposed_advance(pdeopt_ctx* ctx, double dt, int64_t n, const int* nbr, int overlap) {
   CommState* cp = ctx->comm;
-  if (!cp || (!cp->comm && !cp->group))
-    return fail(ctx, PDEOPT_ESTATE, "pdeopt_comm_init / pdeopt_comm_init_local has not been called");
+  if (!cp || (!cp->comm && !cp->group && !cp->ipc))
+    return fail(ctx, PDEOPT_ESTATE, "pdeopt_comm_init / pdeopt_comm_init_local / pdeopt_comm_ipc_attach has not been called");
   CommState& c = *cp;
+  if (c.ipc) {
+    for (int q = 0; q < 8; ++q)
+      if (nbr[q] < 0 || nbr[q] >= c.world) return fail(ctx, PDEOPT_EINVAL, "neighbour rank %d outside 0..%d", nbr[q], c.world - 1);
+    return rk4_ipc_advance(ctx, c, dt, n, nbr);
+  }
   for (int q = 0; q < 8; ++q)
     if (nbr[q] < 0 || nbr[q] >= c.world) return fail(ctx, PDEOPT_EINVAL, "neighbour rank %d outside 0..%d", nbr[q], c.world - 1);
   const size_t strip_elems = halo_strip_elems(ctx);

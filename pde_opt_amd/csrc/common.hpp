@@ -170,6 +170,7 @@ struct pdeopt_ctx {
   void* pair_strip = nullptr;    // next PAIR_34 launch also writes the tile's halo strip here (fused pack)
   const void* pair_recv = nullptr;  // next PAIR_12 launch reads the halo from these gathered strips (fused unpack)
   int pair_nbr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const void* pair_peer[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // ... or from the neighbours' own strip buffers (peer-mapped exchange)
   void* halo_scratch = nullptr;  // single-rank loop-back buffer for pack/unpack
   void* halo_scratch2 = nullptr; // second loop-back strip (halo-8 loop: fused pack writes one while the next is read)
   size_t halo_scratch_bytes = 0, halo_scratch2_bytes = 0;
@@ -248,6 +249,16 @@ int ensure_stream2(pdeopt_ctx* ctx);  // the ctx's second stream + fork / join e
 // api.hip: bring a time-dependent auxiliary field to local time t (no-op for static fields)
 int refresh_time_aux(pdeopt_ctx* ctx, int which, double t);
 inline bool has_time_aux(const pdeopt_ctx* ctx, int which) { return ctx->aux[which].fn != nullptr; }
+// where the next fused-unpack launch finds the strips of its 8 neighbours: slices of the gathered buffer (pair_recv +
+// rank * strip elements), or the neighbours' own buffers (pair_peer, peer-mapped exchange); all nullptr: no fused unpack
+template <typename T>
+inline void fill_neighbour_strips(const pdeopt_ctx* ctx, int64_t strip_rank_elems, const T** nbase) {
+  for (int q = 0; q < 8; ++q) {
+    if (ctx->pair_peer[0]) nbase[q] = static_cast<const T*>(ctx->pair_peer[q]);
+    else if (ctx->pair_recv) nbase[q] = static_cast<const T*>(ctx->pair_recv) + (int64_t)ctx->pair_nbr[q] * strip_rank_elems;
+    else nbase[q] = nullptr;
+  }
+}
 // light spots of the environments from win_lo on, at local time t
 template <typename T>
 inline SpotArgs<T> make_spot_args(const pdeopt_ctx* ctx, double t) {
@@ -290,6 +301,7 @@ int rk4_loopback_advance(pdeopt_ctx* ctx, double dt, int64_t n);
 // recv != nullptr: the halo of the state is NOT in the field yet -- the first pair's edge tiles read it from the
 // gathered strips `recv` (neighbour ranks nbr[8]) and write the frame cells back (fused unpack)
 int rk4_substep_h8(pdeopt_ctx* ctx, double dt, void* strip, const void* recv = nullptr, const int* nbr = nullptr);
+int rk4_substep_h8_peer(pdeopt_ctx* ctx, double dt, void* strip, const void* const* peer);
 int rk4_phase_plan(pdeopt_ctx* ctx, int* fields, int* nphases);
 void* field_ptr(pdeopt_ctx* ctx, int field);
 // comm.hip
@@ -300,6 +312,8 @@ pdeopt_local_group* local_group_new(int world);
 void local_group_delete(pdeopt_local_group* g);
 void comm_destroy(pdeopt_ctx* ctx);
 int rk4_decomposed_advance(pdeopt_ctx* ctx, double dt, int64_t n, const int* nbr, int overlap);
+int comm_ipc_export(pdeopt_ctx* ctx, int world, int rank, void* handle64);
+int comm_ipc_attach(pdeopt_ctx* ctx, const void* handles);
 // reduce.hip
 int reduce_state(pdeopt_ctx* ctx, int op, double* out);
 int probe_state(pdeopt_ctx* ctx, const int32_t* cells, int n_probes, int env_first, int env_count, double* host_out);

@@ -697,6 +697,14 @@ int rk4_loopback_advance(pdeopt_ctx* ctx, double dt, int64_t n) {
 
 // halo-8 layout, the state's halo already unpacked: both stage pairs of one substep; the edge tiles of the second
 // write the NEW state's halo strip into `strip` (nullptr: not wanted)
+// the same with the halo taken from the 8 neighbours' OWN strip buffers (peer-mapped exchange: comm.hip)
+int rk4_substep_h8_peer(pdeopt_ctx* ctx, double dt, void* strip, const void* const* peer) {
+  for (int q = 0; q < 8; ++q) ctx->pair_peer[q] = peer[q];
+  const int rc = rk4_substep_h8(ctx, dt, strip, nullptr, nullptr);
+  for (int q = 0; q < 8; ++q) ctx->pair_peer[q] = nullptr;
+  return rc;
+}
+
 int rk4_substep_h8(pdeopt_ctx* ctx, double dt, void* strip, const void* recv, const int* nbr) {
   ctx->pair_recv = recv;
   if (recv)

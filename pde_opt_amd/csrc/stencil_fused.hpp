@@ -123,13 +123,12 @@ struct PairArgs {
   T* strip;
   int64_t strip_env;  // strip elements per environment
   // PAIR_12 of a decomposed field (halo-8 layout): the launch covers the tile + `ext` ring (pointers pre-shifted by
-  // -ext rows / columns).  With recv != nullptr the edge tiles take the halo cells of their input straight from the
-  // gathered strips (recv: all ranks' strips, rank-major, strip_rank elements each; nbr: ranks of {up, down, left,
-  // right, UL, UR, DL, DR}) instead of from the field's halo frame, and write the frame cells they own back into
-  // the field (the second stage pair reads y there): no unpack launch.
-  const T* recv;
-  int64_t strip_rank;
-  int nbr[8];
+  // -ext rows / columns).  With nbase[0] != nullptr the edge tiles take the halo cells of their input straight from the
+  // neighbour ranks' strips (nbase[q]: the strip of neighbour q in {up, down, left, right, UL, UR, DL, DR}) instead of
+  // from the field's halo frame, and write the frame cells they own back into the field (the second stage pair reads
+  // y there): no unpack launch.
+  const T* nbase[8];  // strips of {up, down, left, right, UL, UR, DL, DR}: rank-major slices of the gathered buffer, or the
+                      // neighbours' own strip buffers mapped into this process (peer-mapped exchange, comm.hip)
   int ext;
 };
 
@@ -350,7 +349,7 @@ __global__ __launch_bounds__(NT) PDEOPT_PAIR_WAVES_ATTR void stage_pair_kernel(c
   // instructions a thread executes per tile.)  A wave reads 34 (36) contiguous vectors of one row.
   bool halo_from_strips = false;  // wave-uniform
   if constexpr (PAIR == PAIR_12 && !RAGGED)
-    halo_from_strips = a.recv != nullptr && (ti == 0 || ti == tiles_i - 1 || tj == 0 || tj == tiles_j - 1);
+    halo_from_strips = a.nbase[0] != nullptr && (ti == 0 || ti == tiles_i - 1 || tj == 0 || tj == tiles_j - 1);
   if (halo_from_strips) {
     // Fused unpack (decomposed field, edge tiles of the extended launch).  True coordinates (tile interior = [0, nx)
     // x [0, ny)) of a loaded vector: gi = i0 - 4 + row - ext, gj = j0 - HV V + lane V - ext.  Interior cells come
@@ -367,22 +366,21 @@ __global__ __launch_bounds__(NT) PDEOPT_PAIR_WAVES_ATTR void stage_pair_kernel(c
       const int nx = g.nx, ny = g.ny, ext = a.ext;
       const StripOffsets<H> so(nx, ny);
       const T* const mem = in + (int64_t)ext * ld + ext;  // cell (0, 0) of the tile interior
-      const T* const rb = a.recv + (int64_t)b * a.strip_env;
-      const int64_t S = a.strip_rank;
+      const int64_t eoff = (int64_t)b * a.strip_env;  // this environment inside a rank's strip
       const int gj = j0 - HV * V + lane * V - ext;
       const T *pT, *pM, *pB;
       int64_t qT, qM, qB;  // pitches
       if (gj >= 0 && gj < ny) {
-        pT = rb + a.nbr[0] * S + so.bottom + gj; qT = ny;   // up's bottom rows
+        pT = a.nbase[0] + eoff + so.bottom + gj; qT = ny;   // up's bottom rows
         pM = mem + gj; qM = ld;
-        pB = rb + a.nbr[1] * S + so.top + gj; qB = ny;      // down's top rows
+        pB = a.nbase[1] + eoff + so.top + gj; qB = ny;      // down's top rows
       } else if (gj < 0) {
         const int c = gj + H;
-        pT = rb + a.nbr[4] * S + so.br + c; pM = rb + a.nbr[2] * S + so.right + c; pB = rb + a.nbr[6] * S + so.tr + c;
+        pT = a.nbase[4] + eoff + so.br + c; pM = a.nbase[2] + eoff + so.right + c; pB = a.nbase[6] + eoff + so.tr + c;
         qT = qM = qB = H;
       } else if (gj < ny + H) {
         const int c = gj - ny;
-        pT = rb + a.nbr[5] * S + so.bl + c; pM = rb + a.nbr[3] * S + so.left + c; pB = rb + a.nbr[7] * S + so.tl + c;
+        pT = a.nbase[5] + eoff + so.bl + c; pM = a.nbase[3] + eoff + so.left + c; pB = a.nbase[7] + eoff + so.tl + c;
         qT = qM = qB = H;
       } else {  // beyond the halo: the margin
         pT = mem + gj - (int64_t)H * ld; pM = mem + gj; pB = mem + gj + (int64_t)nx * ld;

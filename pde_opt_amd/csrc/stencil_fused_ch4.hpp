@@ -56,15 +56,15 @@ struct Quad4Args {
   // A rank's tile of a decomposed field (halo-8 layout, HALO kernels; stencil_fused.hpp: PairArgs has the same
   // fields for the stage pairs).  The tile + 8 input of this kernel IS the layout's halo: one kernel and one exchange
   // per substep, nothing re-evaluated on a ring outside the tile.
-  //   recv != nullptr: the edge tiles take the halo cells of y straight from the gathered strips (all ranks' strips,
-  //   rank-major, strip_rank elements each; nbr: ranks of {up, down, left, right, UL, UR, DL, DR}) -- no unpack launch;
-  //   nullptr: the halo frame of the field holds them (pdeopt_halo_unpack ran).
+  //   nbase[0] != nullptr: the edge tiles take the halo cells of y straight from the neighbour ranks' strips (nbase[q]:
+  //   the strip of neighbour q in {up, down, left, right, UL, UR, DL, DR} -- a slice of the gathered buffer, or the
+  //   neighbour's own buffer mapped into this process) -- no unpack launch; nullptr: the halo frame of the field holds
+  //   them (pdeopt_halo_unpack ran).
   //   strip != nullptr: the edge tiles also write the cells of y' within 8 of the tile border into this rank's strip
   //   (halo.hip's layout) -- no pack launch.
-  const T* recv;
+  const T* nbase[8];
   T* strip;
-  int64_t strip_env, strip_rank;
-  int nbr[8];
+  int64_t strip_env;
 };
 
 #ifndef PDEOPT_CH4_THREADS
@@ -128,7 +128,7 @@ __global__ __launch_bounds__(G::NT, G::kWavesPerSimd) void ch_rk4_quad_kernel(co
   // ---- y on tile + 8 -> A, one tile row per wave and trip (stencil_generic.hpp: load_rows_per_wave)
   bool edge_tile = false;  // wave-uniform
   if constexpr (HALO) edge_tile = ti == 0 || ti == tiles_i - 1 || tj == 0 || tj == tiles_j - 1;
-  if (HALO && edge_tile && a.recv != nullptr) {
+  if (HALO && edge_tile && a.nbase[0] != nullptr) {
     // Fused unpack (stage_pair_kernel does the same for its tile + 4 launch): interior cells from the field, the cells
     // of the 8-wide halo from the strip piece of the neighbour they belong to (halo.hip: my halo piece q <- piece
     // FROM[q] of neighbour q).  A vector never straddles two sources (every boundary is a multiple of V).  Per thread:
@@ -140,22 +140,21 @@ __global__ __launch_bounds__(G::NT, G::kWavesPerSimd) void ch_rk4_quad_kernel(co
     if (lane < PV) {
       const int nx = g.nx, ny = g.ny;
       const StripOffsets<H> so(nx, ny);
-      const T* const rb = a.recv + (int64_t)b * a.strip_env;
-      const int64_t S = a.strip_rank;
+      const int64_t eoff = (int64_t)b * a.strip_env;  // this environment inside a rank's strip
       const int gj = j0 - H + lane * V;
       const T *pT, *pM, *pB;
       int64_t qT, qM, qB;  // pitches
       if (gj >= 0 && gj < ny) {
-        pT = rb + a.nbr[0] * S + so.bottom + gj; qT = ny;  // up's bottom rows
+        pT = a.nbase[0] + eoff + so.bottom + gj; qT = ny;  // up's bottom rows
         pM = in + gj; qM = ld;
-        pB = rb + a.nbr[1] * S + so.top + gj; qB = ny;     // down's top rows
+        pB = a.nbase[1] + eoff + so.top + gj; qB = ny;     // down's top rows
       } else if (gj < 0) {
         const int c = gj + H;
-        pT = rb + a.nbr[4] * S + so.br + c; pM = rb + a.nbr[2] * S + so.right + c; pB = rb + a.nbr[6] * S + so.tr + c;
+        pT = a.nbase[4] + eoff + so.br + c; pM = a.nbase[2] + eoff + so.right + c; pB = a.nbase[6] + eoff + so.tr + c;
         qT = qM = qB = H;
       } else {
         const int c = gj - ny;
-        pT = rb + a.nbr[5] * S + so.bl + c; pM = rb + a.nbr[3] * S + so.left + c; pB = rb + a.nbr[7] * S + so.tl + c;
+        pT = a.nbase[5] + eoff + so.bl + c; pM = a.nbase[3] + eoff + so.left + c; pB = a.nbase[7] + eoff + so.tl + c;
         qT = qM = qB = H;
       }
       T* const lds = A0 - 8 * P + lane * V;
@@ -462,13 +461,9 @@ int launch_ch_quad_g(pdeopt_ctx* ctx, const void* y, void* out, double dt) {
   };
   if (ctx->halo == 8) {
     // decomposed field: halo cells from the gathered strips / the new strip out of the store epilogue (rk4_substep_h8)
-    if (ctx->pair_recv) {
-      s.recv = static_cast<const float*>(ctx->pair_recv);
-      for (int q = 0; q < 8; ++q) s.nbr[q] = ctx->pair_nbr[q];
-    }
     s.strip = static_cast<float*>(ctx->pair_strip);
     s.strip_env = 2LL * 8 * p.ny + 2LL * p.nx * 8 + 4LL * 64;
-    s.strip_rank = s.strip_env * p.batch;
+    fill_neighbour_strips<float>(ctx, s.strip_env * p.batch, s.nbase);
     if (cl == CL_LOGIT && p.mu.n <= 2) return go(ch_rk4_quad_kernel<CL_LOGIT1, G, true>, "rk4_quad<f32,CH,halo8,logit");
     if (cl == CL_LOGIT) return go(ch_rk4_quad_kernel<CL_LOGIT, G, true>, "rk4_quad<f32,CH,halo8,logit");
     return go(ch_rk4_quad_kernel<CL_POLY, G, true>, "rk4_quad<f32,CH,halo8,poly");

@@ -36,12 +36,9 @@ int launch_pair(pdeopt_ctx* ctx, int pair, const void* in, const void* y, const 
       const int64_t shift = (int64_t)ext * s.g.ld + ext;
       s.in -= shift; s.out -= shift; s.acc_out -= shift;
       s.ext = ext;
-      if (ctx->pair_recv) {  // fused unpack: halo cells straight from the gathered strips
-        s.recv = static_cast<const T*>(ctx->pair_recv);
-        s.strip_env = 2LL * 8 * p.ny + 2LL * p.nx * 8 + 4LL * 64;
-        s.strip_rank = s.strip_env * p.batch;
-        for (int q = 0; q < 8; ++q) s.nbr[q] = ctx->pair_nbr[q];
-      }
+      // fused unpack: halo cells straight from the neighbours' strips
+      s.strip_env = 2LL * 8 * p.ny + 2LL * p.nx * 8 + 4LL * 64;
+      fill_neighbour_strips<T>(ctx, s.strip_env * p.batch, s.nbase);
     } else if (ctx->pair_strip) {
       s.strip = static_cast<T*>(ctx->pair_strip);
       s.strip_env = 2LL * 8 * p.ny + 2LL * p.nx * 8 + 4LL * 64;

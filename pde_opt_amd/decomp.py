@@ -237,6 +237,43 @@ class NativeComm:
         raise RuntimeError("NativeComm exchanges inside pdeopt_rk4_decomposed_advance")
 
 
+class PeerMappedComm:
+    """One process per GPU, NO collective in the substep (csrc/comm.hip, peer-mapped exchange): every
+    rank's strip buffers are mapped into every process (hipIpc), a rank's stencil kernel reads its neighbours' strips in
+    place and writes its own next strip, two counters per rank order the exchanges.  ``allgather(obj) -> [obj of rank 0,
+    ..., obj of rank world-1]`` carries the 64-byte handles between the processes once, at set-up (default:
+    ``torch.distributed.all_gather_object``); processes sharing one GPU work too."""
+
+    def __init__(self, world: Optional[int] = None, rank: Optional[int] = None, allgather=None):
+        if world is None or rank is None:
+            import torch.distributed as dist
+
+            world, rank = dist.get_world_size(), dist.get_rank()
+        self.world, self.rank = int(world), int(rank)
+        self._allgather = allgather or self._torch_allgather
+        self._attached = False
+
+    def _torch_allgather(self, obj):
+        import torch.distributed as dist
+
+        out = [None] * self.world
+        dist.all_gather_object(out, obj)
+        return out
+
+    def make_buffers(self, backend):
+        if not self._attached:
+            if getattr(backend, "halo", 4) != 8:
+                raise ValueError("the peer-mapped exchange needs the halo-8 layout (fused Cahn-Hilliard kernels)")
+            eng = backend.engine
+            handles = self._allgather(eng.comm_ipc_export(self.world, self.rank))
+            eng.comm_ipc_attach(handles)
+            self._attached = True
+        return None, None  # the strip buffers live in the library
+
+    def all_gather(self, send, recv):
+        raise RuntimeError("PeerMappedComm exchanges inside pdeopt_rk4_decomposed_advance")
+
+
 class LocalGroupComm:
     """One rank of an IN-PROCESS group (``pdeopt_local_group``, csrc/comm.hip): the ranks are engines of this
     process -- several on one GPU ("virtual ranks": the library's decomposed loop, its neighbour tables and rank
@@ -408,8 +445,8 @@ class DecomposedSolver:
         if (self.use_overlap or self.use_graph) and getattr(be, "halo", HALO) == 8:
             raise ValueError("the interior / edge overlap and the graph replay belong to the halo-4 layout "
                              "(DecomposedSolver(..., halo=4)); halo 8 exchanges once per substep")
-        if isinstance(c, (NativeComm, LocalGroupComm)):
-            self.mode = "native" if isinstance(c, NativeComm) else "local-group"
+        if isinstance(c, (NativeComm, LocalGroupComm, PeerMappedComm)):
+            self.mode = "native" if isinstance(c, NativeComm) else ("peer-mapped" if isinstance(c, PeerMappedComm) else "local-group")
             if self.use_overlap and len(plan) == 2 and isinstance(c, NativeComm):
                 self.mode = "native+overlap"
             be.engine.rk4_decomposed_advance(dt, n, self.neighbours, overlap=self.use_overlap)

@@ -548,6 +548,21 @@ class HipEngine:
         self._check(self._lib.pdeopt_comm_init_local(self._h, group._h, int(rank)))
         self._group = group  # the group outlives its members
 
+    def comm_ipc_export(self, world: int, rank: int) -> bytes:
+        """peer-mapped exchange (no collective in the substep): allocate this rank's strip buffers + counters and return
+        the 64-byte hipIpc handle the other processes map (``comm_ipc_attach``); call after ``configure`` in the
+        halo-8 layout"""
+        buf = C.create_string_buffer(64)
+        self._check(self._lib.pdeopt_comm_ipc_export(self._h, int(world), int(rank), buf))
+        return buf.raw
+
+    def comm_ipc_attach(self, handles: Sequence[bytes]):
+        """map every rank's block: ``handles[r]`` = what rank r's ``comm_ipc_export`` returned (own entry ignored)"""
+        blob = b"".join(bytes(h) for h in handles)
+        if len(blob) % 64:
+            raise ValueError("hipIpc handles are 64 bytes each")
+        self._check(self._lib.pdeopt_comm_ipc_attach(self._h, blob))
+
     def comm_destroy(self):
         self._check(self._lib.pdeopt_comm_destroy(self._h))
 

@@ -116,3 +116,44 @@ def gather_all(comm):
     for _, eng_dst, _, recv, nbytes in comm.members:
         for src_rank, _, send_src, _, _ in comm.members:
             eng_dst.buffer_copy(recv.ptr + src_rank * nbytes, send_src.ptr, nbytes, L.COPY_D2D)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# peer-mapped exchange between PROCESSES (csrc/comm.hip: pdeopt_comm_ipc_export / _attach): worker of
+# tests/test_gpu_decomp.py::test_peer_mapped_exchange_between_processes_sharing_one_gpu
+def peer_mapped_worker(rank, px, py, shape, y0, dt, calls, dtype_name, q_up, q_down, q_out, sabotage=False):
+    """one rank = one process with its own engine on GPU 0; the 64-byte hipIpc handles travel through the parent"""
+    try:
+        import os
+        import sys
+
+        here = os.path.dirname(os.path.abspath(__file__))
+        sys.path.insert(0, os.path.dirname(here))
+        sys.path.insert(0, here)
+        import numpy as np
+
+        import pde_opt_amd as P
+        from pde_opt_amd.decomp import CartesianGrid, DecomposedSolver, PeerMappedComm
+        from util import MOB, MU, std_domain
+
+        def allgather(obj):
+            q_up.put((rank, obj))
+            return q_down.get(timeout=120)
+
+        nx, ny = shape
+        dom = std_domain(P, nx, ny)
+        eq = P.CahnHilliard2DPeriodic(dom, 0.002, MU["regsol"], MOB["c1mc"])
+        dtype = np.dtype(dtype_name).type
+        comm = PeerMappedComm(px * py, rank, allgather=allgather)
+        sol = DecomposedSolver(eq, CartesianGrid(px, py, rank), comm=comm, dtype=dtype, halo=8)
+        sol.set_global_state(y0)
+        if sabotage and rank == px * py - 1:
+            q_out.put((rank, "absent", None, None))  # this rank never joins the substep loop
+            return
+        for n in calls:
+            sol.advance(dt, n)
+        q_out.put((rank, sol.mode, sol.backend.engine.last_kernel, sol.local_state()))
+        q_down.get(timeout=120)  # keep the mapped buffers alive until every rank has finished reading them
+        sol.backend.engine.close()
+    except BaseException as e:  # noqa: BLE001
+        q_out.put((rank, "error", repr(e), None))

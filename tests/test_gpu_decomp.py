@@ -215,6 +215,73 @@ def test_in_library_loop_with_virtual_ranks_equals_monolithic(grid, tile, halo, 
     comms[0].group.close()
 
 
+def _run_peer_mapped(px, py, tile, dtype, calls, sabotage=False):
+    import multiprocessing as mp
+    import threading
+
+    from decomp_util import peer_mapped_worker
+
+    world = px * py
+    nx, ny = px * tile[0], py * tile[1]
+    rng = np.random.default_rng(21)
+    y0 = np.clip(0.5 + 0.05 * rng.standard_normal((nx, ny)), 0.05, 0.95).astype(dtype)
+    ctx = mp.get_context("spawn")
+    q_up, q_out = ctx.Queue(), ctx.Queue()
+    q_down = [ctx.Queue() for _ in range(world)]
+    procs = [ctx.Process(target=peer_mapped_worker, args=(r, px, py, (nx, ny), y0, 2e-7, calls, np.dtype(dtype).name, q_up, q_down[r], q_out,
+                                                          sabotage)) for r in range(world)]
+    for p_ in procs:
+        p_.start()
+
+    def gather():  # the "transport" of the handles: every rank's 64 bytes to every rank
+        got = dict(q_up.get(timeout=180) for _ in range(world))
+        for r in range(world):
+            q_down[r].put([got[i] for i in range(world)])
+
+    t = threading.Thread(target=gather)
+    t.start()
+    try:
+        results = dict((r, (mode, kern, tile_)) for r, mode, kern, tile_ in (q_out.get(timeout=240) for _ in range(world)))
+    finally:
+        t.join(timeout=10)
+        for r in range(world):
+            q_down[r].put("done")
+        for p_ in procs:
+            p_.join(timeout=60)
+            if p_.is_alive():
+                p_.kill()
+    return y0, (nx, ny), results
+
+
+@pytest.mark.parametrize("grid,tile,dtype", [((2, 1), (64, 128), np.float32), ((2, 2), (64, 128), np.float32), ((2, 2), (64, 64), np.float64)])
+def test_peer_mapped_exchange_between_processes_sharing_one_gpu(grid, tile, dtype):
+    """pdeopt_comm_ipc_export / _attach ("P2P stores into peer-mapped halo buffers"): one PROCESS per rank
+    as in the process-per-GPU deployment, here all on GPU 0 (hipIpc handles work across processes on one device).  Every
+    rank's stencil kernel reads its neighbours' strips in place through the mapped buffers and writes its own; counters
+    order the exchanges; no collective.  Bitwise equal to the monolithic periodic solve, across two advance calls."""
+    px, py = grid
+    y0, (nx, ny), res = _run_peer_mapped(px, py, tile, dtype, calls=(4, 3))
+    assert all(v[0] == "peer-mapped" for v in res.values()), {r: v[:2] for r, v in res.items()}
+    quad = dtype is np.float32
+    assert all(("rk4_quad<f32,CH,halo8" in v[1]) == quad for v in res.values()), [v[1] for v in res.values()]
+    dom = std_domain(P, nx, ny)
+    eq = P.CahnHilliard2DPeriodic(dom, 0.002, MU["regsol"], MOB["c1mc"])
+    want, _ = _monolithic(eq, y0, 2e-7, 7, 0)
+    got = np.empty_like(want)
+    for r, (_, _, t_) in res.items():
+        si, sj = CartesianGrid(px, py, r).tile_slices(nx, ny)
+        got[si, sj] = t_
+    np.testing.assert_array_equal(got, want)
+
+
+def test_peer_mapped_exchange_absent_rank_is_an_error_not_a_hang():
+    """a neighbour that never publishes its strip: the wait kernel gives up after 2 s and the call fails on the ranks
+    that waited (no wave spins forever)"""
+    _, _, res = _run_peer_mapped(2, 1, (64, 128), np.float32, calls=(3,), sabotage=True)
+    assert res[1][0] == "absent"
+    assert res[0][0] == "error" and "did not publish" in res[0][1], res[0]
+
+
 def test_local_group_misuse_is_an_error_not_a_hang():
     """a rank whose partners never arrive fails with a message (the rendezvous has a time-out; here a rank count
     mismatch is detected before any waiting)"""
