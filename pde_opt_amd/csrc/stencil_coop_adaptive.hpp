@@ -39,6 +39,7 @@
 #pragma once
 
 #include <cstdlib>
+#include <mutex>
 #include <type_traits>
 
 #include "stencil_small_adaptive.hpp"
@@ -805,6 +806,11 @@ int coop_tsit5_solve(pdeopt_ctx* ctx, double t0, double t1, double dt0, const pd
     s1 = static_cast<const T*>(ctx->aux[PDEOPT_AUX_VY_FACE].dev);
     sstride = ctx->aux[PDEOPT_AUX_VX_FACE].per_env ? cells : 0;
   }
+  // The workgroups of a launch wait for each other: two such launches of one process in flight at once (two engines on
+  // two host threads) could each hold half of the chip and starve the other until the 2 s abort.  One at a time per
+  // process (the call is synchronous anyway); other PROCESSES on the same GPU are the caller's to keep apart.
+  static std::mutex coop_launch_mutex;
+  std::lock_guard<std::mutex> coop_lock(coop_launch_mutex);
   for (int e0 = 0; e0 < batch; e0 += envs_per_launch) {
     const int ne = std::min(envs_per_launch, batch - e0);
     CoopArgs<T> c = s;

@@ -122,7 +122,10 @@ def gather_all(comm):
 # peer-mapped exchange between PROCESSES (csrc/comm.hip: pdeopt_comm_ipc_export / _attach): worker of
 # tests/test_gpu_decomp.py::test_peer_mapped_exchange_between_processes_sharing_one_gpu
 def peer_mapped_worker(rank, px, py, shape, y0, dt, calls, dtype_name, q_up, q_down, q_out, sabotage=False):
-    """one rank = one process with its own engine on GPU 0; the 64-byte hipIpc handles travel through the parent"""
+    """one rank = one process with its own engine on GPU 0; the 64-byte hipIpc handles travel through the parent.  A rank
+    keeps its engine (= the buffers its peers have mapped and may still be polling) alive until the parent says every rank
+    has reported -- also when it failed or plays the absent rank."""
+    sol = None
     try:
         import os
         import sys
@@ -149,11 +152,17 @@ def peer_mapped_worker(rank, px, py, shape, y0, dt, calls, dtype_name, q_up, q_d
         sol.set_global_state(y0)
         if sabotage and rank == px * py - 1:
             q_out.put((rank, "absent", None, None))  # this rank never joins the substep loop
-            return
-        for n in calls:
-            sol.advance(dt, n)
-        q_out.put((rank, sol.mode, sol.backend.engine.last_kernel, sol.local_state()))
-        q_down.get(timeout=120)  # keep the mapped buffers alive until every rank has finished reading them
-        sol.backend.engine.close()
+        else:
+            for n in calls:
+                sol.advance(dt, n)
+            q_out.put((rank, sol.mode, sol.backend.engine.last_kernel, sol.local_state()))
     except BaseException as e:  # noqa: BLE001
         q_out.put((rank, "error", repr(e), None))
+    finally:
+        try:
+            while q_down.get(timeout=120) != "done":  # (the handle list, if the failure came before it was consumed)
+                pass
+        except BaseException:  # noqa: BLE001
+            pass
+        if sol is not None:
+            sol.backend.engine.close()
