@@ -72,7 +72,7 @@ struct CoopArgs {
   pdeopt_tsit5_stats* stats;  // [nenv]
   T* xy[2];                   // exchange buffers [nenv][nx * ny]: candidate state / its slope, double-buffered
   T* xk[2];
-  double* part;        // [2][nenv][px * py] partial error sums
+  double* part;        // [2][nenv][px * py][2] partial error sums: slots of the per-step barrier (two tagged words each)
   unsigned* bar;       // [nenv][2]: arrivals, generation
   unsigned* abort_flag;
   int xs, wpx;         // XCDs an environment's workgroups are spread over (1, 2, 4, 8) and workgroups per XCD
@@ -493,21 +493,63 @@ __global__ __launch_bounds__(PDEOPT_COOP_THREADS) void tsit5_coop_kernel(const C
     if ((tid & 63) == 0) red[tid >> 6] = part;
     __syncthreads();
     PDEOPT_COOP_TICK(2);
-    double* const parts = a.part + ((size_t)(step & 1u) * a.nenv + be) * nwg;
-    if (tid == 0) {
-      double sum = 0.0;
-      for (int i = 0; i < NT / 64; ++i) sum += red[i];
-      xstore(&parts[w], sum);
+    // The per-step barrier IS the exchange of the partial norms: a workgroup posts its sum as two 64-bit words, each
+    // carrying 32 bits of the double and the step's tag, into its slot of the step's parity; wave 0 of every workgroup
+    // polls all slots (one lane each) until both tags match.  One store + one poll round per workgroup instead of an
+    // atomic counter round trip, a generation word and a second read of the sums (one XCD: ~1 us less per step).  Slots
+    // alternate by parity: a workgroup reaches its next write of a slot only after every partner has posted the step
+    // between, i.e. has finished reading this one.  Across XCDs the counter barrier with its fences stays.
+    double* const parts = a.part + ((size_t)(step & 1u) * a.nenv + be) * nwg * 2;  // two words per workgroup
+    const unsigned tag = step + 1u;
+    bool aborted = false;
+    if (one_xcd) {
+      __syncthreads();  // every wave's exchange stores have been acknowledged, red[] is complete
+      if (tid == 0) {
+        double sum = 0.0;
+        for (int i = 0; i < NT / 64; ++i) sum += red[i];
+        const unsigned long long bits = (unsigned long long)__double_as_longlong(sum);
+        unsigned long long* const slot = reinterpret_cast<unsigned long long*>(parts) + 2 * w;
+        xstore(&slot[0], (bits & 0xffffffff00000000ull) | tag);
+        xstore(&slot[1], (bits << 32) | tag);
+      }
+      if (tid < 64) {
+        const unsigned long long t_in = __builtin_amdgcn_s_memrealtime();
+        for (int i = tid; i < nwg; i += 64) {
+          const unsigned long long* const slot = reinterpret_cast<const unsigned long long*>(parts) + 2 * i;
+          unsigned long long w0, w1;
+          for (;;) {
+            w0 = xload(&slot[0]);
+            w1 = xload(&slot[1]);
+            if ((unsigned)w0 == tag && (unsigned)w1 == tag) break;
+            if (xload(a.abort_flag) != 0u) break;
+            if (__builtin_amdgcn_s_memrealtime() - t_in > kCoopTimeoutTicks) {
+              xstore(a.abort_flag, 1u);
+              break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+          }
+          red[24 + i] = __longlong_as_double((long long)((w0 & 0xffffffff00000000ull) | (w1 >> 32)));
+        }
+      }
+      __syncthreads();
+      aborted = xload(a.abort_flag) != 0u;
+    } else {
+      if (tid == 0) {
+        double sum = 0.0;
+        for (int i = 0; i < NT / 64; ++i) sum += red[i];
+        xstore(&parts[w], sum);
+      }
+      if (!coop_env_barrier(bar, a.abort_flag, nwg, &gen, one_xcd)) return;
+      if (tid < 64) {  // wave 0: the partners' partial sums, one lane each (the loads overlap), staged in LDS
+        for (int i = tid; i < nwg; i += 64) red[24 + i] = xload(&parts[i]);
+      }
     }
-    if (!coop_env_barrier(bar, a.abort_flag, nwg, &gen, one_xcd)) return;
+    if (aborted) return;
     PDEOPT_COOP_TICK(3);
     ++step;
     // The controller: ONE lane per workgroup (the same arithmetic on the same partial sums in the same order in every
     // workgroup: one decision for the environment), broadcast through LDS -- all waves running the double-precision
     // pow / sqrt / divisions redundantly cost 6 us per step (14 k ticks), a lone lane ~1
-    if (tid < 64) {  // wave 0: the partners' partial sums, one lane each (the loads overlap), staged in LDS
-      for (int i = tid; i < nwg; i += 64) red[24 + i] = xload(&parts[i]);
-    }
     if (tid == 0) {
       double sum = 0.0;
       for (int i = 0; i < nwg; ++i) sum += red[24 + i];  // one order in every workgroup: the same double everywhere
@@ -736,7 +778,7 @@ int coop_tsit5_solve(pdeopt_ctx* ctx, double t0, double t1, double dt0, const pd
   const size_t ts_bytes = ((size_t)n_save * sizeof(double) + 255) / 256 * 256;
   const size_t st_bytes = ((size_t)batch * sizeof(pdeopt_tsit5_stats) + 255) / 256 * 256;
   const size_t bar_bytes = ((size_t)(2 * batch + 1) * sizeof(unsigned) + 255) / 256 * 256;
-  const size_t part_bytes = ((size_t)2 * batch * nwg * sizeof(double) + 255) / 256 * 256;
+  const size_t part_bytes = ((size_t)2 * batch * nwg * 2 * sizeof(double) + 255) / 256 * 256;  // [parity][env][workgroup][2 words]
   const size_t out_bytes = (size_t)n_save * batch * cells * sizeof(T);
   const size_t need = ts_bytes + st_bytes + bar_bytes + part_bytes + out_bytes + 256;
   if (ctx->adaptive_cap < need) {
@@ -825,7 +867,7 @@ int coop_tsit5_solve(pdeopt_ctx* ctx, double t0, double t1, double dt0, const pd
     c.stats = stats_dev + e0;
     c.xy[0] = static_cast<T*>(ctx->TA) + (int64_t)e0 * cells; c.xy[1] = static_cast<T*>(ctx->TB) + (int64_t)e0 * cells;
     c.xk[0] = static_cast<T*>(ctx->ACC) + (int64_t)e0 * cells; c.xk[1] = static_cast<T*>(ctx->KS) + (int64_t)e0 * cells;
-    c.part = part_dev + (size_t)2 * e0 * nwg;
+    c.part = part_dev + (size_t)2 * e0 * nwg * 2;
     c.bar = bar_dev + 2 * e0;
     c.abort_flag = bar_dev + 2 * batch;
     const int rows_used = (ne + 8 / xs - 1) / (8 / xs);
