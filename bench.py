@@ -70,6 +70,9 @@ WORKLOADS = {
     # level set, regular-solution free energy, contact angle and boundary flux varying in time (notebooks/smooth_boundary.ipynb)
     "ch_sbm_1024_f32": dict(eq="ch_sbm", n=1024, dtype=np.float32, integ="rk4", dt=2e-3, substeps=100, batch=8, words="rk4_sbm",
                             abs_tol=2e-6),  # dt = 2e-3: the state moves 10x as far per substep as in the periodic workloads
+    # Cahn-Hilliard in three dimensions (cahn_hilliard.py:113-200): the two-pass kernels (mu field, then
+    # the flux divergence + Runge-Kutta update), 8 environments of 128^3
+    "ch3d_rk4_128_f32": dict(eq="ch3d", n=128, dtype=np.float32, integ="rk4", dt=2e-7, substeps=20, batch=8),
     "ac_rk4_512_f32": dict(eq="ac", n=512, dtype=np.float32, integ="rk4", dt=5e-5, substeps=100, batch=64),
     "ch_imex_1024_f32": dict(eq="ch", n=1024, dtype=np.float32, integ="imex", dt=1e-6, substeps=100, batch=32),
     # (abs_tol: the spot check's bound on the largest absolute state error; the wavefunction is O(0.2) and its relative
@@ -124,6 +127,12 @@ def make_problem(P, name, batch, rank):
             y0[b] = np.clip(0.5 + 0.1 * np.random.default_rng(rank * batch + b).standard_normal((n, n)), 0.1, 0.9)
         return eq, y0, P.RK4()
     L_ = 0.01 * n
+    if w["eq"] == "ch3d":
+        dom = P.Domain((n, n, n), ((-L_ / 2, L_ / 2),) * 3, "dimensionless")
+        y0 = np.empty((batch, n, n, n), dtype=dtype)
+        for b in range(batch):
+            y0[b] = np.clip(0.5 + 0.01 * np.random.default_rng(rank * batch + b).standard_normal((n, n, n)), 0.05, 0.95)
+        return P.CahnHilliard3DPeriodic(dom, 0.002, REGSOL, C1MC), y0, P.RK4()
     dom = P.Domain((n, n), ((-L_ / 2, L_ / 2), (-L_ / 2, L_ / 2)), "dimensionless")
     y0 = np.empty((batch, n, n), dtype=dtype)
     for b in range(batch):
@@ -549,7 +558,7 @@ def parity_spot(name, eng, eq, solver, y0, threads):
 
     w = WORKLOADS[name]
     dt, batch = w["dt"], y0.shape[0]
-    nsub = w["substeps"] if (w["integ"] == "rk4" and w["eq"] != "ch_sbm") else 8
+    nsub = w["substeps"] if (w["integ"] == "rk4" and w["eq"] not in ("ch_sbm", "ch3d")) else (4 if w["eq"] == "ch3d" else 8)
     eng.set_state(y0)
     eng.advance(solver.integrator, dt, nsub, 0.0)
     # first / last environment of the batch and the two either side of every group edge (at most 8 environments)
@@ -561,7 +570,9 @@ def parity_spot(name, eng, eq, solver, y0, threads):
             break
         edges |= {g * gsz - 1, g * gsz}
     envs = sorted(edges & set(range(batch)))
-    hx, hy = eq.domain.dx
+    if w["eq"] == "ch3d":
+        envs = [0, batch - 1]  # (a numpy right-hand side of 128^3 takes ~1 s)
+    hx, hy = eq.domain.dx[:2]
     worst_rel = worst_abs = 0.0
     for b in envs:
         got = eng.get_state(b, 1)[0].astype(np.float64)
@@ -570,6 +581,11 @@ def parity_spot(name, eng, eq, solver, y0, threads):
             ref = y0[b].astype(np.float64)
             for i in range(nsub):
                 ref = O.rk4_step(frhs, i * dt, ref, dt)
+        elif w["eq"] == "ch3d":
+            f3 = lambda t, u: O.ch3d_rhs_fd(u, hx, hy, eq.domain.dx[2], 0.002, REGSOL, C1MC)
+            ref = y0[b].astype(np.float64)
+            for i in range(nsub):
+                ref = O.rk4_step(f3, i * dt, ref, dt)
         elif w["integ"] == "rk4":
             code, cmu, cmob = _oracle_closures(w)
             ref = CO.rk4(code, y0[b], hx, hy, 0.002, cmu, cmob, dt, nsub, threads=threads).astype(np.float64)
@@ -600,7 +616,7 @@ def parity_spot(name, eng, eq, solver, y0, threads):
             "parity_spot_ok": bool(worst_rel < tol and worst_abs < abs_tol),
             "parity_spot": f"{nsub} substeps of the timed call on fresh inputs, environments {envs} of {batch} "
                            f"(groups: {eng.last_groups()}) vs "
-                           + ("oracle/c_oracle.c" if (w["integ"] == "rk4" and w["eq"] != "ch_sbm") else "oracle/np_oracle.py")}
+                           + ("oracle/c_oracle.c" if (w["integ"] == "rk4" and w["eq"] not in ("ch_sbm", "ch3d")) else "oracle/np_oracle.py")}
 
 
 def cpu_baseline(name, budget_s=15.0):
@@ -656,6 +672,148 @@ def cpu_baseline(name, budget_s=15.0):
                   f"{n_np / el_np:.1f} substeps/s; host reports {os.cpu_count()} logical CPUs, {threads} usable by this job "
                   f"(affinity + cgroup quota)",
     }
+
+
+# The reference's notebook-sized ADAPTIVE solves (Tsit5 + PIDController): a "step" is one diffeqsolve call over a fixed
+# time span, the unit of work a trial step of the controller (accepted or rejected: 7 right-hand sides either way).
+ADAPTIVE = {
+    # notebooks/smooth_boundary.ipynb:228: CahnHilliard2DSmoothedBoundary 100^2, kappa 0.002, dx 0.01, theta = pi / 2,
+    # PIDController(rtol 1e-4, atol 1e-6), 117 890 steps over t = 0 .. 0.1 with 200 saves upstream: a prefix of that solve
+    # with the same save spacing (one save per 5e-4)
+    "ch_sbm_100_tsit5": dict(n=100, dtype=np.float32, t1=2e-3, dt0=1e-6, nsave=5, rtol=1e-4, atol=1e-6),
+    "ch_sbm_100_tsit5_f64": dict(n=100, dtype=np.float64, t1=2e-3, dt0=1e-6, nsave=5, rtol=1e-4, atol=1e-6),
+    # notebooks/run_advection_diffusion.ipynb:84: advection-diffusion 64^2 (8 950 steps upstream)
+    "ad_64_tsit5": dict(n=64, dtype=np.float32, t1=0.4, dt0=1e-5, nsave=2, rtol=1e-4, atol=1e-6),
+}
+
+
+def adaptive_problem(P, name):
+    import types
+
+    w = ADAPTIVE[name]
+    n = w["n"]
+    if name.startswith("ch_sbm"):
+        yy, xx = np.ogrid[:n, :n]
+        r = np.sqrt((xx - n / 2) ** 2 + (yy - n / 2) ** 2)
+        psi = np.maximum(1e-3, 0.5 * (1.0 + np.tanh((20.0 - r) / 3.0)))  # a disc of the notebook's size as a smooth level set
+        dom = P.Domain((n, n), ((-0.5, 0.5), (-0.5, 0.5)), "dimensionless", geometry=types.SimpleNamespace(smooth=psi))
+        eq = P.CahnHilliard2DSmoothedBoundary(dom, 0.002, SBM_F, REGSOL, C1MC, lambda t: np.pi / 2.0, lambda t: 0.0)
+        y0 = 0.9 * np.ones((n, n))
+        y0[:, : n // 2] = 0.1
+        return eq, y0
+    dom = P.Domain((n, n), ((0.0, 0.02 * n), (0.0, 0.02 * n)), "dimensionless")
+
+    def vel(t, x, y):
+        g = np.exp(-((x - 0.4) ** 2 + (y - 0.4) ** 2) / (2 * 0.01))
+        return -0.1 * (x - 0.4) / 0.01 * g, -0.1 * (y - 0.4) / 0.01 * g
+
+    return P.AdvectionDiffusion2D(dom, vel, 0.1, time_dependent=False), 0.5 + 0.01 * np.random.default_rng(0).standard_normal((n, n))
+
+
+def run_adaptive(args, P):
+    """--workload ch_sbm_100_tsit5 / ad_64_tsit5: the whole adaptive solve inside ONE launch (csrc/stencil_coop_adaptive.hpp:
+    several workgroups per environment, controller in the kernel).  value = trial steps per second through
+    ``P.diffeqsolve`` (upload, launch, statistics and save points back: everything the caller waits for)."""
+    w = ADAPTIVE[args.workload]
+    eq, y0 = adaptive_problem(P, args.workload)
+    y0 = y0.astype(w["dtype"])
+    ctl = P.PIDController(rtol=w["rtol"], atol=w["atol"])
+    ts = np.linspace(0.0, w["t1"], w["nsave"])
+    eng = P.HipEngine(int(os.environ.get("LOCAL_RANK", "0")))
+
+    def solve(engine=eng, y=y0):
+        return P.diffeqsolve(eq, P.Tsit5(), 0.0, w["t1"], w["dt0"], y, stepsize_controller=ctl, engine=engine, saveat=P.SaveAt(ts=ts))
+
+    for _ in range(max(args.warmup, 1)):
+        sol = solve()
+    eng.sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        sol = solve()
+    elapsed = time.perf_counter() - t0
+    trials = int(sol.stats["num_steps"])
+    kernel = sol.stats["kernel"]
+    us_per_trial = 1e6 * elapsed / (args.steps * trials)
+    # the launch alone (HIP events around one more solve: upload + kernel + read-back on the engine's stream)
+    eng.timer_start()
+    solve()
+    dev_ms = eng.timer_stop()
+    shader_hz = eng.timer_clock_hz()
+    n = w["n"]
+    esize = np.dtype(w["dtype"]).itemsize
+    sbm = args.workload.startswith("ch_sbm")
+    # SURVEY 8(d)-style bytes of a trial step, had every stage gone through HBM: 7 right-hand sides x (read w, write k)
+    # + the static fields per stage (psi, |grad psi| / psi, mask | two face velocities) + the combination reads
+    words = 7 * (2 + (3 if sbm else 2)) + 9
+    alg_bytes = words * esize * n * n
+    roof = {
+        "bound": "valu", "kernel": kernel, "unit": "VALU utilisation of the compute units the launch occupies",
+        "achieved": None, "peak": 1.0, "frac": None, "traffic": None,
+        "us_per_trial_step_wall": us_per_trial, "us_per_trial_step_device": 1e3 * dev_ms / trials,
+        "algorithmic_bytes_per_trial_step": alg_bytes,
+        "algorithmic_gbs": alg_bytes / (1e-3 * dev_ms / trials) / 1e9,
+        "algorithmic_frac_of_hbm_peak": alg_bytes / (1e-3 * dev_ms / trials) / 1e9 / HBM_PEAK_GBS,
+        "shader_clock_hz": shader_hz,
+        "note": "one launch = the whole solve; the state, the six slopes and the static fields stay in LDS, HBM sees the state once in and the save points "
+                "out (traffic ~ 0): the kernel is bound by the instruction issue + LDS latency of the <= 32 compute units one environment can use "
+                "(one XCD: the per-step exchange then stays in one L2), not by a chip-wide roofline.  frac = VALU-busy share of those compute "
+                "units' SIMD cycles from the committed PMC pass of this command (null while none is committed).",
+    }
+    try:
+        pmc = json.load(open(PMC_FILE)).get(args.workload)
+    except Exception:
+        pmc = None
+    m = __import__("re").search(r"(\d+)x(\d+) workgroups", kernel)
+    nwg = int(m.group(1)) * int(m.group(2)) if m else None
+    if pmc and nwg:
+        c = pmc["counters_per_launch"]
+        hz = shader_hz if shader_hz and shader_hz > 1e8 else SHADER_HZ
+        cycles = 1e-3 * dev_ms * hz
+        if c.get("SQ_ACTIVE_INST_VALU"):
+            roof["workgroups"] = nwg
+            roof["valu_insts_per_trial_step"] = c.get("SQ_INSTS_VALU", 0) / trials
+            roof["achieved"] = roof["frac"] = 4.0 * c["SQ_ACTIVE_INST_VALU"] / (4 * nwg) / cycles / VALU_BUSY_SATURATED
+            roof["traffic"] = pmc.get("hbm_bytes_per_launch")
+            roof["pmc_source"] = os.path.relpath(PMC_FILE, ROOT) + ": " + pmc.get("source", "")
+    # parity + CPU baseline in one: the same solve driven step by step on the numpy oracle under the package's own host loop
+    spot, cpu = {}, None
+    if not args.no_parity_spot or not args.no_cpu_baseline:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from fake_engine import OracleEngine
+
+        tc = time.perf_counter()
+        ref = solve(engine=OracleEngine(), y=y0.astype(np.float64))
+        el_c = time.perf_counter() - tc
+        n_ref = int(ref.stats["num_steps"])
+        got, want = sol.ys.astype(np.float64), ref.ys
+        mabs = float(np.max(np.abs(got - want)))
+        same = (int(sol.stats["num_accepted_steps"]), int(sol.stats["num_rejected_steps"])) == (int(ref.stats["num_accepted_steps"]), int(ref.stats["num_rejected_steps"]))
+        tol = (1e-9 if esize == 8 else 2e-5) if same else 2e-3
+        spot = {"parity_spot_max_abs_err": mabs, "parity_spot_tol": tol, "parity_spot_ok": bool(np.isfinite(mabs) and mabs < tol),
+                "parity_spot_same_accept_reject_sequence": bool(same),
+                "parity_spot": f"the same solve driven step by step on oracle/np_oracle.py in fp64 ({n_ref} trial steps; this run {trials}): "
+                               f"largest difference at the save points"}
+        cpu = {"value": n_ref / el_c, "unit": "trial-steps/s", "cores": 1, "kind": "port",
+               "sample": f"the whole solve ({n_ref} trial steps, 7 right-hand sides each) on the numpy oracle, 1 thread, {el_c:.1f} s"}
+    line = {
+        "metric": f"adaptive trial steps/sec ({args.workload}: Tsit5 + PID rtol {w['rtol']:g} atol {w['atol']:g}, t = 0 .. {w['t1']:g})",
+        "value": args.steps * trials / elapsed, "unit": "trial-steps/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32" if esize == 4 else "f64", "data": "synthetic",
+        "config": {"workload": args.workload, "grid": [n, n], "envs_per_gpu": 1, "integrator": "tsit5 + PID controller (in-kernel)",
+                   "trial_steps_per_solve": trials, "accepted": int(sol.stats["num_accepted_steps"]), "rejected": int(sol.stats["num_rejected_steps"]),
+                   "kernel": kernel, "step": "one P.diffeqsolve call over the span: upload, ONE launch, statistics + save points back"},
+        "us_per_trial_step": us_per_trial,
+        "roofline": roof,
+        "cpu_baseline": cpu,
+        **spot,
+    }
+    eng.close()
+    print(json.dumps(line))
+    sys.stdout.flush()
+    if spot and not spot["parity_spot_ok"]:
+        raise SystemExit(f"adaptive workload FAILED its parity spot: {spot}")
+    return line
 
 
 def run_single_process(args, P, engines=None):
@@ -750,7 +908,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="ch_rk4_1024_f32", choices=sorted(WORKLOADS) + ["ch_rk4_4096_decomp"])
+    ap.add_argument("--workload", default="ch_rk4_1024_f32", choices=sorted(WORKLOADS) + sorted(ADAPTIVE) + ["ch_rk4_4096_decomp"])
     ap.add_argument("--batch-per-gpu", type=int, default=0)
     ap.add_argument("--kernel-path", type=int, default=0, help="0 auto, 1 generic, 2 tiled")
     ap.add_argument("--tile-rows", type=int, default=0, help="0 auto, 16 or 32")
@@ -813,6 +971,10 @@ def main():
         return run_single_process(args, P)
     if args.workload == "ch_rk4_4096_decomp":
         return run_decomp(args, P, world, rank, local_rank, dist)
+    if args.workload in ADAPTIVE:
+        if world > 1:
+            raise SystemExit("the adaptive workloads are single-environment latency measurements: one GPU")
+        return run_adaptive(args, P)
     w = WORKLOADS[args.workload]
     batch = args.batch_per_gpu or w["batch"]
     eq, y0, solver = make_problem(P, args.workload, batch, rank)
@@ -873,10 +1035,10 @@ def main():
         spot = parity_spot(args.workload, eng, eq, solver, y0, usable_cores())
 
     if rank == 0:
-        nx, ny = eq.domain.points
+        nx, ny = eq.domain.points[:2]
         esize = y0.dtype.itemsize
         words = WORDS[w.get("words", w["integ"])]
-        total_bytes = words * esize * nx * ny * batch * substeps * args.steps
+        total_bytes = words * esize * int(np.prod(eq.domain.points)) * batch * substeps * args.steps
         launches = max(launches, 1)
         bytes_per_launch = total_bytes / launches
         # two environment groups side by side (PDEOPT_OPT_GROUP_STREAMS): a launch lasts twice its share of the timed region
@@ -898,7 +1060,7 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": args.workload,
-                "grid": [nx, ny],
+                "grid": [int(v) for v in eq.domain.points],
                 "envs_per_gpu": batch,
                 "envs_total": batch * args.gpus,
                 "integrator": w["integ"],

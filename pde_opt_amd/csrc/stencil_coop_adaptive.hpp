@@ -151,6 +151,9 @@ __device__ __forceinline__ T xload(const T* p) { return __hip_atomic_load(p, __A
 template <typename T>
 __device__ __forceinline__ void xstore(T* p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
+#ifndef PDEOPT_COOP_UNROLL
+#define PDEOPT_COOP_UNROLL 2  // cells per trip of the stage loops (region_u)
+#endif
 #ifndef PDEOPT_COOP_THREADS
 #define PDEOPT_COOP_THREADS 512  // 1024 threads cap a thread at 128 registers: the step loop's uniform doubles then spill (48-140 B fp32)
 #endif
@@ -247,6 +250,57 @@ __global__ __launch_bounds__(PDEOPT_COOP_THREADS) void tsit5_coop_kernel(const C
       }
     }
   };
+  // The same cells, PDEOPT_COOP_UNROLL of them per trip: compute(o, r, c) -> value for each, THEN commit(o, r, c, value)
+  // for each.  A workgroup has 2 waves per SIMD: the LDS latency and the quarter-rate log / rcp / sqrt chains of one cell
+  // are not hidden by other waves, and inside `region` the compiler may not move the next cell's loads above this
+  // cell's LDS store (same address space).  With the loads of U cells issued before any store their chains overlap.
+  // Trips where every lane of the wave has all U cells (a scalar condition) run unrolled, the remainder one cell a trip.
+  auto region_u = [&](const int e, auto compute, auto commit) {
+    constexpr int U = PDEOPT_COOP_UNROLL;
+    const int wd = tw + 2 * e, total = (th + 2 * e) * wd;
+    const float inv = 1.0f / (float)wd;
+    int rr = (int)(((float)tid + 0.5f) * inv);
+    int cc = tid - rr * wd;
+    if (cc < 0) { cc += wd; --rr; }
+    if (cc >= wd) { cc -= wd; ++rr; }
+    const int dr = (int)(((float)NT + 0.5f) * inv), dc = NT - dr * wd;
+    int o = (rr - e + H) * P + (cc - e + H);
+    const int dO = dr * P + dc;
+    auto advance = [&]() {
+      rr += dr;
+      cc += dc;
+      o += dO;
+      if (cc >= wd) {
+        cc -= wd;
+        ++rr;
+        o += P - wd;
+      }
+    };
+    int idx = tid;
+    if constexpr (U > 1) {
+      int wave_first = __builtin_amdgcn_readfirstlane(idx);  // lane 0 holds the wave's smallest index
+      while (wave_first + 63 + (U - 1) * NT < total) {
+        int ou[U], ru[U], cu[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          ou[u] = o; ru[u] = rr - e; cu[u] = cc - e;
+          advance();
+        }
+        decltype(compute(0, 0, 0)) v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = compute(ou[u], ru[u], cu[u]);
+#pragma unroll
+        for (int u = 0; u < U; ++u) commit(ou[u], ru[u], cu[u], v[u]);
+        idx += U * NT;
+        wave_first += U * NT;
+      }
+    }
+    for (; idx < total; idx += NT) {
+      const auto v = compute(o, rr - e, cc - e);
+      commit(o, rr - e, cc - e, v);
+      advance();
+    }
+  };
   auto gidx = [&](int r, int c) -> int64_t { return (int64_t)wrap1(i0 + r, nx) * ny + wrap1(j0 + c, ny); };
 
   // ---- the state and the static fields on T + H
@@ -298,14 +352,14 @@ __global__ __launch_bounds__(PDEOPT_COOP_THREADS) void tsit5_coop_kernel(const C
   };
   auto pass1 = [&](const T* src, int e, T twa, T twb) {
     if constexpr (kTwoPass) {
-      region(e + 1, [&](int o, int, int) {
+      region_u(e + 1, [&](int o, int, int) -> T {
         if constexpr (EQ == PDEOPT_EQ_CAHN_HILLIARD) {
           const T c = src[o];
-          sM[o] = coop_mu<T, FAST>(a.mu, p.mu, c) - kap * lap_at<T>(c, src[o + P], src[o - P], src[o + 1], src[o - 1], a.rhx2, a.rhy2);
+          return coop_mu<T, FAST>(a.mu, p.mu, c) - kap * lap_at<T>(c, src[o + P], src[o - P], src[o + 1], src[o - 1], a.rhx2, a.rhy2);
         } else {
-          sM[o] = inner_at(src, o, twa, twb);
+          return inner_at(src, o, twa, twb);
         }
-      });
+      }, [&](int o, int, int, T v) { sM[o] = v; });
       __syncthreads();
     }
   };
@@ -441,13 +495,18 @@ __global__ __launch_bounds__(PDEOPT_COOP_THREADS) void tsit5_coop_kernel(const C
       if constexpr (kSBM && !kTwoPass) __syncthreads();  // every wave has read this stage's terms before thread 0 posts the next
       pass1(sW, e, twa, twb);
       T* const ks = sK + s * FS;
-      region(e, [&](int o, int, int) {
+      struct KW {
+        T k, w;
+      };
+      region_u(e, [&](int o, int, int) -> KW {
         const T k = kcell(sW, o, twa, twb, tsrc);
-        ks[o] = k;
         T r = sY[o];
 #pragma unroll
         for (int i = 0; i < s; ++i) r = r + cs[i] * sK[i * FS + o];
-        sV[o] = r + cs[s] * k;
+        return KW{k, r + cs[s] * k};
+      }, [&](int o, int, int, const KW& v) {
+        ks[o] = v.k;
+        sV[o] = v.w;
       });
       put_time_terms(t + kTsC[s] * h);  // the NEXT stage's time (its reads come after the barrier)
       __syncthreads();

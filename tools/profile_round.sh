@@ -7,7 +7,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $ROOT
 mkdir -p gpurun_out/round
 timeout 1500 bash tools/profile_gpu.sh round/ch_rk4_1024_f32 > /dev/null 2>&1
-SECONDARY="ac_rk4_512_f32 ch_imex_1024_f32 gpe_strang_512_c64 ch_rk4_1024_f64 ch_rk4_64_f32_small ch_rk4_128_f32_small ac_rk4_64_f32_small ch_sbm_1024_f32"
+SECONDARY="ac_rk4_512_f32 ch_imex_1024_f32 gpe_strang_512_c64 ch_rk4_1024_f64 ch_rk4_64_f32_small ch_rk4_128_f32_small ac_rk4_64_f32_small ch_sbm_1024_f32 ch3d_rk4_128_f32 ch_sbm_100_tsit5"
 for w in $SECONDARY; do
   timeout 400 bash tools/trace_only.sh round/$w --workload $w > gpurun_out/round/${w}_trace_summary.txt 2>&1
 done
@@ -26,7 +26,7 @@ timeout 900 bash tools/pmc_busy.sh busy > gpurun_out/busy_summary.txt 2>&1
 timeout 120 bash tools/make_pmc_json.sh $TAG
 cp profiles/pmc_$TAG.json gpurun_out/round/pmc_$TAG.json
 timeout 600 python bench.py > gpurun_out/round/bench.json 2> gpurun_out/round/bench.err
-for w in $SECONDARY gpe_strang_512_c64_spots ch_rk4_1024_f32_cubic ch_rk4_4096_decomp; do
+for w in $SECONDARY gpe_strang_512_c64_spots ch_rk4_1024_f32_cubic ch_rk4_4096_decomp ch_sbm_100_tsit5_f64 ad_64_tsit5; do
   timeout 400 python bench.py --workload $w --steps 5 --warmup 2 2>/dev/null | tail -1 > gpurun_out/round/bench_$w.json
 done
 timeout 300 python bench.py --workload ch_rk4_4096_decomp --virtual-ranks 4 --no-cpu-baseline --steps 5 --warmup 2 2>/dev/null | tail -1 > gpurun_out/round/bench_decomp_4_virtual_ranks_one_gpu.json
