@@ -46,6 +46,7 @@ struct pdeopt_local_group {
   uint64_t generation = 0;
   bool broken = false;
   std::vector<int> attached;          // rank taken?
+  std::vector<int> device;            // [rank] HIP device of the rank's ctx
   std::vector<void*> send[2];         // [parity][rank] strip buffers, published by their owners
   std::vector<size_t> send_bytes;     // [rank]
   std::vector<hipEvent_t> ready[2], done[2];
@@ -174,6 +175,7 @@ int comm_init_local(pdeopt_ctx* ctx, pdeopt_local_group* g, int rank) {
     if (rank < 0 || rank >= g->world) return fail(ctx, PDEOPT_EINVAL, "rank %d outside the local group of %d", rank, g->world);
     if (g->attached[rank]) return fail(ctx, PDEOPT_EINVAL, "rank %d of the local group is taken", rank);
     g->attached[rank] = 1;
+    g->device[rank] = ctx->device;
   }
   if (!ctx->comm) ctx->comm = new CommState();
   CommState& c = *ctx->comm;
@@ -302,6 +304,7 @@ pdeopt_local_group* local_group_new(int world) {
   auto* g = new pdeopt_local_group();
   g->world = world;
   g->attached.assign((size_t)world, 0);
+  g->device.assign((size_t)world, -1);
   g->send_bytes.assign((size_t)world, 0);
   for (int p = 0; p < 2; ++p) {
     g->send[p].assign((size_t)world, nullptr);
@@ -499,6 +502,66 @@ int rk4_decomposed_advance(pdeopt_ctx* ctx, double dt, int64_t n, const int* nbr
     if (c.local()) c.group->fail_all();  // the other ranks' threads must not wait for this one
     return code;
   };
+
+  // In-process ranks on ONE device: no copies at all.  A rank's kernel reads its neighbours' strips where their kernels
+  // wrote them (the fused unpack through the neighbours' OWN buffers, as in the peer-mapped exchange above) -- per substep
+  // and rank one kernel, the waits on the neighbours' `ready` events and one event record, instead of world copies of
+  // a strip into a gathered buffer.  Exchange e lives in send[e & 1]; the kernel that reads exchange e writes e + 1:
+  //   * it may read a neighbour's strip e once that neighbour's `ready` of e is reached (recorded behind the kernel /
+  //     the pack that wrote it; the host barrier orders the record before this rank's wait is enqueued);
+  //   * it overwrites this rank's strip e - 1, which the neighbours' kernels e - 1 read: those precede the neighbours'
+  //     `ready` of e in their streams -- the same wait.
+  // `done` (recorded behind every kernel) is what comm_destroy waits for before the buffers go.
+  bool same_device = c.local();
+  if (c.local()) {
+    std::lock_guard<std::mutex> lk(c.group->m);
+    for (int r = 0; r < c.world; ++r) same_device = same_device && c.group->device[r] == ctx->device;
+  }
+  if (ctx->halo == 8 && same_device && getenv("PDEOPT_LOCAL_GATHER") == nullptr) {
+    if (n <= 0) return PDEOPT_OK;
+    pdeopt_local_group& g = *c.group;
+    auto publish = [&]() -> int {  // exchange c.seq is complete in this rank's stream
+      const int p = (int)(c.seq & 1);
+      PDEOPT_HIP_CHECK(ctx, hipEventRecord(g.ready[p][c.rank], ctx->stream));
+      if (!g.barrier(60.0))
+        return fail(ctx, PDEOPT_ESTATE, "local group: a rank did not reach exchange %llu (every rank's host thread must be "
+                    "inside pdeopt_rk4_decomposed_advance at the same time, with the same substep count)", (unsigned long long)c.seq);
+      ++c.seq;
+      return PDEOPT_OK;
+    };
+    if ((rc = halo_pack(ctx, 0, c.send_buf()))) return abort_group(rc);
+    if ((rc = publish())) return abort_group(rc);
+    for (int64_t s = 0; s < n; ++s) {
+      const bool more = s + 1 < n;
+      const int p = (int)((c.seq - 1) & 1);  // parity of the exchange this substep reads
+      const void* peer[8];
+      {
+        std::lock_guard<std::mutex> lk(g.m);
+        for (int q = 0; q < 8; ++q) {
+          peer[q] = g.send[p][nbr[q]];
+          if (!peer[q] || g.send_bytes[nbr[q]] != c.strip_bytes) {
+            g.broken = true;
+            g.cv.notify_all();
+            return fail(ctx, PDEOPT_EINVAL, "local group: rank %d publishes a strip of %zu bytes, this rank expects %zu", nbr[q],
+                        g.send_bytes[nbr[q]], c.strip_bytes);
+          }
+        }
+      }
+      for (int q = 0; q < 8; ++q) {
+        bool seen = nbr[q] == c.rank;
+        for (int q2 = 0; q2 < q; ++q2) seen = seen || nbr[q2] == nbr[q];
+        if (!seen) PDEOPT_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, g.ready[p][nbr[q]], 0));
+      }
+      if ((rc = rk4_substep_h8_peer(ctx, dt, more ? c.send_buf() : nullptr, peer))) return abort_group(rc);
+      PDEOPT_HIP_CHECK(ctx, hipEventRecord(g.done[p][c.rank], ctx->stream));
+      {
+        std::lock_guard<std::mutex> lk(g.m);
+        g.done_recorded[p][c.rank] = 1;
+      }
+      if (more && (rc = publish())) return abort_group(rc);
+    }
+    return PDEOPT_OK;
+  }
 
   if (ctx->halo == 8) {
     // ONE exchange per substep (halo-8 layout):

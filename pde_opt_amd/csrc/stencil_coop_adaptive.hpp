@@ -154,6 +154,21 @@ __device__ __forceinline__ void xstore(T* p, T v) { __hip_atomic_store(p, v, __A
 #ifndef PDEOPT_COOP_UNROLL
 #define PDEOPT_COOP_UNROLL 2  // cells per trip of the stage loops (region_u)
 #endif
+// The cell loops' geometry (a thread's first row / column / LDS offset, the strides) is the same in every trial step, so
+// the compiler hoists all of it -- for each of the ~13 loops of a step -- out of the step loop and keeps it in registers
+// across the whole step: with 256 registers full the stage loops spill.  The empty asm statements make the thread index
+// and the tile width opaque at every loop entry: ~10 instructions per loop instead of ~5 live registers per loop.
+#ifndef PDEOPT_COOP_HOIST
+#define PDEOPT_COOP_FRESH_GEOMETRY \
+  int tid_ = tid, tw_ = __builtin_amdgcn_readfirstlane(tw); \
+  asm volatile("" : "+v"(tid_));                            \
+  asm volatile("" : "+s"(tw_))
+#else
+#define PDEOPT_COOP_FRESH_GEOMETRY const int tid_ = tid, tw_ = tw
+#endif
+#ifndef PDEOPT_COOP_RING_REGS
+#define PDEOPT_COOP_RING_REGS 6
+#endif
 #ifndef PDEOPT_COOP_THREADS
 #define PDEOPT_COOP_THREADS 512  // 1024 threads cap a thread at 128 registers: the step loop's uniform doubles then spill (48-140 B fp32)
 #endif
@@ -229,16 +244,17 @@ __global__ __launch_bounds__(PDEOPT_COOP_THREADS) void tsit5_coop_kernel(const C
   auto region = [&](const int e, auto f) {
     // (row, column) of a thread's cells are carried from one trip to the next: idx += NT is rr += NT / wd, cc += NT % wd
     // with one carry -- a division per trip was ~12 of the ~110 instructions a cell costs
-    const int wd = tw + 2 * e, total = (th + 2 * e) * wd;
+    PDEOPT_COOP_FRESH_GEOMETRY;
+    const int wd = tw_ + 2 * e, total = (th + 2 * e) * wd;
     const float inv = 1.0f / (float)wd;
-    int rr = (int)(((float)tid + 0.5f) * inv);
-    int cc = tid - rr * wd;
+    int rr = (int)(((float)tid_ + 0.5f) * inv);
+    int cc = tid_ - rr * wd;
     if (cc < 0) { cc += wd; --rr; }
     if (cc >= wd) { cc -= wd; ++rr; }
     const int dr = (int)(((float)NT + 0.5f) * inv), dc = NT - dr * wd;  // NT = dr wd + dc, 0 <= dc < wd (wd <= NT + ...: see below)
     int o = (rr - e + H) * P + (cc - e + H);
     const int dO = dr * P + dc;
-    for (int idx = tid; idx < total; idx += NT) {
+    for (int idx = tid_; idx < total; idx += NT) {
       f(o, rr - e, cc - e);
       rr += dr;
       cc += dc;
@@ -256,11 +272,13 @@ __global__ __launch_bounds__(PDEOPT_COOP_THREADS) void tsit5_coop_kernel(const C
   // cell's LDS store (same address space).  With the loads of U cells issued before any store their chains overlap.
   // Trips where every lane of the wave has all U cells (a scalar condition) run unrolled, the remainder one cell a trip.
   auto region_u = [&](const int e, auto compute, auto commit) {
-    constexpr int U = PDEOPT_COOP_UNROLL;
-    const int wd = tw + 2 * e, total = (th + 2 * e) * wd;
+    // (fp64 smoothed-boundary cells -- three software logarithms each -- fill the registers on their own: one a trip)
+    constexpr int U = (sizeof(T) == 8 && kSBM) ? 1 : PDEOPT_COOP_UNROLL;
+    PDEOPT_COOP_FRESH_GEOMETRY;
+    const int wd = tw_ + 2 * e, total = (th + 2 * e) * wd;
     const float inv = 1.0f / (float)wd;
-    int rr = (int)(((float)tid + 0.5f) * inv);
-    int cc = tid - rr * wd;
+    int rr = (int)(((float)tid_ + 0.5f) * inv);
+    int cc = tid_ - rr * wd;
     if (cc < 0) { cc += wd; --rr; }
     if (cc >= wd) { cc -= wd; ++rr; }
     const int dr = (int)(((float)NT + 0.5f) * inv), dc = NT - dr * wd;
@@ -276,7 +294,7 @@ __global__ __launch_bounds__(PDEOPT_COOP_THREADS) void tsit5_coop_kernel(const C
         o += P - wd;
       }
     };
-    int idx = tid;
+    int idx = tid_;
     if constexpr (U > 1) {
       int wave_first = __builtin_amdgcn_readfirstlane(idx);  // lane 0 holds the wave's smallest index
       while (wave_first + 63 + (U - 1) * NT < total) {
@@ -428,6 +446,57 @@ __global__ __launch_bounds__(PDEOPT_COOP_THREADS) void tsit5_coop_kernel(const C
       const int o = (r + H) * P + (c + H);
       if (srcy) sY[o] = vy;
       sK[o] = vk;
+    }
+  };
+
+  // The same ring, fetched into REGISTERS while the controller runs (one lane's double-precision pow: ~1.7 us in which
+  // every other wave waits): the candidate y1 / k7 of the neighbours are in the exchange buffers once the step's barrier
+  // has passed, whatever the decision will be.  ring_commit() stores them on accept; a rejected step drops them.
+  // ring cells per thread held in registers (larger rings: load_rings after the decision); fp64 -- two registers a value, smaller tiles -- half
+  constexpr int kRingRegs = sizeof(T) == 8 ? PDEOPT_COOP_RING_REGS / 2 : PDEOPT_COOP_RING_REGS;
+  const int ring_total = 2 * H * (tw + 2 * H) + 2 * H * th;
+  const bool ring_in_regs = kRingRegs > 0 && ring_total <= kRingRegs * NT;
+  T ring_y[kRingRegs > 0 ? kRingRegs : 1], ring_k[kRingRegs > 0 ? kRingRegs : 1];
+  auto ring_cell = [&](int idx, int* r, int* c) {
+    const int wd = tw + 2 * H, top = 2 * H * wd;
+    if (idx < top) {
+      int rr = (int)(((float)idx + 0.5f) * (1.0f / (float)wd));
+      int cc = idx - rr * wd;
+      if (cc < 0) { cc += wd; --rr; }
+      if (cc >= wd) { cc -= wd; ++rr; }
+      *r = rr < H ? rr - H : th + rr - H;
+      *c = cc - H;
+    } else {
+      const int i2 = idx - top;
+      const int rr = i2 / (2 * H), s2 = i2 - rr * (2 * H);
+      *r = rr;
+      *c = s2 < H ? s2 - H : tw + s2 - H;
+    }
+  };
+  auto ring_fetch = [&](const T* srcy, const T* srck) {
+#pragma unroll
+    for (int j = 0; j < kRingRegs; ++j) {
+      const int idx = tid + j * NT;
+      if (idx < ring_total) {
+        int r, c;
+        ring_cell(idx, &r, &c);
+        const int64_t g = gidx(r, c);
+        ring_y[j] = xload(&srcy[g]);
+        ring_k[j] = xload(&srck[g]);
+      }
+    }
+  };
+  auto ring_commit = [&]() {
+#pragma unroll
+    for (int j = 0; j < kRingRegs; ++j) {
+      const int idx = tid + j * NT;
+      if (idx < ring_total) {
+        int r, c;
+        ring_cell(idx, &r, &c);
+        const int o = (r + H) * P + (c + H);
+        sY[o] = ring_y[j];
+        sK[o] = ring_k[j];
+      }
     }
   };
 
@@ -606,6 +675,7 @@ __global__ __launch_bounds__(PDEOPT_COOP_THREADS) void tsit5_coop_kernel(const C
     if (aborted) return;
     PDEOPT_COOP_TICK(3);
     ++step;
+    if (ring_in_regs) ring_fetch(a.xy[cur ^ 1] + xoff, a.xk[cur ^ 1] + xoff);  // in flight under the controller
     // The controller: ONE lane per workgroup (the same arithmetic on the same partial sums in the same order in every
     // workgroup: one decision for the environment), broadcast through LDS -- all waves running the double-precision
     // pow / sqrt / divisions redundantly cost 6 us per step (14 k ticks), a lone lane ~1
@@ -654,7 +724,8 @@ __global__ __launch_bounds__(PDEOPT_COOP_THREADS) void tsit5_coop_kernel(const C
         sK[o] = sV[o];
       });
       cur ^= 1;
-      load_rings(a.xy[cur] + xoff, a.xk[cur] + xoff);
+      if (ring_in_regs) ring_commit();
+      else load_rings(a.xy[cur] + xoff, a.xk[cur] + xoff);
       t = uniform_f(t_new < a.t1 - 1e-14 * fmax(1.0, fabs(a.t1)) ? t_new : a.t1);
       prev_prev_inv = prev_inv;
       prev_inv = uniform_f(inv);

@@ -282,6 +282,39 @@ def test_peer_mapped_exchange_absent_rank_is_an_error_not_a_hang():
     assert res[0][0] == "error" and "did not publish" in res[0][1], res[0]
 
 
+@pytest.mark.parametrize("grid,tile,dtype", [((2, 2), (64, 128), np.float32), ((1, 2), (96, 256), np.float32), ((2, 2), (64, 128), np.float64)])
+def test_virtual_ranks_gathered_copy_path_equals_monolithic(grid, tile, dtype, monkeypatch):
+    """Ranks of one process on ONE device read each other's strips in place (no copies: the default, covered above); the
+    event-ordered device copies into a gathered buffer are what in-process ranks on DIFFERENT devices use.  One GPU here:
+    PDEOPT_LOCAL_GATHER keeps that path selectable -- bitwise the same result."""
+    monkeypatch.setenv("PDEOPT_LOCAL_GATHER", "1")
+    px, py = grid
+    tx, ty = tile
+    if dtype is np.float64:
+        ty //= 2
+    nx, ny = px * tx, py * ty
+    dom = std_domain(P, nx, ny)
+    eq = P.CahnHilliard2DPeriodic(dom, 0.002, MU["regsol"], MOB["c1mc"])
+    y0 = np.clip(0.5 + 0.05 * np.random.default_rng(11).standard_normal((nx, ny)), 0.05, 0.95).astype(dtype)
+    want, _ = _monolithic(eq, y0, 2e-7, 7, 0)
+    comms = LocalGroupComm.create(px * py)
+    solvers = []
+    for r in range(px * py):
+        s = DecomposedSolver(eq, CartesianGrid(px, py, r), comm=comms[r], dtype=dtype, backend=HipTileBackend(eq, (tx, ty), dtype, halo=8))
+        s.set_global_state(y0)
+        solvers.append(s)
+    advance_group(solvers, 2e-7, 4)
+    advance_group(solvers, 2e-7, 3)
+    got = np.empty_like(want)
+    for s in solvers:
+        si, sj = s.grid.tile_slices(nx, ny)
+        got[si, sj] = s.local_state()
+    np.testing.assert_array_equal(got, want)
+    for s in solvers:
+        s.backend.engine.close()
+    comms[0].group.close()
+
+
 def test_local_group_misuse_is_an_error_not_a_hang():
     """a rank whose partners never arrive fails with a message (the rendezvous has a time-out; here a rank count
     mismatch is detected before any waiting)"""

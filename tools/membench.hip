@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -64,8 +65,11 @@ int run(const char* name, f32x4** buf, size_t n, int per_thread) {
   return 0;
 }
 
-int main() {
-  const size_t n = (size_t)32 * 1024 * 1024 / 4;  // 32 envs x 1024^2 floats = 128 MiB per array
+int main(int argc, char** argv) {
+  // MiB per array (default 128 = 32 envs x 1024^2 floats: HBM streams; 64 = BASELINE config 2's 64 x 512^2 state, whose
+  // read + write arrays stay resident in the 256 MiB Infinity Cache: the ceiling of the whole-substep kernels)
+  const size_t mib = argc > 1 ? (size_t)atoi(argv[1]) : 128;
+  const size_t n = mib * 1024 * 1024 / 16;
   f32x4* buf[5];
   for (auto& p : buf) {
     CK(hipMalloc((void**)&p, n * 16));
