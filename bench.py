@@ -408,7 +408,7 @@ def run_decomp(args, P, world, rank, local_rank, dist, make_solver=None):
     sol = sols[0]
     engines = [s_.backend.engine for s_ in sols]
     eng = engines[0]
-    if args.tile_rows and on_gpu:
+    if getattr(args, "tile_rows", 0) and on_gpu:
         for e in engines:
             e.set_tile_rows(args.tile_rows)
 

@@ -104,9 +104,22 @@ int launch_generic(pdeopt_ctx* ctx, const StageArgs<T>& s) {
     if (rc) return rc;
     StageArgs<T> s3 = s;
     s3.mu3 = static_cast<const T*>(ctx->KS) + (int64_t)ctx->win_lo * s.g.bstride;
-    hipLaunchKernelGGL(ch3d_mu_kernel<T>, g3, block, 0, ctx->stream, s3, const_cast<T*>(s3.mu3));
-    hipLaunchKernelGGL(ch3d_stage_kernel<T>, g3, block, 0, ctx->stream, s3);
-    ctx->last_kernel = "stage_generic<CH-3D>";
+    switch (classify_closures(p.mu, p.mob)) {
+      case CL_POLY:
+        hipLaunchKernelGGL((ch3d_mu_kernel<T, CL_POLY>), g3, block, 0, ctx->stream, s3, const_cast<T*>(s3.mu3));
+        hipLaunchKernelGGL((ch3d_stage_kernel<T, CL_POLY>), g3, block, 0, ctx->stream, s3);
+        ctx->last_kernel = "stage_generic<CH-3D,poly>";
+        break;
+      case CL_LOGIT:
+        hipLaunchKernelGGL((ch3d_mu_kernel<T, CL_LOGIT>), g3, block, 0, ctx->stream, s3, const_cast<T*>(s3.mu3));
+        hipLaunchKernelGGL((ch3d_stage_kernel<T, CL_LOGIT>), g3, block, 0, ctx->stream, s3);
+        ctx->last_kernel = "stage_generic<CH-3D,logit>";
+        break;
+      default:
+        hipLaunchKernelGGL((ch3d_mu_kernel<T, CL_GENERIC>), g3, block, 0, ctx->stream, s3, const_cast<T*>(s3.mu3));
+        hipLaunchKernelGGL((ch3d_stage_kernel<T, CL_GENERIC>), g3, block, 0, ctx->stream, s3);
+        ctx->last_kernel = "stage_generic<CH-3D>";
+    }
     PDEOPT_HIP_CHECK(ctx, hipGetLastError());
     return PDEOPT_OK;
   }

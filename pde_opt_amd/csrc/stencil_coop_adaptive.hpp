@@ -151,21 +151,25 @@ __device__ __forceinline__ T xload(const T* p) { return __hip_atomic_load(p, __A
 template <typename T>
 __device__ __forceinline__ void xstore(T* p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
+// cells per trip of the stage loops (region_u).  Measured on the 100^2 smoothed-boundary solve (profiles/r04_adaptive_variants_ab.txt):
+// 1, 2 and 4 cells a trip, 512 or 768 threads, hoisted or fresh loop geometry all land within 16.4 - 18.4 us per trial step,
+// inside the run-to-run spread of one build (~1 us): the stage loops are bound neither by VALU issue (27 % of the step's
+// cycles, SQ_INSTS_VALU) nor by the LDS pipe (33 %, SQ_LDS_IDX_ACTIVE) but by the 16 workgroup barriers of a step and the
+// dependent LDS -> VALU chains between them.  One cell a trip is the smallest code.
 #ifndef PDEOPT_COOP_UNROLL
-#define PDEOPT_COOP_UNROLL 2  // cells per trip of the stage loops (region_u)
+#define PDEOPT_COOP_UNROLL 1
 #endif
 // The cell loops' geometry (a thread's first row / column / LDS offset, the strides) is the same in every trial step, so
 // the compiler hoists all of it -- for each of the ~13 loops of a step -- out of the step loop and keeps it in registers
-// across the whole step: with 256 registers full the stage loops spill.  The empty asm statements make the thread index
-// and the tile width opaque at every loop entry: ~10 instructions per loop instead of ~5 live registers per loop.
-#ifndef PDEOPT_COOP_HOIST
-#define PDEOPT_COOP_FRESH_GEOMETRY \
+// across the whole step: the smoothed-boundary forms then sit at exactly 256 registers, and anything added spills.  The
+// empty asm statements make the thread index and the tile width opaque at a loop's entry: ~10 instructions per loop
+// instead of ~5 live registers per loop.  Applied to the loops OUTSIDE the stages (load, stage-2 input, stage 7, dense
+// output, accept, store: `region`); the five stage loops (`region_u`) keep their hoisted geometry unless
+// -DPDEOPT_COOP_FRESH (measured: neither faster nor slower beyond the run-to-run spread).
+#define PDEOPT_COOP_OPAQUE_GEOMETRY                         \
   int tid_ = tid, tw_ = __builtin_amdgcn_readfirstlane(tw); \
   asm volatile("" : "+v"(tid_));                            \
   asm volatile("" : "+s"(tw_))
-#else
-#define PDEOPT_COOP_FRESH_GEOMETRY const int tid_ = tid, tw_ = tw
-#endif
 #ifndef PDEOPT_COOP_RING_REGS
 #define PDEOPT_COOP_RING_REGS 6
 #endif
@@ -244,7 +248,7 @@ __global__ __launch_bounds__(PDEOPT_COOP_THREADS) void tsit5_coop_kernel(const C
   auto region = [&](const int e, auto f) {
     // (row, column) of a thread's cells are carried from one trip to the next: idx += NT is rr += NT / wd, cc += NT % wd
     // with one carry -- a division per trip was ~12 of the ~110 instructions a cell costs
-    PDEOPT_COOP_FRESH_GEOMETRY;
+    PDEOPT_COOP_OPAQUE_GEOMETRY;
     const int wd = tw_ + 2 * e, total = (th + 2 * e) * wd;
     const float inv = 1.0f / (float)wd;
     int rr = (int)(((float)tid_ + 0.5f) * inv);
@@ -271,10 +275,14 @@ __global__ __launch_bounds__(PDEOPT_COOP_THREADS) void tsit5_coop_kernel(const C
   // are not hidden by other waves, and inside `region` the compiler may not move the next cell's loads above this
   // cell's LDS store (same address space).  With the loads of U cells issued before any store their chains overlap.
   // Trips where every lane of the wave has all U cells (a scalar condition) run unrolled, the remainder one cell a trip.
-  auto region_u = [&](const int e, auto compute, auto commit) {
-    // (fp64 smoothed-boundary cells -- three software logarithms each -- fill the registers on their own: one a trip)
-    constexpr int U = (sizeof(T) == 8 && kSBM) ? 1 : PDEOPT_COOP_UNROLL;
-    PDEOPT_COOP_FRESH_GEOMETRY;
+  auto region_n = [&](auto u_c, auto opaque_c, const int e, auto compute, auto commit) {
+    constexpr int U = decltype(u_c)::value;
+    int tid_ = tid, tw_ = tw;
+    if constexpr (decltype(opaque_c)::value) {  // (PDEOPT_COOP_OPAQUE_GEOMETRY)
+      tw_ = __builtin_amdgcn_readfirstlane(tw);
+      asm volatile("" : "+v"(tid_));
+      asm volatile("" : "+s"(tw_));
+    }
     const int wd = tw_ + 2 * e, total = (th + 2 * e) * wd;
     const float inv = 1.0f / (float)wd;
     int rr = (int)(((float)tid_ + 0.5f) * inv);
@@ -318,6 +326,22 @@ __global__ __launch_bounds__(PDEOPT_COOP_THREADS) void tsit5_coop_kernel(const C
       commit(o, rr - e, cc - e, v);
       advance();
     }
+  };
+  // the five stage loops: PDEOPT_COOP_UNROLL cells a trip (fp64 smoothed-boundary cells -- three software logarithms each
+  // -- fill the registers on their own: one a trip), geometry hoisted unless -DPDEOPT_COOP_FRESH
+  auto region_u = [&](const int e, auto compute, auto commit) {
+    constexpr int U = (sizeof(T) == 8 && kSBM) ? 1 : PDEOPT_COOP_UNROLL;
+#ifdef PDEOPT_COOP_FRESH
+    region_n(std::integral_constant<int, U>{}, std::true_type{}, e, compute, commit);
+#else
+    region_n(std::integral_constant<int, U>{}, std::false_type{}, e, compute, commit);
+#endif
+  };
+  // the short pointwise passes (stage-2 input, accept): a trip is two LDS reads, one multiply-add and a write, all
+  // latency -- four cells' loads issued before the first store instead of four dependent round trips (a trip cost
+  // ~500 ticks: the stage-2 input pass alone was 1.9 k of a step's 39 k)
+  auto region_4 = [&](const int e, auto compute, auto commit) {
+    region_n(std::integral_constant<int, 4>{}, std::true_type{}, e, compute, commit);
   };
   auto gidx = [&](int r, int c) -> int64_t { return (int64_t)wrap1(i0 + r, nx) * ny + wrap1(j0 + c, ny); };
 
@@ -449,9 +473,11 @@ __global__ __launch_bounds__(PDEOPT_COOP_THREADS) void tsit5_coop_kernel(const C
     }
   };
 
-  // The same ring, fetched into REGISTERS while the controller runs (one lane's double-precision pow: ~1.7 us in which
-  // every other wave waits): the candidate y1 / k7 of the neighbours are in the exchange buffers once the step's barrier
-  // has passed, whatever the decision will be.  ring_commit() stores them on accept; a rejected step drops them.
+  // The same ring through REGISTERS on an accepted step: load_rings' loop waits for a trip's loads before it stores them,
+  // so a thread's 3 trips are 3 global-memory latencies in a row (~4 k ticks of the step's ~39 k); ring_fetch issues
+  // all of a thread's loads, ring_commit stores them.  (-DPDEOPT_COOP_RING_EARLY fetches before the controller -- the
+  // candidate y1 / k7 are in the exchange buffers once the step's barrier has passed, whatever the decision -- to hide
+  // the loads under the controller's pow: measured slower, see below.)
   // ring cells per thread held in registers (larger rings: load_rings after the decision); fp64 -- two registers a value, smaller tiles -- half
   constexpr int kRingRegs = sizeof(T) == 8 ? PDEOPT_COOP_RING_REGS / 2 : PDEOPT_COOP_RING_REGS;
   const int ring_total = 2 * H * (tw + 2 * H) + 2 * H * th;
@@ -473,10 +499,14 @@ __global__ __launch_bounds__(PDEOPT_COOP_THREADS) void tsit5_coop_kernel(const C
       *c = s2 < H ? s2 - H : tw + s2 - H;
     }
   };
+  // (the cells' coordinates are the same in every step: the opaque copy of the thread index keeps the compiler from
+  // carrying all of them in registers across the whole step loop, where the stage loops then spill)
   auto ring_fetch = [&](const T* srcy, const T* srck) {
+    int tid_ = tid;
+    asm volatile("" : "+v"(tid_));
 #pragma unroll
     for (int j = 0; j < kRingRegs; ++j) {
-      const int idx = tid + j * NT;
+      const int idx = tid_ + j * NT;
       if (idx < ring_total) {
         int r, c;
         ring_cell(idx, &r, &c);
@@ -487,9 +517,11 @@ __global__ __launch_bounds__(PDEOPT_COOP_THREADS) void tsit5_coop_kernel(const C
     }
   };
   auto ring_commit = [&]() {
+    int tid_ = tid;
+    asm volatile("" : "+v"(tid_));
 #pragma unroll
     for (int j = 0; j < kRingRegs; ++j) {
-      const int idx = tid + j * NT;
+      const int idx = tid_ + j * NT;
       if (idx < ring_total) {
         int r, c;
         ring_cell(idx, &r, &c);
@@ -530,6 +562,7 @@ __global__ __launch_bounds__(PDEOPT_COOP_THREADS) void tsit5_coop_kernel(const C
   double t = a.t0, dt = a.dt0, prev_inv = 1.0, prev_prev_inv = 1.0;
   int64_t accepted = 0, rejected = 0;
   int qi = 0, status = PDEOPT_TSIT5_DONE;
+  double next_tq = uniform_f(a.n_save > 0 ? a.save_ts[0] : __builtin_inf());
   unsigned step = 0;
   while (t < a.t1) {
     if (accepted + rejected >= a.max_steps) {
@@ -546,7 +579,7 @@ __global__ __launch_bounds__(PDEOPT_COOP_THREADS) void tsit5_coop_kernel(const C
     // stage 2 input on T + 6 R (where k1 lives)
     {
       const T c0 = T(h * kTsA[0][0]);
-      region(H, [&](int o, int, int) { sW[o] = sY[o] + c0 * sK[o]; });
+      region_4(H, [&](int o, int, int) -> T { return sY[o] + c0 * sK[o]; }, [&](int o, int, int, T v) { sW[o] = v; });
     }
     put_time_terms(t + kTsC[0] * h);
     __syncthreads();
@@ -642,6 +675,7 @@ __global__ __launch_bounds__(PDEOPT_COOP_THREADS) void tsit5_coop_kernel(const C
       }
       if (tid < 64) {
         const unsigned long long t_in = __builtin_amdgcn_s_memrealtime();
+        bool gave_up = false;
         for (int i = tid; i < nwg; i += 64) {
           const unsigned long long* const slot = reinterpret_cast<const unsigned long long*>(parts) + 2 * i;
           unsigned long long w0, w1;
@@ -649,18 +683,27 @@ __global__ __launch_bounds__(PDEOPT_COOP_THREADS) void tsit5_coop_kernel(const C
             w0 = xload(&slot[0]);
             w1 = xload(&slot[1]);
             if ((unsigned)w0 == tag && (unsigned)w1 == tag) break;
-            if (xload(a.abort_flag) != 0u) break;
+            if (xload(a.abort_flag) != 0u) {
+              gave_up = true;
+              break;
+            }
             if (__builtin_amdgcn_s_memrealtime() - t_in > kCoopTimeoutTicks) {
               xstore(a.abort_flag, 1u);
+              gave_up = true;
               break;
             }
             __builtin_amdgcn_s_sleep(1);
           }
           red[24 + i] = __longlong_as_double((long long)((w0 & 0xffffffff00000000ull) | (w1 >> 32)));
         }
+        // The abort flag is only ever looked at while a slot is missing: a step whose slots all arrived needs no
+        // global-memory round trip to learn that nobody gave up (an abort raised elsewhere after this workgroup passed
+        // is met at the next step's poll, where the partner's slot stays missing)
+        const bool any = __any(gave_up);
+        if (tid == 0) red[22] = any ? 1.0 : 0.0;
       }
       __syncthreads();
-      aborted = xload(a.abort_flag) != 0u;
+      aborted = red[22] != 0.0;
     } else {
       if (tid == 0) {
         double sum = 0.0;
@@ -675,7 +718,9 @@ __global__ __launch_bounds__(PDEOPT_COOP_THREADS) void tsit5_coop_kernel(const C
     if (aborted) return;
     PDEOPT_COOP_TICK(3);
     ++step;
+#ifdef PDEOPT_COOP_RING_EARLY  // (measured slower: the fetched values live across the dense-output code and spill)
     if (ring_in_regs) ring_fetch(a.xy[cur ^ 1] + xoff, a.xk[cur ^ 1] + xoff);  // in flight under the controller
+#endif
     // The controller: ONE lane per workgroup (the same arithmetic on the same partial sums in the same order in every
     // workgroup: one decision for the environment), broadcast through LDS -- all waves running the double-precision
     // pow / sqrt / divisions redundantly cost 6 us per step (14 k ticks), a lone lane ~1
@@ -701,7 +746,7 @@ __global__ __launch_bounds__(PDEOPT_COOP_THREADS) void tsit5_coop_kernel(const C
       ++accepted;
       const double t_new = t + h;
       while (qi < a.n_save) {
-        const double tq = a.save_ts[qi];
+        const double tq = next_tq;  // (a.save_ts[qi], loaded when qi last moved: not a global-memory round trip per step)
         if (!(tq <= t_new + 1e-14 * fmax(1.0, fabs(t_new)))) break;
         double bw[7];
         tsit5_dense_weights(fmin(1.0, fmax(0.0, (tq - t) / h)), bw);
@@ -717,15 +762,25 @@ __global__ __launch_bounds__(PDEOPT_COOP_THREADS) void tsit5_coop_kernel(const C
           out[(int64_t)(i0 + r) * ny + (j0 + c)] = rv;
         });
         ++qi;
+        next_tq = uniform_f(qi < a.n_save ? a.save_ts[qi] : __builtin_inf());
       }
       // y <- y1, k1 <- k7 (FSAL): the tile from LDS, the halo ring from the neighbours' tiles
-      region(0, [&](int o, int, int) {
-        sY[o] = sW[o];
-        sK[o] = sV[o];
+      struct YK {
+        T y, k;
+      };
+      region_4(0, [&](int o, int, int) -> YK { return YK{sW[o], sV[o]}; }, [&](int o, int, int, const YK& v) {
+        sY[o] = v.y;
+        sK[o] = v.k;
       });
       cur ^= 1;
-      if (ring_in_regs) ring_commit();
-      else load_rings(a.xy[cur] + xoff, a.xk[cur] + xoff);
+      if (ring_in_regs) {
+#ifndef PDEOPT_COOP_RING_EARLY
+        ring_fetch(a.xy[cur] + xoff, a.xk[cur] + xoff);  // every load of the thread's ring cells in flight at once
+#endif
+        ring_commit();
+      } else {
+        load_rings(a.xy[cur] + xoff, a.xk[cur] + xoff);
+      }
       t = uniform_f(t_new < a.t1 - 1e-14 * fmax(1.0, fabs(a.t1)) ? t_new : a.t1);
       prev_prev_inv = prev_inv;
       prev_inv = uniform_f(inv);

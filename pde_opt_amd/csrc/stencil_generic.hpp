@@ -341,9 +341,11 @@ __global__ __launch_bounds__(256) void sbm_ch_stage_kernel(const StageArgs<T> a)
 // CahnHilliard3DPeriodic.rhs_fd (cahn_hilliard.py:180-200), fields [b][nx][ny][nz] with z contiguous.
 // Two passes: mu = mu_h(u) - kappa lap7(u) into a work field, then k = div(D grad mu) from the 7-point
 // neighbourhoods of mu and u with the stage update fused in.  (One thread per cell; the 32^3 - 64^3
-// problems this class is used for upstream are launch-bound, not bandwidth-bound.)
+// problems this class is used for upstream are launch-bound, not bandwidth-bound.)  CL: the closure class of the 2-D
+// kernels (closures.hpp: fixed polynomial / logit forms unrolled; CL_GENERIC walks the family at run time -- with it the
+// stage kernel spent 340 VALU instructions per cell, most of them in the seven mobility evaluations).
 // ---------------------------------------------------------------------------------------------------
-template <typename T>
+template <typename T, int CL>
 __global__ __launch_bounds__(256) void ch3d_mu_kernel(const StageArgs<T> a, T* __restrict__ mu_out) {
   const int nx = a.g.nx, ny = a.g.ny, nz = a.g.nz;
   const int k = blockIdx.x * 64 + threadIdx.x;
@@ -359,10 +361,10 @@ __global__ __launch_bounds__(256) void ch3d_mu_kernel(const StageArgs<T> a, T* _
   const T c = U(i, j, k);
   const T lap = (U(ip, j, k) - T(2) * c + U(im, j, k)) * a.rhx2 + (U(i, jp, k) - T(2) * c + U(i, jm, k)) * a.rhy2 +
                 (U(i, j, kp) - T(2) * c + U(i, j, km)) * a.rhz2;
-  mu_out[(int64_t)b * a.g.bstride + ((int64_t)i * ny + j) * nz + k] = closure_generic<T>(a.mu, p.mu, c) - p.kappa * lap;
+  mu_out[(int64_t)b * a.g.bstride + ((int64_t)i * ny + j) * nz + k] = eval_mu<T, CL>(a.mu, p.mu, c) - p.kappa * lap;
 }
 
-template <typename T>
+template <typename T, int CL>
 __global__ __launch_bounds__(256) void ch3d_stage_kernel(const StageArgs<T> a) {
   const int nx = a.g.nx, ny = a.g.ny, nz = a.g.nz;
   const int k = blockIdx.x * 64 + threadIdx.x;
@@ -378,10 +380,10 @@ __global__ __launch_bounds__(256) void ch3d_stage_kernel(const StageArgs<T> a) {
   const int jp = (j + 1 == ny) ? 0 : j + 1, jm = (j == 0) ? ny - 1 : j - 1;
   const int kp = (k + 1 == nz) ? 0 : k + 1, km = (k == 0) ? nz - 1 : k - 1;
   const int64_t c0 = at(i, j, k);
-  const T m0 = m[c0], d0 = closure_generic<T>(a.mob, p.mob, u[c0]);
+  const T m0 = m[c0], d0 = eval_mob<T, CL>(a.mob, p.mob, u[c0]);
   // flux through the face between this cell and a neighbour: avg_face(D) * grad_face(mu)
   auto flux = [&](int64_t n, T rh, bool plus) -> T {
-    const T dn = closure_generic<T>(a.mob, p.mob, u[n]);
+    const T dn = eval_mob<T, CL>(a.mob, p.mob, u[n]);
     const T g = plus ? (m[n] - m0) * rh : (m0 - m[n]) * rh;
     return (T(0.5) * (plus ? (d0 + dn) : (dn + d0))) * g;
   };
@@ -392,6 +394,10 @@ __global__ __launch_bounds__(256) void ch3d_stage_kernel(const StageArgs<T> a) {
   if (a.scaled) kk *= p.kscale;
   stage_update<T>(a, base + c0, kk);
 }
+
+// (A single-pass LDS-brick form -- u on an 8 x 8 x 64 brick + 2 and mu on the brick + 1 in LDS, one launch per stage --
+// was built and measured in round 4: bitwise equal, 249 us per stage of 8 x 128^3 against 146 us for the two passes above.
+// Its 65 KB of LDS leave 8 waves per CU; the two simple kernels run 32 and find their neighbours in L1 / L2.  Removed.)
 
 // jit.hip: closures compiled at run time (PDEOPT_CL_JIT; pdeopt_set_jit_closures)
 bool jit_closures_active(const pdeopt_ctx* ctx);

@@ -56,6 +56,39 @@ def test_explicit_trajectory_vs_oracle(solver):
         assert abs(sol.ys[-1][b].mean() - y0[b].mean()) < 1e-14  # flux form conserves the mean
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("closures", ["regsol", "cubic", "legendre"])
+def test_closure_classes_of_the_3d_kernels_vs_oracle(dtype, closures):
+    """the 3-D kernels are instantiated per closure class (fixed polynomial / logit forms unrolled, run-time walk for the
+    rest of the family): each against the numpy oracle on a grid that does not fill the launch's blocks"""
+    nx, ny, nz = 18, 9, 70
+    dom = _dom(nx, ny, nz)
+    hx, hy, hz = dom.dx
+    if closures == "legendre":
+        mu = P.ChemicalPotentialLegendrePolynomials(np.array([0.0, 0.3, -0.1, 0.05, 0.02, -0.01]), prior_fn=lambda c: np.log(c / (1.0 - c)))
+        mob = MOB["c1mc"]
+    elif closures == "cubic":
+        mu, mob = MU["cubic"], (lambda c: 1.0 + c * c)
+    else:
+        mu, mob = MU["regsol"], MOB["c1mc"]
+    eq = P.CahnHilliard3DPeriodic(dom, 0.002, mu, mob)
+    rng = np.random.default_rng(3)
+    y0 = np.clip(0.5 + 0.05 * rng.standard_normal((2, nx, ny, nz)), 0.05, 0.95).astype(dtype)
+    sol = P.diffeqsolve(eq, P.RK4(), 0.0, 3e-7, 1e-7, y0)
+    want_tag = {"regsol": "CH-3D,logit", "cubic": "CH-3D,poly", "legendre": "CH-3D>"}[closures]
+    assert want_tag in sol.stats["kernel"], sol.stats["kernel"]
+    f = lambda t, u: O.ch3d_rhs_fd(u, hx, hy, hz, 0.002, mu, mob)
+    for b in range(2):
+        ref = y0[b].astype(np.float64)
+        for i in range(3):
+            ref = O.rk4_step(f, 0.0, ref, 1e-7)
+        got = sol.ys[-1][b].astype(np.float64)
+        if dtype is np.float64:
+            assert rel_l2(got - y0[b], ref - y0[b]) < 1e-10, (closures, b)
+        else:  # the fp32 state's own rounding (6e-8) is the floor of an increment this small
+            assert np.max(np.abs(got - ref)) < 1e-6, (closures, b, float(np.max(np.abs(got - ref))))
+
+
 def test_long_run_replays_the_substep_graph():
     """>= 32 substeps of a small grid replay a captured hipGraph (two kernels per stage in 3-D)"""
     rng = np.random.default_rng(6)

@@ -30,10 +30,11 @@ def _pick(res, prefix):
 # moved to LDS what is left over the 256 of a 512-thread workgroup is <= 42 dwords of rarely touched controller
 # state.  The alternatives measured worse on paper: 256 threads x 8 vectors runs one wave per SIMD.
 # The multi-workgroup adaptive kernel (stencil_coop_adaptive.hpp; 512 threads, 256 registers each): the fp32 fixed-closure
-# instantiations -- the notebook workloads -- hold everything in registers; the fp64 smoothed-boundary forms spill a
+# instantiations -- the notebook workloads -- hold everything in registers but for one register of step-loop state of the
+# smoothed-boundary Cahn-Hilliard form (8 B); the fp64 smoothed-boundary forms spill a
 # little (five stage bodies with their hoisted constants in one kernel), the run-time closure walk (Legendre recurrences
 # in a loop, fp64) is the rare path and may spill more.
-SCRATCH_ALLOWED = [("small_tsit5_kernel<", ", 4, 512>", 192), ("tsit5_coop_kernel<float, ", ", true>", 0),
+SCRATCH_ALLOWED = [("small_tsit5_kernel<", ", 4, 512>", 192), ("tsit5_coop_kernel<float, ", ", true>", 16),
                    ("tsit5_coop_kernel<float, ", ", false>", 96), ("tsit5_coop_kernel<double, ", ", true>", 256),
                    ("tsit5_coop_kernel<double, ", ", false>", 1280)]
 
