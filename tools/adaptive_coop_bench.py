@@ -43,7 +43,7 @@ def cases():
 
     rng = np.random.default_rng(0)
     yield "advection-diffusion 64^2 (run_advection_diffusion.ipynb:84)", P.AdvectionDiffusion2D(dom, vel, 0.1, time_dependent=False), 0.5 + 0.01 * rng.standard_normal((n, n)), 2.0, 1e-5
-    for n in (64, 100, 128):
+    for n in (64, 100, 128, 192, 256, 384, 512):  # up to 200^2 one XCD's L2; beyond: several XCDs, fenced barrier
         dom = P.Domain((n, n), ((-0.005 * n, 0.005 * n),) * 2, "dimensionless")
         yield f"CH periodic {n}^2", P.CahnHilliard2DPeriodic(dom, 0.002, MU, D), np.clip(0.5 + 0.05 * rng.standard_normal((n, n)), 0.05, 0.95), 1e-4, 1e-7
 

@@ -20,6 +20,8 @@ cp gpurun_out/busy_summary.txt profiles/${TAG}_pmc_busy.txt
 [ -f gpurun_out/adaptive_coop_bench.txt ] && grep -v "coop prof" gpurun_out/adaptive_coop_bench.txt > profiles/${TAG}_adaptive_multi_workgroup.txt
 [ -f gpurun_out/ab_adaptive_r04.txt ] && cp gpurun_out/ab_adaptive_r04.txt profiles/${TAG}_adaptive_variants_ab.txt
 [ -f gpurun_out/membench_64MiB.txt ] && cat gpurun_out/membench_64MiB.txt > profiles/${TAG}_membench_cache_resident_64MiB.txt
+[ -f gpurun_out/peer_mapped_bench.txt ] && cp gpurun_out/peer_mapped_bench.txt profiles/${TAG}_peer_mapped_processes_one_gpu.txt
+[ -f gpurun_out/adaptive_coop_larger_grids.txt ] && cp gpurun_out/adaptive_coop_larger_grids.txt profiles/${TAG}_adaptive_larger_grids.txt
 [ -f gpurun_out/single_env_latency.txt ] && cp gpurun_out/single_env_latency.txt profiles/${TAG}_single_env_latency.txt
 bash tools/make_pmc_json.sh ${TAG}
 for f in stencil.hip strang_fused.hip; do python tools/kernel_resources.py $f > /tmp/kres_$f.txt; done
