@@ -242,7 +242,10 @@ __global__ __launch_bounds__(PDEOPT_COOP_THREADS) void tsit5_coop_kernel(const C
   const int64_t xoff = (int64_t)be * nx * ny;
   unsigned* const bar = a.bar + 2 * be;
   unsigned gen = 0;
-  const bool one_xcd = a.xs == 1;
+#ifndef PDEOPT_COOP_XCD_FENCES
+#define PDEOPT_COOP_XCD_FENCES 1
+#endif
+  const bool one_xcd = a.xs == 1 || !PDEOPT_COOP_XCD_FENCES;  // (0: experiment -- scoped accesses alone across XCDs)
 
   // cells of the region T + e, local coordinates (r, c) relative to the tile origin: f(LDS offset, r, c)
   auto region = [&](const int e, auto f) {
