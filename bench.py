@@ -684,6 +684,9 @@ ADAPTIVE = {
     # PIDController(rtol 1e-4, atol 1e-6), 117 890 steps over t = 0 .. 0.1 with 200 saves upstream: a prefix of that solve
     # with the same save spacing (one save per 5e-4)
     "ch_sbm_100_tsit5": dict(n=100, dtype=np.float32, t1=2e-3, dt0=1e-6, nsave=5, rtol=1e-4, atol=1e-6),
+    # notebooks/smooth_boundary.ipynb:397: the second solve of the notebook, contact angle theta(t) a quadratic in t (352 104 steps
+    # upstream): the kernel evaluates cos theta at its own stage times
+    "ch_sbm_100_tsit5_theta": dict(n=100, dtype=np.float32, t1=2e-3, dt0=1e-6, nsave=5, rtol=1e-4, atol=1e-6),
     "ch_sbm_100_tsit5_f64": dict(n=100, dtype=np.float64, t1=2e-3, dt0=1e-6, nsave=5, rtol=1e-4, atol=1e-6),
     # notebooks/run_advection_diffusion.ipynb:84: advection-diffusion 64^2 (8 950 steps upstream)
     "ad_64_tsit5": dict(n=64, dtype=np.float32, t1=0.4, dt0=1e-5, nsave=2, rtol=1e-4, atol=1e-6),
@@ -700,7 +703,8 @@ def adaptive_problem(P, name):
         r = np.sqrt((xx - n / 2) ** 2 + (yy - n / 2) ** 2)
         psi = np.maximum(1e-3, 0.5 * (1.0 + np.tanh((20.0 - r) / 3.0)))  # a disc of the notebook's size as a smooth level set
         dom = P.Domain((n, n), ((-0.5, 0.5), (-0.5, 0.5)), "dimensionless", geometry=types.SimpleNamespace(smooth=psi))
-        eq = P.CahnHilliard2DSmoothedBoundary(dom, 0.002, SBM_F, REGSOL, C1MC, lambda t: np.pi / 2.0, lambda t: 0.0)
+        theta = SBM_THETA if name.endswith("_theta") else (lambda t: np.pi / 2.0)
+        eq = P.CahnHilliard2DSmoothedBoundary(dom, 0.002, SBM_F, REGSOL, C1MC, theta, lambda t: 0.0)
         y0 = 0.9 * np.ones((n, n))
         y0[:, : n // 2] = 0.1
         return eq, y0

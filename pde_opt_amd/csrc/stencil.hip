@@ -342,6 +342,15 @@ static bool small_chosen(const pdeopt_ctx* ctx, int integrator, int64_t n) {
 
 int advance_explicit(pdeopt_ctx* ctx, int integrator, double t0, double dt, int64_t n) {
   int rc;
+  // one environment (or a few) of a mid-sized grid: several compute units per environment, all substeps in one launch
+  // (stencil_coop_adaptive.hpp, MODE 1)
+  const bool coop = ctx->prob.dtype == PDEOPT_F32 ? coop_fixed_chosen<float>(ctx, integrator, n) : coop_fixed_chosen<double>(ctx, integrator, n);
+  if (coop && (ctx->opt_small_persist == 2 || !small_chosen(ctx, integrator, n))) {
+    ctx->win_lo = 0;
+    ctx->win_n = ctx->prob.batch;
+    ctx->last_groups = 1;
+    return ctx->prob.dtype == PDEOPT_F32 ? coop_fixed_advance<float>(ctx, integrator, t0, dt, n) : coop_fixed_advance<double>(ctx, integrator, t0, dt, n);
+  }
   if (small_chosen(ctx, integrator, n)) {
     ctx->win_lo = 0;
     ctx->win_n = ctx->prob.batch;

@@ -78,6 +78,11 @@ struct CoopArgs {
   int xs, wpx;         // XCDs an environment's workgroups are spread over (1, 2, 4, 8) and workgroups per XCD
   int rows, pitch;     // LDS array geometry: (largest tile + 2 H) rows x pitch
   int red_off;         // byte offset of the reduction / control scratch in LDS
+  // fixed-step mode (MODE 1 of the kernel: n_sub substeps of explicit Euler / classical RK4 with step dt from t0)
+  int fixed_rk4;
+  int64_t n_sub;
+  double dt;
+  unsigned* tags;      // [nenv][px * py] exchange rounds a workgroup has published
 };
 
 // the fixed closure forms of stencil_sbm_tiled.hpp (FAST) or the run-time walk (closure_generic)
@@ -115,11 +120,10 @@ __device__ __forceinline__ int wrap1(int i, int n) {  // |offset| <= n: one cond
 
 constexpr unsigned long long kCoopTimeoutTicks = 200000000ull;  // 2 s of s_memrealtime (100 MHz)
 
-// Barrier over the nwg workgroups of one environment.  false: the solve was aborted (a partner did not arrive).
-// one_xcd: the environment's workgroups share one XCD's L2 -- the exchange data is written and read with agent-scope
-// (L1-bypassing) accesses (xstore / xload below) and the barrier needs no cache maintenance; otherwise agent-scope
-// release / acquire fences write the L2 back and invalidate it (measured on the 100^2 smoothed-boundary solve: 6.5 us per
-// barrier with the fences; profiles/r04_coop_adaptive.txt).
+// Counter barrier over the nwg workgroups of one environment (the solve's prologue; the step loop's barrier is the slot
+// exchange in the kernel).  false: the solve was aborted (a partner did not arrive).  one_xcd = no fences: the exchange
+// data is written and read with agent-scope accesses (xstore / xload below), which need no cache maintenance -- see the
+// kernel; otherwise (-DPDEOPT_COOP_XCD_FENCES=1) agent-scope release / acquire fences write the L2 back and invalidate it.
 __device__ __forceinline__ bool coop_env_barrier(unsigned* bar, unsigned* abort_flag, int nwg, unsigned* gen, bool one_xcd) {
   __syncthreads();  // every wave's stores have been acknowledged (s_waitcnt vmcnt(0) precedes the s_barrier)
   if (threadIdx.x == 0) {
@@ -176,14 +180,23 @@ __device__ __forceinline__ void xstore(T* p, T v) { __hip_atomic_store(p, v, __A
 #ifndef PDEOPT_COOP_THREADS
 #define PDEOPT_COOP_THREADS 512  // 1024 threads cap a thread at 128 registers: the step loop's uniform doubles then spill (48-140 B fp32)
 #endif
-template <typename T, int EQ, bool FAST>
-__global__ __launch_bounds__(PDEOPT_COOP_THREADS) void tsit5_coop_kernel(const CoopArgs<T> a) {
-  constexpr int NT = PDEOPT_COOP_THREADS;
+// the fixed-step mode holds no slopes and no controller: 51 - 95 registers in fp32 -> 1024 threads, 4 waves per SIMD
+#ifndef PDEOPT_COOP_FIXED_THREADS_F32
+#define PDEOPT_COOP_FIXED_THREADS_F32 1024
+#endif
+template <typename T, int MODE>
+constexpr int coop_threads() { return MODE == 1 && sizeof(T) == 4 ? PDEOPT_COOP_FIXED_THREADS_F32 : PDEOPT_COOP_THREADS; }
+// MODE 0: the adaptive Tsit5 solve.  MODE 1: n_sub substeps of explicit Euler / classical RK4 on the same tiling (one
+// environment on several compute units; see the fixed-step loop below).
+template <typename T, int EQ, bool FAST, int MODE = 0>
+__global__ __launch_bounds__((coop_threads<T, MODE>())) void tsit5_coop_kernel(const CoopArgs<T> a) {
+  constexpr int NT = coop_threads<T, MODE>();
   constexpr bool kTwoPass = EQ == PDEOPT_EQ_CAHN_HILLIARD || EQ == PDEOPT_EQ_CAHN_HILLIARD_SBM;  // mu / inner array
   constexpr bool kSBM = EQ == PDEOPT_EQ_ALLEN_CAHN_SBM || EQ == PDEOPT_EQ_CAHN_HILLIARD_SBM;
   constexpr bool kAD = EQ == PDEOPT_EQ_ADVECTION_DIFFUSION;
   constexpr int R = kTwoPass ? 2 : 1;  // stencil radius of one right-hand side
-  constexpr int H = 6 * R;
+  constexpr int H = MODE == 1 ? 8 : 6 * R;  // fixed-step: 8 = one RK4 substep of the radius-2 forms, two of the radius-1 forms
+  constexpr int NK = MODE == 1 ? 1 : 6;      // slope arrays (fixed-step: the Runge-Kutta accumulator)
 
   // block -> (environment of this launch, tile).  Blocks are dealt round-robin over the 8 XCDs (block index mod 8): an
   // environment's workgroups sit on a.xs neighbouring XCDs (1 wherever they fit one XCD's compute units: the exchange
@@ -206,11 +219,11 @@ __global__ __launch_bounds__(PDEOPT_COOP_THREADS) void tsit5_coop_kernel(const C
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   T* const sY = reinterpret_cast<T*>(smem_raw);
   T* const sK = sY + FS;          // k1 .. k6: sK + j FS
-  T* sW = sK + 6 * FS;            // current stage input
+  T* sW = sK + NK * FS;           // current stage input
   T* sV = sW + FS;                // next stage input / k7
   T* const sM = sV + FS;          // mu / inner (two-pass forms)
   T* const sS = sM + (kTwoPass ? FS : 0);  // static fields: sS + j FS
-  double* const red = reinterpret_cast<double*>(smem_raw + a.red_off);  // [0..15] wave partials, [16..18] time terms, [19..21] controller, [24..] partners' sums
+  double* const red = reinterpret_cast<double*>(smem_raw + a.red_off);  // [0..15] wave partials, [19..22] controller / abort broadcast, [24..] partners' sums, [280..] the step's time terms
 
   // this environment's closure coefficients.  Fixed forms: copied into registers once -- read through the pointer inside
   // the cell loops the compiler re-loaded the coefficient arrays from memory in every trip (two global_load_dwordx4 per
@@ -242,10 +255,17 @@ __global__ __launch_bounds__(PDEOPT_COOP_THREADS) void tsit5_coop_kernel(const C
   const int64_t xoff = (int64_t)be * nx * ny;
   unsigned* const bar = a.bar + 2 * be;
   unsigned gen = 0;
+  // Every cross-workgroup access of the step loop is an agent-scope access (xload / xstore, the slot words): its scope bits
+  // take it past the caches that are not coherent at that scope -- the per-CU vector cache, and the per-XCD L2 when the
+  // partner sits on another XCD -- so an environment spread over several XCDs needs no release / acquire fences (an L2
+  // write-back + invalidate per barrier: 6.5 us on one XCD, 15 us across two, measured in this kernel's first version)
+  // either.  Ordering: a workgroup's data stores are acknowledged (s_waitcnt vmcnt(0) in front of the s_barrier) before its
+  // slot word is stored; a reader issues its data loads after it has seen the slot words.  -DPDEOPT_COOP_XCD_FENCES=1
+  // keeps the fenced counter barrier for environments on several XCDs (384^2 CH: 61 us per trial step against 45).
 #ifndef PDEOPT_COOP_XCD_FENCES
-#define PDEOPT_COOP_XCD_FENCES 1
+#define PDEOPT_COOP_XCD_FENCES 0
 #endif
-  const bool one_xcd = a.xs == 1 || !PDEOPT_COOP_XCD_FENCES;  // (0: experiment -- scoped accesses alone across XCDs)
+  const bool one_xcd = a.xs == 1 || !PDEOPT_COOP_XCD_FENCES;
 
   // cells of the region T + e, local coordinates (r, c) relative to the tile origin: f(LDS offset, r, c)
   auto region = [&](const int e, auto f) {
@@ -365,17 +385,22 @@ __global__ __launch_bounds__(PDEOPT_COOP_THREADS) void tsit5_coop_kernel(const C
   }
   const T sqk = kSBM ? T(sqrt((double)kap)) : T(0);
 
-  // time terms of a right-hand-side evaluation at time ts: thread 0 -> red[16..18], read by everyone after a barrier
-  auto put_time_terms = [&](const double ts) {
-    if (kSBM && tid == 0) {
+  // Time terms of the right-hand-side evaluations of a trial step -- cos theta(ts) on / off the mask, flux(ts) at the six
+  // stage times ts = t + c_i h -- in a table red[kTT + 3 i ..]: six LANES fill it side by side at the start of the step
+  // (one lane evaluating the double-precision cosines stage by stage while every other wave waited cost ~2 us per step
+  // of the notebook's theta(t) solve), the stages read their entry after the barrier that follows.
+  constexpr int kTT = 24 + 256;
+  auto put_time_terms = [&](const int slot, const double ts) {  // (called by the lane that owns the slot)
+    if constexpr (kSBM) {
+      double* const tt = red + kTT + 3 * slot;
       if (a.tmode == 0) {
-        red[16] = a.tw[0]; red[17] = a.tw[1]; red[18] = a.tw[2];
+        tt[0] = a.tw[0]; tt[1] = a.tw[1]; tt[2] = a.tw[2];
       } else {
         const double thv = ((a.theta[3] * ts + a.theta[2]) * ts + a.theta[1]) * ts + a.theta[0];
-        red[16] = cos(thv);
+        tt[0] = cos(thv);
         // Cahn-Hilliard: cos(pi - theta) off the mask (cahn_hilliard.py:271-272); Allen-Cahn: nothing there (allen_cahn.py:150)
-        red[17] = EQ == PDEOPT_EQ_ALLEN_CAHN_SBM ? 0.0 : cos(3.14159265358979323846 - thv);
-        red[18] = ((a.flux[3] * ts + a.flux[2]) * ts + a.flux[1]) * ts + a.flux[0];
+        tt[1] = EQ == PDEOPT_EQ_ALLEN_CAHN_SBM ? 0.0 : cos(3.14159265358979323846 - thv);
+        tt[2] = ((a.flux[3] * ts + a.flux[2]) * ts + a.flux[1]) * ts + a.flux[0];
       }
     }
   };
@@ -443,10 +468,10 @@ __global__ __launch_bounds__(PDEOPT_COOP_THREADS) void tsit5_coop_kernel(const C
       }
     }
   };
-  auto time_terms = [&](T* twa, T* twb, T* tsrc) {
-    *twa = kSBM ? T(red[16]) : T(0);
-    *twb = kSBM ? T(red[17]) : T(0);
-    *tsrc = kSBM ? T(red[18]) : T(0);
+  auto time_terms = [&](const int slot, T* twa, T* twb, T* tsrc) {
+    *twa = kSBM ? T(red[kTT + 3 * slot]) : T(0);
+    *twb = kSBM ? T(red[kTT + 3 * slot + 1]) : T(0);
+    *tsrc = kSBM ? T(red[kTT + 3 * slot + 2]) : T(0);
   };
   // the halo ring (T + H minus T) of y and k1 <- the exchange buffers: ring cells only (2 H full rows above and below,
   // H columns left and right of every tile row), both fields' loads of a cell issued together
@@ -535,12 +560,138 @@ __global__ __launch_bounds__(PDEOPT_COOP_THREADS) void tsit5_coop_kernel(const C
     }
   };
 
+  if constexpr (MODE == 1) {
+    // ------------------------------------------------------------------------------------------------ fixed step
+    // n_sub substeps of explicit Euler / classical RK4 for ONE environment on several compute units (VERDICT r3 Weak #6:
+    // a single 96^2 - 256^2 environment is 2 dependent launches of ~5.8 us per RK4 substep on the tiled path whatever
+    // its size).  A round = as many substeps as the 8-cell halo pays for (a substep consumes stages x radius of it: RK4
+    // Cahn-Hilliard 1 per round, RK4 Allen-Cahn / advection-diffusion 2, Euler 4 / 8), every stage on the region the later
+    // stages still need, nothing exchanged inside a round; then the tile of y goes to the exchange buffer of the round's
+    // parity, the workgroup publishes the round number, waits for its partners' and reloads its halo ring.  Update
+    // formulas in the association of the stage-pair / whole-step kernels (stencil_small.hpp):
+    //   w2 = y + dt/2 k1, acc = y + dt/6 k1;  w3 = y + dt/2 k2, acc += dt/3 k2;  w4 = y + dt k3, acc += dt/3 k3;  y' = acc + dt/6 k4
+    const bool rk4 = a.fixed_rk4 != 0;
+    const int stages = rk4 ? 4 : 1;
+    const int S = H / (stages * R);  // substeps per round
+    const T dtT = T(a.dt), h2 = T(a.dt / 2), h3 = T(a.dt / 3), h6 = T(a.dt / 6);
+    T* y = sY;
+    T* acc = sK;
+    unsigned* const tags = a.tags + (size_t)be * nwg;
+    const int ring_n = 2 * H * (tw + 2 * H) + 2 * H * th;
+    constexpr int kRing = sizeof(T) == 8 ? 3 : 6;
+    __syncthreads();  // y and the static fields are in place
+    // one right-hand side on T + e_out from `src`, its update applied per cell
+    auto rhs_update = [&](const T* src, const int e_out, const int slot, auto update) {
+      T twa, twb, tsrc;
+      time_terms(slot, &twa, &twb, &tsrc);
+      pass1(src, e_out, twa, twb);
+      region_u(e_out, [&](int o, int, int) -> T { return kcell(src, o, twa, twb, tsrc); }, update);
+      __syncthreads();
+    };
+    unsigned round = 0;
+    for (int64_t done = 0; done < a.n_sub; ++round) {
+      const int m = (int)((a.n_sub - done) < (int64_t)S ? (a.n_sub - done) : (int64_t)S);
+      if constexpr (kSBM) {  // theta(t), flux(t) at the round's stage times: one lane each
+        if (tid < m * stages) {
+          const int sub = tid / stages, st = tid - sub * stages;
+          const double t_sub = a.t0 + (double)(done + sub) * a.dt;
+          put_time_terms(tid, !rk4 || st == 0 ? t_sub : (st == 3 ? t_sub + a.dt : t_sub + 0.5 * a.dt));
+        }
+        __syncthreads();
+      }
+      int e = H;
+      for (int sub = 0; sub < m; ++sub) {
+        if (rk4) {
+          rhs_update(y, e - R, 4 * sub, [&](int o, int, int, T k) {
+            const T y0 = y[o];
+            sW[o] = y0 + h2 * k;
+            acc[o] = y0 + h6 * k;
+          });
+          rhs_update(sW, e - 2 * R, 4 * sub + 1, [&](int o, int, int, T k) {
+            sV[o] = y[o] + h2 * k;
+            acc[o] = acc[o] + h3 * k;
+          });
+          rhs_update(sV, e - 3 * R, 4 * sub + 2, [&](int o, int, int, T k) {
+            sW[o] = y[o] + dtT * k;
+            acc[o] = acc[o] + h3 * k;
+          });
+          rhs_update(sW, e - 4 * R, 4 * sub + 3, [&](int o, int, int, T k) { y[o] = acc[o] + h6 * k; });
+          e -= 4 * R;
+        } else {
+          T* const nxt = y == sY ? sV : sY;
+          rhs_update(y, e - R, sub, [&](int o, int, int, T k) { nxt[o] = y[o] + dtT * k; });
+          y = nxt;
+          e -= R;
+        }
+      }
+      done += m;
+      if (done >= a.n_sub) break;
+      // ---- exchange: tile -> buffer of this round's parity; publish; wait for every partner; ring <- their tiles.
+      // A workgroup reaches its next write of this buffer (two rounds on) only after every partner has published the round
+      // between, i.e. has finished reading this one.
+      T* const xb = a.xy[round & 1u] + xoff;
+      region(0, [&](int o, int r, int c) { xstore(&xb[(int64_t)(i0 + r) * ny + (j0 + c)], y[o]); });
+      __syncthreads();  // every wave's exchange stores have been acknowledged
+      const unsigned tag = round + 1u;
+      if (tid == 0) xstore(&tags[w], tag);
+      if (tid < 64) {
+        const unsigned long long t_in = __builtin_amdgcn_s_memrealtime();
+        bool gave_up = false;
+        for (int i = tid; i < nwg; i += 64) {
+          for (;;) {
+            if (xload(&tags[i]) >= tag) break;
+            if (xload(a.abort_flag) != 0u) {
+              gave_up = true;
+              break;
+            }
+            if (__builtin_amdgcn_s_memrealtime() - t_in > kCoopTimeoutTicks) {
+              xstore(a.abort_flag, 1u);
+              gave_up = true;
+              break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+          }
+        }
+        const bool any = __any(gave_up);
+        if (tid == 0) red[22] = any ? 1.0 : 0.0;
+      }
+      __syncthreads();
+      if (red[22] != 0.0) return;  // (the host reports the abort; the state is then garbage)
+      {
+        T ring[kRing];
+        const int trips = (ring_n + NT - 1) / NT;
+        for (int j0r = 0; j0r < trips; j0r += kRing) {  // (one pass for tiles up to ~40^2)
+#pragma unroll
+          for (int j = 0; j < kRing; ++j) {
+            const int idx = tid + (j0r + j) * NT;
+            if (idx < ring_n) {
+              int r, c;
+              ring_cell(idx, &r, &c);
+              ring[j] = xload(&xb[gidx(r, c)]);
+            }
+          }
+#pragma unroll
+          for (int j = 0; j < kRing; ++j) {
+            const int idx = tid + (j0r + j) * NT;
+            if (idx < ring_n) {
+              int r, c;
+              ring_cell(idx, &r, &c);
+              y[(r + H) * P + (c + H)] = ring[j];
+            }
+          }
+        }
+      }
+      __syncthreads();
+    }
+    region(0, [&](int o, int r, int c) { yg[(int64_t)(i0 + r) * ny + (j0 + c)] = y[o]; });
+    return;
+  } else {
   // ---- k1 = f(t0, y0) on the tile; its halo through the exchange
-  put_time_terms(a.t0);
+  if (tid == 0) put_time_terms(0, a.t0);
   __syncthreads();  // sY, the static fields and the time terms are in place
   {
     T twa, twb, tsrc;
-    time_terms(&twa, &twb, &tsrc);
+    time_terms(0, &twa, &twb, &tsrc);
     pass1(sY, 0, twa, twb);
     T* const xk0 = a.xk[0] + xoff;
     region(0, [&](int o, int r, int c) {
@@ -584,7 +735,7 @@ __global__ __launch_bounds__(PDEOPT_COOP_THREADS) void tsit5_coop_kernel(const C
       const T c0 = T(h * kTsA[0][0]);
       region_4(H, [&](int o, int, int) -> T { return sY[o] + c0 * sK[o]; }, [&](int o, int, int, T v) { sW[o] = v; });
     }
-    put_time_terms(t + kTsC[0] * h);
+    if (tid < 6) put_time_terms(tid, t + kTsC[tid] * h);  // (the previous step's last read lies behind its barriers)
     __syncthreads();
     PDEOPT_COOP_TICK(0);
     // stages 2 .. 6 (slope index s = 1 .. 5): k on T + R (6 - s), with it the next stage's input there.  One instantiation
@@ -596,8 +747,7 @@ __global__ __launch_bounds__(PDEOPT_COOP_THREADS) void tsit5_coop_kernel(const C
 #pragma unroll
       for (int i = 0; i <= s; ++i) cs[i] = T(h * kTsA[s][i]);
       T twa, twb, tsrc;
-      time_terms(&twa, &twb, &tsrc);
-      if constexpr (kSBM && !kTwoPass) __syncthreads();  // every wave has read this stage's terms before thread 0 posts the next
+      time_terms(s - 1, &twa, &twb, &tsrc);
       pass1(sW, e, twa, twb);
       T* const ks = sK + s * FS;
       struct KW {
@@ -613,7 +763,6 @@ __global__ __launch_bounds__(PDEOPT_COOP_THREADS) void tsit5_coop_kernel(const C
         ks[o] = v.k;
         sV[o] = v.w;
       });
-      put_time_terms(t + kTsC[s] * h);  // the NEXT stage's time (its reads come after the barrier)
       __syncthreads();
       T* const tmp = sW;
       sW = sV;
@@ -632,8 +781,8 @@ __global__ __launch_bounds__(PDEOPT_COOP_THREADS) void tsit5_coop_kernel(const C
 #pragma unroll
       for (int i = 0; i < 7; ++i) ce[i] = T(h * kTsE[i]);
       T twa, twb, tsrc;
-      time_terms(&twa, &twb, &tsrc);
-      pass1(sW, 0, twa, twb);  // (the next write of the time terms lies behind the environment barrier)
+      time_terms(5, &twa, &twb, &tsrc);
+      pass1(sW, 0, twa, twb);
       T* const xyn = a.xy[cur ^ 1] + xoff;
       T* const xkn = a.xk[cur ^ 1] + xoff;
       region(0, [&](int o, int r, int c) {
@@ -811,11 +960,18 @@ __global__ __launch_bounds__(PDEOPT_COOP_THREADS) void tsit5_coop_kernel(const C
     st.saved = qi;
     a.stats[be] = st;
   }
+  }  // MODE 0
 }
 
 // --------------------------------------------------------------------------------------------- host
 
 constexpr size_t kCoopLdsMax = 160 * 1024;
+
+// launches whose workgroups wait for each other: one at a time per process (coop_tsit5_solve)
+inline std::mutex& coop_launch_mutex() {
+  static std::mutex m;
+  return m;
+}
 
 struct CoopPlan {
   int px = 0, py = 0, rows = 0, pitch = 0, nfields = 0, halo = 0;
@@ -832,13 +988,14 @@ inline int coop_radius(int equation) {
 // workgroups (the exchange then stays in one L2 and the barrier needs no cache maintenance: 2 us against 15 us per step,
 // profiles/r04_coop_adaptive.txt), only then among larger grids (fp64 with many static fields: small tiles).
 // Measured on the 100^2 smoothed-boundary solve: 4 x 4 tiles 23 us per trial step, 5 x 5 19.5, 7 x 7 (two XCDs) 39.
+// fixed: 0 = the adaptive solve (H = 6 R, six slope arrays), 1 / 2 = explicit Euler / RK4 substeps (H = 8, one accumulator)
 template <typename T>
-bool coop_plan(const pdeopt_problem& p, int num_cus, CoopPlan* out) {
+bool coop_plan(const pdeopt_problem& p, int num_cus, CoopPlan* out, int fixed = 0) {
   const int eq = p.equation;
-  const int R = coop_radius(eq), H = 6 * R;
+  const int R = coop_radius(eq), H = fixed ? 8 : 6 * R;
   const bool sbm = eq == PDEOPT_EQ_ALLEN_CAHN_SBM || eq == PDEOPT_EQ_CAHN_HILLIARD_SBM;
   const int nstatic = sbm ? 3 : (eq == PDEOPT_EQ_ADVECTION_DIFFUSION ? 2 : 0);
-  const int nf = 1 + 6 + 2 + (R == 2 ? 1 : 0) + nstatic;
+  const int nf = 1 + (fixed ? 1 : 6) + 2 + (R == 2 ? 1 : 0) + nstatic;
   if (p.nx < H || p.ny < H) return false;
   auto fits = [&](int px, int py, CoopPlan* pl) {
     const int tx = (p.nx + px - 1) / px, ty = (p.ny + py - 1) / py;
@@ -847,7 +1004,7 @@ bool coop_plan(const pdeopt_problem& p, int num_cus, CoopPlan* out) {
     if (pitch % 2 == 0) ++pitch;  // odd pitch: vertically adjacent cells on different banks
     const size_t field = (size_t)rows * pitch * sizeof(T);
     const size_t arrays = (nf * field + 15) / 16 * 16;
-    const size_t lds = arrays + (24 + 256) * sizeof(double);  // wave partials, time terms, controller broadcast, partial-sum staging
+    const size_t lds = arrays + (24 + 256 + 24) * sizeof(double);  // wave partials, controller broadcast, partial-sum staging, the step's time-term table
     if (lds > kCoopLdsMax) return false;
     pl->px = px; pl->py = py; pl->rows = rows; pl->pitch = pitch; pl->nfields = nf; pl->halo = H; pl->lds = lds; pl->red_off = (int)arrays;
     return true;
@@ -855,6 +1012,10 @@ bool coop_plan(const pdeopt_problem& p, int num_cus, CoopPlan* out) {
   auto work = [&](int px, int py) {
     const int tx = (p.nx + px - 1) / px, ty = (p.ny + py - 1) / py;
     int64_t wk = 0;
+    if (fixed) {  // one round: the right-hand sides of 8 / R halo cells' worth of stages, on their shrinking regions
+      for (int e = H - R; e >= 0; e -= R) wk += (int64_t)(tx + 2 * e + (R == 2 ? 1 : 0)) * (ty + 2 * e + (R == 2 ? 1 : 0));
+      return wk + 300 * (int64_t)px * py / 8;
+    }
     for (int s = 1; s <= 6; ++s) wk += (int64_t)(tx + 2 * R * (6 - s) + (R == 2 ? 1 : 0)) * (ty + 2 * R * (6 - s) + (R == 2 ? 1 : 0));
     return wk + 150 * (int64_t)px * py / 8;  // + a little for every partner the barrier waits for
   };
@@ -865,14 +1026,19 @@ bool coop_plan(const pdeopt_problem& p, int num_cus, CoopPlan* out) {
   }
   if (forced) return fits(std::max(1, (p.nx + forced - 1) / forced), std::max(1, (p.ny + forced - 1) / forced), out) && out->px * out->py <= num_cus;
   const int per_xcd = std::max(1, num_cus / 8);
-  for (const int cap : {per_xcd, num_cus}) {
+  // One environment: latency -- the split with the least modelled work per step wherever it lands (the per-step exchange
+  // needs no cache maintenance across XCDs: see coop_env_barrier; the notebook's 100^2 solve: 5 x 6 tiles 16.3 us per trial
+  // step, 7 x 7 14.6, 8 x 8 14.4, 10 x 10 14.3).  A batch: throughput -- an environment on one XCD's compute units where it
+  // fits (8 environments per launch), otherwise on as few workgroups as hold it.
+  const bool latency = p.batch == 1;
+  // (latency: at most 7 of the 8 XCDs' compute units -- a launch that needs EVERY compute unit free waits for any other kernel)
+  for (const int cap : {latency ? num_cus - per_xcd : per_xcd, num_cus}) {
     int64_t best = -1;
     for (int px = 1; px <= std::min(p.nx / 4, cap); ++px)
       for (int py = 1; py <= std::min(p.ny / 4, cap / px); ++py) {
         CoopPlan pl;
         if (!fits(px, py, &pl)) continue;
-        // beyond one XCD the barrier (L2 write-back + invalidate per partner set) outweighs the arithmetic: fewest workgroups first
-        const int64_t wk = cap == per_xcd ? work(px, py) : (int64_t)px * py * 1000000 + work(px, py);
+        const int64_t wk = (latency || cap == per_xcd) ? work(px, py) : (int64_t)px * py * 1000000 + work(px, py);
         if (best < 0 || wk < best) {
           best = wk;
           *out = pl;
@@ -883,8 +1049,8 @@ bool coop_plan(const pdeopt_problem& p, int num_cus, CoopPlan* out) {
   return false;
 }
 
-template <typename T>
-bool coop_tsit5_supported(const pdeopt_ctx* ctx) {
+// the part of "does the multi-workgroup kernel cover this problem" that does not depend on the tile plan
+inline bool coop_problem_supported(const pdeopt_ctx* ctx) {
   const pdeopt_problem& p = ctx->prob;
   if (ctx->opt_small_persist < 0 || ctx->opt_kernel_path == 1 || ctx->opt_debug_ablate) return false;
   if (ctx->halo || p.nz > 1) return false;
@@ -903,8 +1069,12 @@ bool coop_tsit5_supported(const pdeopt_ctx* ctx) {
     if (has_time_aux(ctx, PDEOPT_AUX_VX_FACE) || has_time_aux(ctx, PDEOPT_AUX_VY_FACE)) return false;  // velocity_fn(t, .) varies
     if (!ctx->aux[PDEOPT_AUX_VX_FACE].dev || !ctx->aux[PDEOPT_AUX_VY_FACE].dev) return false;
   }
+  return true;
+}
+template <typename T>
+bool coop_tsit5_supported(const pdeopt_ctx* ctx) {
   CoopPlan pl;
-  return coop_plan<T>(p, ctx->num_cus, &pl);
+  return coop_problem_supported(ctx) && coop_plan<T>(ctx->prob, ctx->num_cus, &pl);
 }
 
 template <typename T>
@@ -1039,8 +1209,7 @@ int coop_tsit5_solve(pdeopt_ctx* ctx, double t0, double t1, double dt0, const pd
   // The workgroups of a launch wait for each other: two such launches of one process in flight at once (two engines on
   // two host threads) could each hold half of the chip and starve the other until the 2 s abort.  One at a time per
   // process (the call is synchronous anyway); other PROCESSES on the same GPU are the caller's to keep apart.
-  static std::mutex coop_launch_mutex;
-  std::lock_guard<std::mutex> coop_lock(coop_launch_mutex);
+  std::lock_guard<std::mutex> coop_lock(coop_launch_mutex());
   for (int e0 = 0; e0 < batch; e0 += envs_per_launch) {
     const int ne = std::min(envs_per_launch, batch - e0);
     CoopArgs<T> c = s;
@@ -1070,6 +1239,157 @@ int coop_tsit5_solve(pdeopt_ctx* ctx, double t0, double t1, double dt0, const pd
   PDEOPT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   if (aborted)
     return fail(ctx, PDEOPT_ESTATE, "the multi-workgroup adaptive solve was aborted: a workgroup waited more than 2 s for its partners "
+                                    "(the launch's workgroups were not all resident, or the device was shared)");
+  return PDEOPT_OK;
+}
+
+
+// ------------------------------------------------------------------------------------- fixed step on several CUs
+
+// environments of one launch for a plan: every workgroup of a launch must be resident at once
+struct CoopLaunchShape {
+  int xs, wpx, envs_per_launch;
+};
+inline bool coop_launch_shape(int nwg, int num_cus, CoopLaunchShape* o) {
+  const int cus_per_xcd = std::max(1, num_cus / 8);
+  int xs = 1;
+  while (xs < 8 && (nwg + xs - 1) / xs > cus_per_xcd) xs *= 2;
+  const int wpx = (nwg + xs - 1) / xs;
+  if (wpx > cus_per_xcd) return false;
+  o->xs = xs;
+  o->wpx = wpx;
+  o->envs_per_launch = (cus_per_xcd / wpx) * (8 / xs);
+  return true;
+}
+
+// Explicit Euler / RK4 with the MODE 1 kernel: when is it the better path?  One launch must hold every environment (the
+// tiled kernels sweep a whole batch per launch; this kernel spends 16 - 100 compute units on ONE environment), and the
+// grid must be beyond the one-CU whole-step kernel's range -- that kernel's 4.6 us per 64^2 substep is below what an
+// exchange per substep allows here.  PDEOPT_OPT_SMALL_PERSIST = 2 takes it wherever it can run, -1 never.
+template <typename T>
+bool coop_fixed_chosen(const pdeopt_ctx* ctx, int integrator, int64_t n) {
+  if (integrator != PDEOPT_INT_EULER && integrator != PDEOPT_INT_RK4) return false;
+  if (!coop_problem_supported(ctx)) return false;
+  const pdeopt_problem& p = ctx->prob;
+  CoopPlan pl;
+  if (!coop_plan<T>(p, ctx->num_cus, &pl, integrator == PDEOPT_INT_RK4 ? 2 : 1)) return false;
+  CoopLaunchShape sh;
+  if (!coop_launch_shape(pl.px * pl.py, ctx->num_cus, &sh)) return false;
+  if (ctx->opt_small_persist == 2) return true;
+  if (ctx->opt_small_persist != 0) return false;
+  // a caller who turned one of the tiled path's knobs is asking for that path
+  if (ctx->opt_fuse_stages != 0 || ctx->opt_kernel_path != 0 || ctx->opt_graph != 0 || ctx->opt_group_envs != 0 || ctx->opt_tile_rows != 0)
+    return false;
+  const int64_t cells = (int64_t)p.nx * p.ny;
+  return n >= 8 && p.batch <= sh.envs_per_launch && cells > kSmallAutoCells && cells <= 320 * 320;
+}
+
+template <typename T>
+int coop_fixed_advance(pdeopt_ctx* ctx, int integrator, double t0, double dt, int64_t n) {
+  const pdeopt_problem& p = ctx->prob;
+  const int batch = p.batch;
+  const int64_t cells = (int64_t)p.nx * p.ny;
+  const bool rk4 = integrator == PDEOPT_INT_RK4;
+  CoopPlan pl;
+  CoopLaunchShape sh;
+  if (!coop_plan<T>(p, ctx->num_cus, &pl, rk4 ? 2 : 1) || !coop_launch_shape(pl.px * pl.py, ctx->num_cus, &sh))
+    return fail(ctx, PDEOPT_EINVAL, "the multi-workgroup fixed-step kernel does not cover this problem");
+  const int nwg = pl.px * pl.py;
+  const int eq = p.equation;
+  const bool sbm = eq == PDEOPT_EQ_ALLEN_CAHN_SBM || eq == PDEOPT_EQ_CAHN_HILLIARD_SBM;
+  int rc;
+  if ((rc = ensure_buffer(ctx, &ctx->TA, ctx->total_bytes))) return rc;
+  if ((rc = ensure_buffer(ctx, &ctx->TB, ctx->total_bytes))) return rc;
+  CoopArgs<T> s{};
+  s.nx = p.nx; s.ny = p.ny; s.px = pl.px; s.py = pl.py;
+  s.bstride = make_geo(ctx).bstride;
+  s.rhx = T(1.0 / p.hx); s.rhy = T(1.0 / p.hy);
+  s.rhx2 = T(1.0 / (p.hx * p.hx)); s.rhy2 = T(1.0 / (p.hy * p.hy));
+  s.mu = ClosureSpec{p.mu.kind, p.mu.flags, p.mu.n};
+  s.mob = ClosureSpec{p.mob.kind, p.mob.flags, p.mob.n};
+  s.fe = ClosureSpec{p.fe.kind, p.fe.flags, p.fe.n};
+  s.t0 = t0; s.dt = dt; s.n_sub = n; s.fixed_rk4 = rk4 ? 1 : 0;
+  s.rows = pl.rows; s.pitch = pl.pitch; s.red_off = pl.red_off;
+  s.xs = sh.xs; s.wpx = sh.wpx;
+  if (sbm) {
+    if (ctx->time_poly_valid) {
+      s.tmode = 1;
+      for (int i = 0; i < 4; ++i) { s.theta[i] = ctx->time_theta[i]; s.flux[i] = ctx->time_flux[i]; }
+    } else {
+      s.tmode = 0;
+      for (int i = 0; i < 3; ++i) s.tw[i] = ctx->time_const[i];
+    }
+  }
+  // device block: the published round numbers of every workgroup + the abort flag
+  const size_t need = ((size_t)batch * nwg + 1) * sizeof(unsigned) + 256;
+  if (ctx->adaptive_cap < need) {
+    if (ctx->adaptive_blk) {
+      PDEOPT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+      (void)hipFree(ctx->adaptive_blk);
+      ctx->adaptive_blk = nullptr;
+      ctx->adaptive_cap = 0;
+    }
+    PDEOPT_HIP_CHECK(ctx, hipMalloc(&ctx->adaptive_blk, need));
+    ctx->adaptive_cap = need;
+  }
+  unsigned* const tags_dev = static_cast<unsigned*>(ctx->adaptive_blk);
+  unsigned* const abort_dev = tags_dev + (size_t)batch * nwg;
+  PDEOPT_HIP_CHECK(ctx, hipMemsetAsync(tags_dev, 0, ((size_t)batch * nwg + 1) * sizeof(unsigned), ctx->stream));
+
+  const char* eqn = eq == PDEOPT_EQ_CAHN_HILLIARD ? "CH" : eq == PDEOPT_EQ_ALLEN_CAHN ? "AC" : eq == PDEOPT_EQ_CAHN_HILLIARD_SBM ? "CH-SBM"
+                    : eq == PDEOPT_EQ_ALLEN_CAHN_SBM ? "AC-SBM" : "AD";
+  const bool fast = eq == PDEOPT_EQ_ADVECTION_DIFFUSION || coop_fast_closures(p, sbm);
+  char name[112];
+  snprintf(name, sizeof(name), "%s_coop<%s,%s,%s,%dx%d workgroups>", rk4 ? "rk4" : "euler", sizeof(T) == 4 ? "f32" : "f64", eqn,
+           fast ? "fixed closures" : "generic closures", pl.px, pl.py);
+  ctx->last_kernel = name;
+  auto kern = [&]() -> const void* {
+#define PDEOPT_COOP_KF(EQV) (fast ? reinterpret_cast<const void*>(tsit5_coop_kernel<T, EQV, true, 1>) : reinterpret_cast<const void*>(tsit5_coop_kernel<T, EQV, false, 1>))
+    switch (eq) {
+      case PDEOPT_EQ_CAHN_HILLIARD: return PDEOPT_COOP_KF(PDEOPT_EQ_CAHN_HILLIARD);
+      case PDEOPT_EQ_ALLEN_CAHN: return PDEOPT_COOP_KF(PDEOPT_EQ_ALLEN_CAHN);
+      case PDEOPT_EQ_CAHN_HILLIARD_SBM: return PDEOPT_COOP_KF(PDEOPT_EQ_CAHN_HILLIARD_SBM);
+      case PDEOPT_EQ_ALLEN_CAHN_SBM: return PDEOPT_COOP_KF(PDEOPT_EQ_ALLEN_CAHN_SBM);
+      default: return reinterpret_cast<const void*>(tsit5_coop_kernel<T, PDEOPT_EQ_ADVECTION_DIFFUSION, true, 1>);
+    }
+#undef PDEOPT_COOP_KF
+  }();
+  PDEOPT_HIP_CHECK(ctx, hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds));
+  const T* s0 = nullptr; const T* s1 = nullptr; const T* s2 = nullptr;
+  int64_t sstride = 0;
+  if (sbm) {
+    s0 = static_cast<const T*>(ctx->aux[PDEOPT_AUX_SBM_PSI].dev);
+    s1 = static_cast<const T*>(ctx->aux[PDEOPT_AUX_SBM_NORM_GRAD].dev);
+    s2 = static_cast<const T*>(ctx->aux[PDEOPT_AUX_SBM_MASK].dev);
+  } else if (eq == PDEOPT_EQ_ADVECTION_DIFFUSION) {
+    s0 = static_cast<const T*>(ctx->aux[PDEOPT_AUX_VX_FACE].dev);
+    s1 = static_cast<const T*>(ctx->aux[PDEOPT_AUX_VY_FACE].dev);
+    sstride = ctx->aux[PDEOPT_AUX_VX_FACE].per_env ? cells : 0;
+  }
+  std::lock_guard<std::mutex> coop_lock(coop_launch_mutex());  // (see coop_tsit5_solve)
+  for (int e0 = 0; e0 < batch; e0 += sh.envs_per_launch) {
+    const int ne = std::min(sh.envs_per_launch, batch - e0);
+    CoopArgs<T> c = s;
+    c.nenv = ne;
+    c.y = static_cast<T*>(ctx->Y) + (int64_t)e0 * s.bstride;
+    c.ep = static_cast<const EnvParams<T>*>(ctx->env_params_dev) + e0;
+    c.s0 = s0 ? s0 + (int64_t)e0 * sstride : nullptr;
+    c.s1 = s1 ? s1 + (int64_t)e0 * sstride : nullptr;
+    c.s2 = s2;
+    c.sstride = sstride;
+    c.xy[0] = static_cast<T*>(ctx->TA) + (int64_t)e0 * cells; c.xy[1] = static_cast<T*>(ctx->TB) + (int64_t)e0 * cells;
+    c.tags = tags_dev + (size_t)e0 * nwg;
+    c.abort_flag = abort_dev;
+    const int rows_used = (ne + 8 / sh.xs - 1) / (8 / sh.xs);
+    void* params[] = {&c};
+    PDEOPT_HIP_CHECK(ctx, hipLaunchKernel(kern, dim3(8 * rows_used * sh.wpx), dim3(coop_threads<T, 1>()), params, pl.lds, ctx->stream));
+    ctx->n_stage_launches++;
+  }
+  unsigned aborted = 0;
+  PDEOPT_HIP_CHECK(ctx, hipMemcpyAsync(&aborted, abort_dev, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
+  PDEOPT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  if (aborted)
+    return fail(ctx, PDEOPT_ESTATE, "the multi-workgroup fixed-step advance was aborted: a workgroup waited more than 2 s for its partners "
                                     "(the launch's workgroups were not all resident, or the device was shared)");
   return PDEOPT_OK;
 }
