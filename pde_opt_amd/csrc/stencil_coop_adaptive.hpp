@@ -1280,8 +1280,12 @@ bool coop_fixed_chosen(const pdeopt_ctx* ctx, int integrator, int64_t n) {
   // a caller who turned one of the tiled path's knobs is asking for that path
   if (ctx->opt_fuse_stages != 0 || ctx->opt_kernel_path != 0 || ctx->opt_graph != 0 || ctx->opt_group_envs != 0 || ctx->opt_tile_rows != 0)
     return false;
+  // measured, 100 RK4 substeps of one CH environment (tools/small_grid_bench.py, profiles/r04_small_grid_ch.txt), this kernel
+  // / tiled / one CU: fp32 96^2 0.61 / 1.30 / 1.63 ms, 128^2 0.69 / 0.84 / 1.65, 256^2 0.92 / 0.88 / -; 64^2 0.54 / 0.82 /
+  // 0.47; fp64 64^2 0.70 / 1.35 / 1.14, 32^2 0.56 / 1.42 / 0.37
   const int64_t cells = (int64_t)p.nx * p.ny;
-  return n >= 8 && p.batch <= sh.envs_per_launch && cells > kSmallAutoCells && cells <= 320 * 320;
+  const int64_t lo = sizeof(T) == 8 && p.batch == 1 ? kSmallAutoCells - 1 : kSmallAutoCells;
+  return n >= 8 && p.batch <= sh.envs_per_launch && cells > lo && cells <= 192 * 192;
 }
 
 template <typename T>

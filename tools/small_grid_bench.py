@@ -1,6 +1,7 @@
 """Latency of one env-step (100 RK4 substeps) on the small grids the reference's tests and notebooks use (32^2 ..
 256^2): the whole-environment-step kernel (stencil_small.hpp, one launch per pdeopt_advance) against the tiled
-stage-pair kernels (two dependent launches per substep).  usage: python tools/small_grid_bench.py [eq]"""
+stage-pair kernels (two dependent launches per substep) and the multi-workgroup fixed-step kernel (stencil_coop_adaptive.hpp,
+MODE 1: several compute units per environment).  usage: python tools/small_grid_bench.py [eq]"""
 import sys, time
 import numpy as np
 sys.path.insert(0, ".")
@@ -24,7 +25,7 @@ for dtype in (np.float32, np.float64):
             rng = np.random.default_rng(0)
             y0 = np.clip(0.5 + 0.01 * rng.standard_normal((batch, n, n)), 0.05, 0.95).astype(dtype)
             row = []
-            for opt in (1, -1):
+            for opt in (1, -1, 2, 0):  # one CU per environment; tiled; several CUs per environment; the library's own choice
                 eng = P.HipEngine()
                 eng.set_small_persist(opt)
                 eng.configure(dtype=dtype, batch=batch, **eq._engine_problem())
@@ -40,7 +41,8 @@ for dtype in (np.float32, np.float64):
                 el = (time.perf_counter() - t0) / reps
                 row.append((el, eng.last_kernel))
                 eng.close()
-            (a, ka), (b, kb) = row
+            (a, ka), (b, kb), (c, kc), (d, kd) = row
             tag = "whole-step" if ka.startswith("small_persist") else "(n/a)"
-            print(f"{kind} {np.dtype(dtype).name} {n:4d}^2 x {batch:3d} envs: {tag} {a * 1e3:8.3f} ms | tiled {b * 1e3:8.3f} ms per env-step "
-                  f"-> x{b / a:5.2f}   [{ka} | {kb}]", flush=True)
+            multi = f"{c * 1e3:8.3f} ms" if "_coop<" in kc else "   (n/a)   "
+            print(f"{kind} {np.dtype(dtype).name} {n:4d}^2 x {batch:3d} envs: {tag} {a * 1e3:8.3f} ms | tiled {b * 1e3:8.3f} ms | several CUs per env {multi} | "
+                  f"auto {d * 1e3:8.3f} ms per env-step [{kd}]", flush=True)
