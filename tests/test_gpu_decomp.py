@@ -15,6 +15,7 @@ pytestmark = pytest.mark.gpu
 def _monolithic(eq, y0, dt, n, fuse):
     eng = P.HipEngine()
     eng.set_fuse_stages(fuse)
+    eng.set_small_persist(-1)  # the tiled kernels (a single mid-sized environment would otherwise take several CUs: other association)
     out = P.diffeqsolve(eq, P.RK4(), 0.0, n * dt, dt, y0, engine=eng).ys[-1]
     kern = eng.last_kernel
     eng.close()

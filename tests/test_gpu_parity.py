@@ -685,7 +685,10 @@ def test_linear_logit_class_matches_the_cubic_one():
     outs = []
     for coef in ((3.0, -6.0), (3.0, -6.0, 0.0, 0.0)):
         eq = P.CahnHilliard2DPeriodic(dom, 0.002, ClosureDesc(POLY, LOGIT_PRIOR, coef), MOB["c1mc"])
-        sol = P.diffeqsolve(eq, P.RK4(), 0.0, 8 * 2e-7, 2e-7, y0)
+        eng = P.HipEngine()
+        eng.set_small_persist(-1)  # the tiled whole-substep kernel (whose closure classes are the subject)
+        sol = P.diffeqsolve(eq, P.RK4(), 0.0, 8 * 2e-7, 2e-7, y0, engine=eng)
+        eng.close()
         assert "rk4_quad" in sol.stats["kernel"]
         outs.append(sol.ys[-1])
     eps = np.finfo(np.float32).eps

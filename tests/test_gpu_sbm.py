@@ -193,6 +193,7 @@ def test_time_terms_are_sampled_once_per_advance_not_per_stage():
     eq = _eq("ch", sbm_domain(P, psi), theta=theta)
     y0 = np.clip(0.5 + 0.1 * rng.standard_normal(psi.shape), 0.1, 0.9)
     eng = P.HipEngine()
+    eng.set_small_persist(-1)  # the tiled kernel with host-sampled time terms (a polynomial theta(t) would otherwise be evaluated in-kernel)
     sol = P.diffeqsolve(eq, P.RK4(), 0.03, 0.03 + 50 * 2e-3, 2e-3, y0, engine=eng)
     # (the upload also probes theta for being a polynomial in t -- closures.poly_in_t: a symbol and the times 0, 0.37, 1.9,
     # outside this run's stage times -- for the in-kernel adaptive solve; not counted here)
@@ -202,6 +203,7 @@ def test_time_terms_are_sampled_once_per_advance_not_per_stage():
     calls.clear()
     # the callback path (table cleared by hand): 4 calls per substep, same bits
     eng2 = P.HipEngine()
+    eng2.set_small_persist(-1)
     eng2._upload_time_table = lambda *a, **k: None
     sol2 = P.diffeqsolve(eq, P.RK4(), 0.03, 0.03 + 50 * 2e-3, 2e-3, y0, engine=eng2)
     assert len(stage_calls()) == 200
