@@ -345,12 +345,29 @@ __global__ __launch_bounds__(256) void sbm_ch_stage_kernel(const StageArgs<T> a)
 // kernels (closures.hpp: fixed polynomial / logit forms unrolled; CL_GENERIC walks the family at run time -- with it the
 // stage kernel spent 340 VALU instructions per cell, most of them in the seven mobility evaluations).
 // ---------------------------------------------------------------------------------------------------
+// Block -> (z segment, y group, x plane, environment).  Blocks are dealt round-robin over the 8 XCDs, each with its own L2:
+// in launch order the x - 1 / x / x + 1 planes a cell needs sit on three different XCDs and every one of them fetches its
+// own copy (FETCH_SIZE of the mu pass: 2.4 x the field).  The 1-D grid is re-dealt so that an XCD owns a contiguous run
+// of blocks = a slab of consecutive x planes (stencil_fused.hpp's xcd_remap).
+struct Ch3dGrid {
+  int gx, gy, nblk;  // blocks along z, along y; total = gx * gy * nx * environments
+};
+__device__ __forceinline__ void ch3d_decode(const Ch3dGrid& g, int nx, int* k0, int* j0, int* i, int* b) {
+  int l = blockIdx.x;
+  if ((g.nblk & 7) == 0) l = (l & 7) * (g.nblk >> 3) + (l >> 3);
+  const int bx = l % g.gx, q = l / g.gx, by = q % g.gy, bz = q / g.gy;
+  *k0 = bx * 64;
+  *j0 = by * 4;
+  *i = bz % nx;
+  *b = bz / nx;
+}
 template <typename T, int CL>
-__global__ __launch_bounds__(256) void ch3d_mu_kernel(const StageArgs<T> a, T* __restrict__ mu_out) {
+__global__ __launch_bounds__(256) void ch3d_mu_kernel(const StageArgs<T> a, T* __restrict__ mu_out, const Ch3dGrid grid) {
   const int nx = a.g.nx, ny = a.g.ny, nz = a.g.nz;
-  const int k = blockIdx.x * 64 + threadIdx.x;
-  const int j = blockIdx.y * 4 + threadIdx.y;
-  const int i = blockIdx.z % nx, b = blockIdx.z / nx;
+  int k0, j0, i, b;
+  ch3d_decode(grid, nx, &k0, &j0, &i, &b);
+  const int k = k0 + threadIdx.x;
+  const int j = j0 + threadIdx.y;
   if (k >= nz || j >= ny) return;
   const T* __restrict__ u = a.in + (int64_t)b * a.g.bstride;
   const EnvParams<T>& p = a.ep[b];
@@ -365,11 +382,12 @@ __global__ __launch_bounds__(256) void ch3d_mu_kernel(const StageArgs<T> a, T* _
 }
 
 template <typename T, int CL>
-__global__ __launch_bounds__(256) void ch3d_stage_kernel(const StageArgs<T> a) {
+__global__ __launch_bounds__(256) void ch3d_stage_kernel(const StageArgs<T> a, const Ch3dGrid grid) {
   const int nx = a.g.nx, ny = a.g.ny, nz = a.g.nz;
-  const int k = blockIdx.x * 64 + threadIdx.x;
-  const int j = blockIdx.y * 4 + threadIdx.y;
-  const int i = blockIdx.z % nx, b = blockIdx.z / nx;
+  int k0, j0, i, b;
+  ch3d_decode(grid, nx, &k0, &j0, &i, &b);
+  const int k = k0 + threadIdx.x;
+  const int j = j0 + threadIdx.y;
   if (k >= nz || j >= ny) return;
   const int64_t base = (int64_t)b * a.g.bstride;
   const T* __restrict__ u = a.in + base;
