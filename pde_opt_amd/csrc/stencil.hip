@@ -99,27 +99,25 @@ int launch_generic(pdeopt_ctx* ctx, const StageArgs<T>& s) {
     // two passes: chemical potential into the work field, then the flux divergence + stage update
     const int nz = s.g.nz;
     dim3 g3((nz + 63) / 64, (p.ny + 3) / 4, (unsigned)(p.nx * ctx->win_n));
-    if ((uint64_t)g3.x * g3.y * g3.z > 0x7fffffffull) return fail(ctx, PDEOPT_EINVAL, "grid too large for the 3-D kernels");
+    if (g3.y > 65535u || g3.z > 65535u) return fail(ctx, PDEOPT_EINVAL, "grid too large for the 3-D kernels");
     int rc = ensure_buffer(ctx, &ctx->KS, ctx->total_bytes);
     if (rc) return rc;
     StageArgs<T> s3 = s;
     s3.mu3 = static_cast<const T*>(ctx->KS) + (int64_t)ctx->win_lo * s.g.bstride;
-    const Ch3dGrid cg{(int)g3.x, (int)g3.y, (int)(g3.x * g3.y * g3.z)};
-    const dim3 g1((unsigned)cg.nblk);
     switch (classify_closures(p.mu, p.mob)) {
       case CL_POLY:
-        hipLaunchKernelGGL((ch3d_mu_kernel<T, CL_POLY>), g1, block, 0, ctx->stream, s3, const_cast<T*>(s3.mu3), cg);
-        hipLaunchKernelGGL((ch3d_stage_kernel<T, CL_POLY>), g1, block, 0, ctx->stream, s3, cg);
+        hipLaunchKernelGGL((ch3d_mu_kernel<T, CL_POLY>), g3, block, 0, ctx->stream, s3, const_cast<T*>(s3.mu3));
+        hipLaunchKernelGGL((ch3d_stage_kernel<T, CL_POLY>), g3, block, 0, ctx->stream, s3);
         ctx->last_kernel = "stage_generic<CH-3D,poly>";
         break;
       case CL_LOGIT:
-        hipLaunchKernelGGL((ch3d_mu_kernel<T, CL_LOGIT>), g1, block, 0, ctx->stream, s3, const_cast<T*>(s3.mu3), cg);
-        hipLaunchKernelGGL((ch3d_stage_kernel<T, CL_LOGIT>), g1, block, 0, ctx->stream, s3, cg);
+        hipLaunchKernelGGL((ch3d_mu_kernel<T, CL_LOGIT>), g3, block, 0, ctx->stream, s3, const_cast<T*>(s3.mu3));
+        hipLaunchKernelGGL((ch3d_stage_kernel<T, CL_LOGIT>), g3, block, 0, ctx->stream, s3);
         ctx->last_kernel = "stage_generic<CH-3D,logit>";
         break;
       default:
-        hipLaunchKernelGGL((ch3d_mu_kernel<T, CL_GENERIC>), g1, block, 0, ctx->stream, s3, const_cast<T*>(s3.mu3), cg);
-        hipLaunchKernelGGL((ch3d_stage_kernel<T, CL_GENERIC>), g1, block, 0, ctx->stream, s3, cg);
+        hipLaunchKernelGGL((ch3d_mu_kernel<T, CL_GENERIC>), g3, block, 0, ctx->stream, s3, const_cast<T*>(s3.mu3));
+        hipLaunchKernelGGL((ch3d_stage_kernel<T, CL_GENERIC>), g3, block, 0, ctx->stream, s3);
         ctx->last_kernel = "stage_generic<CH-3D>";
     }
     PDEOPT_HIP_CHECK(ctx, hipGetLastError());

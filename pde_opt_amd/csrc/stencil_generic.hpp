@@ -345,29 +345,12 @@ __global__ __launch_bounds__(256) void sbm_ch_stage_kernel(const StageArgs<T> a)
 // kernels (closures.hpp: fixed polynomial / logit forms unrolled; CL_GENERIC walks the family at run time -- with it the
 // stage kernel spent 340 VALU instructions per cell, most of them in the seven mobility evaluations).
 // ---------------------------------------------------------------------------------------------------
-// Block -> (z segment, y group, x plane, environment).  Blocks are dealt round-robin over the 8 XCDs, each with its own L2:
-// in launch order the x - 1 / x / x + 1 planes a cell needs sit on three different XCDs and every one of them fetches its
-// own copy (FETCH_SIZE of the mu pass: 2.4 x the field).  The 1-D grid is re-dealt so that an XCD owns a contiguous run
-// of blocks = a slab of consecutive x planes (stencil_fused.hpp's xcd_remap).
-struct Ch3dGrid {
-  int gx, gy, nblk;  // blocks along z, along y; total = gx * gy * nx * environments
-};
-__device__ __forceinline__ void ch3d_decode(const Ch3dGrid& g, int nx, int* k0, int* j0, int* i, int* b) {
-  int l = blockIdx.x;
-  if ((g.nblk & 7) == 0) l = (l & 7) * (g.nblk >> 3) + (l >> 3);
-  const int bx = l % g.gx, q = l / g.gx, by = q % g.gy, bz = q / g.gy;
-  *k0 = bx * 64;
-  *j0 = by * 4;
-  *i = bz % nx;
-  *b = bz / nx;
-}
 template <typename T, int CL>
-__global__ __launch_bounds__(256) void ch3d_mu_kernel(const StageArgs<T> a, T* __restrict__ mu_out, const Ch3dGrid grid) {
+__global__ __launch_bounds__(256) void ch3d_mu_kernel(const StageArgs<T> a, T* __restrict__ mu_out) {
   const int nx = a.g.nx, ny = a.g.ny, nz = a.g.nz;
-  int k0, j0, i, b;
-  ch3d_decode(grid, nx, &k0, &j0, &i, &b);
-  const int k = k0 + threadIdx.x;
-  const int j = j0 + threadIdx.y;
+  const int k = blockIdx.x * 64 + threadIdx.x;
+  const int j = blockIdx.y * 4 + threadIdx.y;
+  const int i = blockIdx.z % nx, b = blockIdx.z / nx;
   if (k >= nz || j >= ny) return;
   const T* __restrict__ u = a.in + (int64_t)b * a.g.bstride;
   const EnvParams<T>& p = a.ep[b];
@@ -382,12 +365,11 @@ __global__ __launch_bounds__(256) void ch3d_mu_kernel(const StageArgs<T> a, T* _
 }
 
 template <typename T, int CL>
-__global__ __launch_bounds__(256) void ch3d_stage_kernel(const StageArgs<T> a, const Ch3dGrid grid) {
+__global__ __launch_bounds__(256) void ch3d_stage_kernel(const StageArgs<T> a) {
   const int nx = a.g.nx, ny = a.g.ny, nz = a.g.nz;
-  int k0, j0, i, b;
-  ch3d_decode(grid, nx, &k0, &j0, &i, &b);
-  const int k = k0 + threadIdx.x;
-  const int j = j0 + threadIdx.y;
+  const int k = blockIdx.x * 64 + threadIdx.x;
+  const int j = blockIdx.y * 4 + threadIdx.y;
+  const int i = blockIdx.z % nx, b = blockIdx.z / nx;
   if (k >= nz || j >= ny) return;
   const int64_t base = (int64_t)b * a.g.bstride;
   const T* __restrict__ u = a.in + base;
@@ -413,6 +395,9 @@ __global__ __launch_bounds__(256) void ch3d_stage_kernel(const StageArgs<T> a, c
   stage_update<T>(a, base + c0, kk);
 }
 
+// (Also measured without effect: an XCD-aware block map -- the 1-D grid re-dealt so that an XCD owns a slab of consecutive
+// x planes instead of every 8th block: 672 against 678-710 env-steps/s on 8 x 128^3, although the mu pass fetches 2.4 x
+// the field in launch order.)
 // (A single-pass LDS-brick form -- u on an 8 x 8 x 64 brick + 2 and mu on the brick + 1 in LDS, one launch per stage --
 // was built and measured in round 4: bitwise equal, 249 us per stage of 8 x 128^3 against 146 us for the two passes above.
 // Its 65 KB of LDS leave 8 waves per CU; the two simple kernels run 32 and find their neighbours in L1 / L2.  Removed.)

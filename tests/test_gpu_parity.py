@@ -694,7 +694,10 @@ def test_linear_logit_class_matches_the_cubic_one():
     eps = np.finfo(np.float32).eps
     np.testing.assert_allclose(outs[0], outs[1], rtol=0, atol=8 * eps)
     # the traced callable closure is recognised as the same 2-coefficient description: same kernel, same bits
-    ref = P.diffeqsolve(P.CahnHilliard2DPeriodic(dom, 0.002, MU["regsol"], MOB["c1mc"]), P.RK4(), 0.0, 8 * 2e-7, 2e-7, y0).ys[-1]
+    eng = P.HipEngine()
+    eng.set_small_persist(-1)
+    ref = P.diffeqsolve(P.CahnHilliard2DPeriodic(dom, 0.002, MU["regsol"], MOB["c1mc"]), P.RK4(), 0.0, 8 * 2e-7, 2e-7, y0, engine=eng).ys[-1]
+    eng.close()
     np.testing.assert_array_equal(outs[0], ref)
 
 
