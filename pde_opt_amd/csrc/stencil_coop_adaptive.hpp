@@ -1014,7 +1014,7 @@ bool coop_plan(const pdeopt_problem& p, int num_cus, CoopPlan* out, int fixed = 
     int64_t wk = 0;
     if (fixed) {  // one round: the right-hand sides of 8 / R halo cells' worth of stages, on their shrinking regions
       for (int e = H - R; e >= 0; e -= R) wk += (int64_t)(tx + 2 * e + (R == 2 ? 1 : 0)) * (ty + 2 * e + (R == 2 ? 1 : 0));
-      return wk + 300 * (int64_t)px * py / 8;
+      return wk + 100 * (int64_t)px * py / 8;  // (tools/coop_fixed_tile_sweep.py: 128^2 6 x 8 tiles 0.744 ms per 100 substeps, 8 x 8 0.703; 192^2 8 x 8 0.871, 12 x 12 0.836)
     }
     for (int s = 1; s <= 6; ++s) wk += (int64_t)(tx + 2 * R * (6 - s) + (R == 2 ? 1 : 0)) * (ty + 2 * R * (6 - s) + (R == 2 ? 1 : 0));
     return wk + 150 * (int64_t)px * py / 8;  // + a little for every partner the barrier waits for
