@@ -988,6 +988,22 @@ inline int coop_radius(int equation) {
 // workgroups (the exchange then stays in one L2 and the barrier needs no cache maintenance: 2 us against 15 us per step,
 // profiles/r04_coop_adaptive.txt), only then among larger grids (fp64 with many static fields: small tiles).
 // Measured on the 100^2 smoothed-boundary solve: 4 x 4 tiles 23 us per trial step, 5 x 5 19.5, 7 x 7 (two XCDs) 39.
+// environments of one launch for a plan: every workgroup of a launch must be resident at once
+struct CoopLaunchShape {
+  int xs, wpx, envs_per_launch;
+};
+inline bool coop_launch_shape(int nwg, int num_cus, CoopLaunchShape* o) {
+  const int cus_per_xcd = std::max(1, num_cus / 8);
+  int xs = 1;
+  while (xs < 8 && (nwg + xs - 1) / xs > cus_per_xcd) xs *= 2;
+  const int wpx = (nwg + xs - 1) / xs;
+  if (wpx > cus_per_xcd) return false;
+  o->xs = xs;
+  o->wpx = wpx;
+  o->envs_per_launch = (cus_per_xcd / wpx) * (8 / xs);
+  return true;
+}
+
 // fixed: 0 = the adaptive solve (H = 6 R, six slope arrays), 1 / 2 = explicit Euler / RK4 substeps (H = 8, one accumulator)
 template <typename T>
 bool coop_plan(const pdeopt_problem& p, int num_cus, CoopPlan* out, int fixed = 0) {
@@ -1026,19 +1042,21 @@ bool coop_plan(const pdeopt_problem& p, int num_cus, CoopPlan* out, int fixed = 
   }
   if (forced) return fits(std::max(1, (p.nx + forced - 1) / forced), std::max(1, (p.ny + forced - 1) / forced), out) && out->px * out->py <= num_cus;
   const int per_xcd = std::max(1, num_cus / 8);
-  // One environment: latency -- the split with the least modelled work per step wherever it lands (the per-step exchange
-  // needs no cache maintenance across XCDs: see coop_env_barrier; the notebook's 100^2 solve: 5 x 6 tiles 16.3 us per trial
-  // step, 7 x 7 14.6, 8 x 8 14.4, 10 x 10 14.3).  A batch: throughput -- an environment on one XCD's compute units where it
-  // fits (8 environments per launch), otherwise on as few workgroups as hold it.
-  const bool latency = p.batch == 1;
-  // (latency: at most 7 of the 8 XCDs' compute units -- a launch that needs EVERY compute unit free waits for any other kernel)
-  for (const int cap : {latency ? num_cus - per_xcd : per_xcd, num_cus}) {
-    int64_t best = -1;
+  // The split with the least modelled TIME for the whole batch: launches x work per step, where a launch holds as many
+  // environments as its workgroups leave room for (every workgroup of a launch is resident at once).  One environment: the
+  // least work per step wherever it lands -- the per-step exchange needs no cache maintenance across XCDs (see the kernel;
+  // the notebook's 100^2 solve: 5 x 6 tiles 16.3 us per trial step, 7 x 7 14.6, 8 x 8 14.4, 10 x 10 14.3); a large batch:
+  // an environment on one XCD's compute units, 8 environments per launch.  At most 7 of the 8 XCDs' compute units per
+  // environment: a launch that needs EVERY compute unit free waits for any other kernel.
+  int64_t best = -1;
+  for (const int cap : {num_cus - per_xcd, num_cus}) {
     for (int px = 1; px <= std::min(p.nx / 4, cap); ++px)
       for (int py = 1; py <= std::min(p.ny / 4, cap / px); ++py) {
         CoopPlan pl;
-        if (!fits(px, py, &pl)) continue;
-        const int64_t wk = (latency || cap == per_xcd) ? work(px, py) : (int64_t)px * py * 1000000 + work(px, py);
+        CoopLaunchShape sh;
+        if (!fits(px, py, &pl) || !coop_launch_shape(px * py, num_cus, &sh)) continue;
+        const int64_t launches = (std::max(1, p.batch) + sh.envs_per_launch - 1) / sh.envs_per_launch;
+        const int64_t wk = launches * work(px, py);
         if (best < 0 || wk < best) {
           best = wk;
           *out = pl;
@@ -1245,22 +1263,6 @@ int coop_tsit5_solve(pdeopt_ctx* ctx, double t0, double t1, double dt0, const pd
 
 
 // ------------------------------------------------------------------------------------- fixed step on several CUs
-
-// environments of one launch for a plan: every workgroup of a launch must be resident at once
-struct CoopLaunchShape {
-  int xs, wpx, envs_per_launch;
-};
-inline bool coop_launch_shape(int nwg, int num_cus, CoopLaunchShape* o) {
-  const int cus_per_xcd = std::max(1, num_cus / 8);
-  int xs = 1;
-  while (xs < 8 && (nwg + xs - 1) / xs > cus_per_xcd) xs *= 2;
-  const int wpx = (nwg + xs - 1) / xs;
-  if (wpx > cus_per_xcd) return false;
-  o->xs = xs;
-  o->wpx = wpx;
-  o->envs_per_launch = (cus_per_xcd / wpx) * (8 / xs);
-  return true;
-}
 
 // Explicit Euler / RK4 with the MODE 1 kernel: when is it the better path?  One launch must hold every environment (the
 // tiled kernels sweep a whole batch per launch; this kernel spends 16 - 100 compute units on ONE environment), and the
