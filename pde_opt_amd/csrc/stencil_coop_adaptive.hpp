@@ -1030,7 +1030,9 @@ bool coop_plan(const pdeopt_problem& p, int num_cus, CoopPlan* out, int fixed = 
     int64_t wk = 0;
     if (fixed) {  // one round: the right-hand sides of 8 / R halo cells' worth of stages, on their shrinking regions
       for (int e = H - R; e >= 0; e -= R) wk += (int64_t)(tx + 2 * e + (R == 2 ? 1 : 0)) * (ty + 2 * e + (R == 2 ? 1 : 0));
-      return wk + 100 * (int64_t)px * py / 8;  // (tools/coop_fixed_tile_sweep.py: 128^2 6 x 8 tiles 0.744 ms per 100 substeps, 8 x 8 0.703; 192^2 8 x 8 0.871, 12 x 12 0.836)
+      // (tools/coop_fixed_tile_sweep.py, 100 substeps: 128^2 6 x 8 tiles 0.744 ms, 8 x 8 0.703, 8 x 10 0.767; 96^2 6 x 6 0.605, 8 x 8 0.673;
+      //  192^2 8 x 8 ... 12 x 12 0.84-0.87: flat)
+      return wk + 200 * (int64_t)px * py / 8;
     }
     for (int s = 1; s <= 6; ++s) wk += (int64_t)(tx + 2 * R * (6 - s) + (R == 2 ? 1 : 0)) * (ty + 2 * R * (6 - s) + (R == 2 ? 1 : 0));
     return wk + 150 * (int64_t)px * py / 8;  // + a little for every partner the barrier waits for
@@ -1287,7 +1289,9 @@ bool coop_fixed_chosen(const pdeopt_ctx* ctx, int integrator, int64_t n) {
   // 0.47; fp64 64^2 0.70 / 1.35 / 1.14, 32^2 0.56 / 1.42 / 0.37
   const int64_t cells = (int64_t)p.nx * p.ny;
   const int64_t lo = sizeof(T) == 8 && p.batch == 1 ? kSmallAutoCells - 1 : kSmallAutoCells;
-  return n >= 8 && p.batch <= sh.envs_per_launch && cells > lo && cells <= 192 * 192;
+  // (up to 16 environments on >= 16 compute units each -- 16 x 96^2: 0.73 ms against 1.29 tiled, 16 x 128^2: 0.87 / 0.85;
+  // beyond that the tiled kernels' one launch per batch is the better use of the chip)
+  return n >= 8 && p.batch <= 16 && p.batch <= sh.envs_per_launch && pl.px * pl.py >= 16 && cells > lo && cells <= 192 * 192;
 }
 
 template <typename T>
