@@ -345,8 +345,8 @@ int advance_explicit(pdeopt_ctx* ctx, int integrator, double t0, double dt, int6
   // one environment (or a few) of a mid-sized grid: several compute units per environment, all substeps in one launch
   // (stencil_coop_adaptive.hpp, MODE 1)
   const bool coop = ctx->prob.dtype == PDEOPT_F32 ? coop_fixed_chosen<float>(ctx, integrator, n) : coop_fixed_chosen<double>(ctx, integrator, n);
-  const bool f64_one_env = ctx->prob.dtype == PDEOPT_F64 && ctx->prob.batch == 1;  // (64^2 fp64: 0.70 ms against the one-CU kernel's 1.14)
-  if (coop && (ctx->opt_small_persist == 2 || f64_one_env || !small_chosen(ctx, integrator, n))) {
+  const bool f64 = ctx->prob.dtype == PDEOPT_F64;  // (64^2 fp64: 0.70 ms against the one-CU kernel's 1.14, which small_chosen would pick)
+  if (coop && (ctx->opt_small_persist == 2 || f64 || !small_chosen(ctx, integrator, n))) {
     ctx->win_lo = 0;
     ctx->win_n = ctx->prob.batch;
     ctx->last_groups = 1;

@@ -1288,7 +1288,7 @@ bool coop_fixed_chosen(const pdeopt_ctx* ctx, int integrator, int64_t n) {
   // / tiled / one CU: fp32 96^2 0.61 / 1.30 / 1.63 ms, 128^2 0.69 / 0.84 / 1.65, 256^2 0.92 / 0.88 / -; 64^2 0.54 / 0.82 /
   // 0.47; fp64 64^2 0.70 / 1.35 / 1.14, 32^2 0.56 / 1.42 / 0.37
   const int64_t cells = (int64_t)p.nx * p.ny;
-  const int64_t lo = sizeof(T) == 8 && p.batch == 1 ? kSmallAutoCells - 1 : kSmallAutoCells;
+  const int64_t lo = sizeof(T) == 8 ? kSmallAutoCells - 1 : kSmallAutoCells;  // (fp64 64^2: 0.70 ms, 16 of them 0.79, against the one-CU kernel's 1.15)
   // (up to 16 environments on >= 16 compute units each -- 16 x 96^2: 0.73 ms against 1.29 tiled, 16 x 128^2: 0.87 / 0.85;
   // beyond that the tiled kernels' one launch per batch is the better use of the chip)
   return n >= 8 && p.batch <= 16 && p.batch <= sh.envs_per_launch && pl.px * pl.py >= 16 && cells > lo && cells <= 192 * 192;
