@@ -186,8 +186,7 @@ typedef enum {
                                  -1 = never; 2 = as 1, and the multi-workgroup kernel (stencil_coop_adaptive.hpp: several
                                  compute units per environment) is preferred wherever it can run -- for the adaptive
                                  solve and for Euler / RK4.  In auto mode that kernel takes Euler / RK4 advances of >= 8
-                                 substeps of up to 8 environments of 65^2 ... 192^2 cells (fp64: one environment from
-                                 64^2 on) and the adaptive solves one compute unit cannot hold */
+                                 substeps of up to 16 environments of 65^2 ... 192^2 cells (fp64: from 64^2 on) and the adaptive solves one compute unit cannot hold */
   PDEOPT_OPT_GROUP_STREAMS = 9,/* explicit integrators running the batch in cache-resident groups: 0 = auto (two groups
                                   side by side on two HIP streams, each half the size, so that one group's launch
                                   fills the other's ramp and tail), 1 = one group at a time, 2 = force two */
