@@ -1,13 +1,16 @@
 #!/bin/bash
 cd ${GRAFT_REPO_ROOT:-.}
 mkdir -p gpurun_out
-O=gpurun_out/exp11.txt
+O=gpurun_out/exp12.txt
 : > $O
-timeout 1500 python -m pytest tests -q -m gpu > gpurun_out/pytest_gpu.log 2>&1
-grep -E "passed|failed" gpurun_out/pytest_gpu.log | tail -2 >> $O
-grep -E "^FAILED|^ERROR" gpurun_out/pytest_gpu.log | head -20 >> $O
-timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1 >> $O
-timeout 400 python tools/small_grid_bench.py ch > gpurun_out/small_grid_ch.txt 2>&1
-grep "float32   96^2\|float32  128^2\|float64   64^2\|float64   96^2\|float32   64^2 x   1" gpurun_out/small_grid_ch.txt >> $O
-timeout 120 python bench.py --steps 5 --warmup 2 --no-cpu-baseline 2>/dev/null | tail -1 | cut -c1-200 >> $O
-cat $O | cut -c1-220
+echo "== config 2 (AC 512^2 x 64): environment groups x streams" >> $O
+for r in 1 2; do
+for ge in 0 8 16 32 -1; do
+  for gs in 0 1 2; do
+    timeout 120 python bench.py --workload ac_rk4_512_f32 --group-envs $ge --group-streams $gs --no-cpu-baseline --no-parity-spot --no-api --steps 10 --warmup 3 2>/dev/null | tail -1 | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('group-envs $ge streams $gs', round(d['value'],0), 'env-steps/s', d['config'].get('kernel'), d['roofline'].get('concurrent_launches'), round(d['roofline']['avg_launch_us'],1))" >> $O 2>&1
+  done
+done
+done
+cat $O
