@@ -66,6 +66,10 @@ WORKLOADS = {
     "ch_rk4_64_f32_small": dict(eq="ch", n=64, dtype=np.float32, integ="rk4", dt=2e-7, substeps=100, batch=256),
     "ch_rk4_128_f32_small": dict(eq="ch", n=128, dtype=np.float32, integ="rk4", dt=2e-7, substeps=100, batch=256),
     "ac_rk4_64_f32_small": dict(eq="ac", n=64, dtype=np.float32, integ="rk4", dt=5e-5, substeps=100, batch=256),
+    # ONE mid-sized environment (single-environment latency: the RL loop of pde_env.py:244-317 on one 96^2 / 128^2 field):
+    # several compute units per environment, 1-2 substeps per neighbour exchange (csrc/stencil_coop_adaptive.hpp, MODE 1)
+    "ch_rk4_96_f32_1env": dict(eq="ch", n=96, dtype=np.float32, integ="rk4", dt=2e-7, substeps=100, batch=1),
+    "ch_rk4_128_f32_1env": dict(eq="ch", n=128, dtype=np.float32, integ="rk4", dt=2e-7, substeps=100, batch=1),
     # smoothed-boundary Cahn-Hilliard (cahn_hilliard.py:204-289) on the LDS-tiled kernel: a disc-shaped
     # level set, regular-solution free energy, contact angle and boundary flux varying in time (notebooks/smooth_boundary.ipynb)
     "ch_sbm_1024_f32": dict(eq="ch_sbm", n=1024, dtype=np.float32, integ="rk4", dt=2e-3, substeps=100, batch=8, words="rk4_sbm",

@@ -26,7 +26,7 @@ timeout 900 bash tools/pmc_busy.sh busy > gpurun_out/busy_summary.txt 2>&1
 timeout 120 bash tools/make_pmc_json.sh $TAG
 cp profiles/pmc_$TAG.json gpurun_out/round/pmc_$TAG.json
 timeout 600 python bench.py > gpurun_out/round/bench.json 2> gpurun_out/round/bench.err
-for w in $SECONDARY gpe_strang_512_c64_spots ch_rk4_1024_f32_cubic ch_rk4_4096_decomp ch_sbm_100_tsit5_f64 ch_sbm_100_tsit5_theta ad_64_tsit5; do
+for w in $SECONDARY gpe_strang_512_c64_spots ch_rk4_1024_f32_cubic ch_rk4_4096_decomp ch_sbm_100_tsit5_f64 ch_sbm_100_tsit5_theta ad_64_tsit5 ch_rk4_96_f32_1env ch_rk4_128_f32_1env; do
   timeout 400 python bench.py --workload $w --steps 10 --warmup 3 2>/dev/null | tail -1 > gpurun_out/round/bench_$w.json
 done
 timeout 300 python bench.py --workload ch_rk4_4096_decomp --virtual-ranks 4 --no-cpu-baseline --steps 5 --warmup 2 2>/dev/null | tail -1 > gpurun_out/round/bench_decomp_4_virtual_ranks_one_gpu.json
