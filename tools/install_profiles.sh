@@ -8,7 +8,7 @@ R=gpurun_out/round
 cp $R/bench.json profiles/${TAG}_bench.json
 cp $R/ch_rk4_1024_f32/summary.txt profiles/${TAG}_ch_rk4_1024_f32_summary.txt
 cp $(ls -t $R/ch_rk4_1024_f32/trace/*/*kernel_stats.csv | head -1) profiles/${TAG}_ch_rk4_1024_f32_kernel_stats.csv
-for w in ac_rk4_512_f32 ch_imex_1024_f32 gpe_strang_512_c64 ch_rk4_1024_f64 ch_rk4_64_f32_small ch_rk4_128_f32_small ac_rk4_64_f32_small ch_sbm_1024_f32 ch3d_rk4_128_f32 ch_sbm_100_tsit5 decomp_tile2048; do
+for w in ac_rk4_512_f32 ch_imex_1024_f32 gpe_strang_512_c64 ch_rk4_1024_f64 ch_rk4_64_f32_small ch_rk4_128_f32_small ac_rk4_64_f32_small ch_sbm_1024_f32 ch3d_rk4_128_f32 ch_sbm_100_tsit5 ch_rk4_128_f32_1env decomp_tile2048; do
   [ -f $R/${w}_trace_summary.txt ] && cp $R/${w}_trace_summary.txt profiles/${TAG}_${w}_trace_summary.txt
 done
 [ -f gpurun_out/small_grid_ch.txt ] && cp gpurun_out/small_grid_ch.txt profiles/${TAG}_small_grid_ch.txt

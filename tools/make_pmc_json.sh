@@ -19,6 +19,7 @@ python tools/pmc_to_json.py ac_rk4_64_f32_small ${TAG} "small_persist_kernel" $R
 python tools/pmc_to_json.py ch_sbm_1024_f32 ${TAG} "sbm_tiled_kernel" $R/pmc_ch_sbm_1024_f32/pmc_fetch $R/pmc_ch_sbm_1024_f32/pmc_write $R/pmc_ch_sbm_1024_f32/pmc_valu > /dev/null 2>&1
 python tools/pmc_to_json.py ch3d_rk4_128_f32 ${TAG} "ch3d_mu_kernel|ch3d_stage_kernel" $R/pmc_ch3d_rk4_128_f32/pmc_fetch $R/pmc_ch3d_rk4_128_f32/pmc_write $R/pmc_ch3d_rk4_128_f32/pmc_valu > /dev/null 2>&1
 python tools/pmc_to_json.py ch_sbm_100_tsit5 ${TAG} "tsit5_coop_kernel" $R/pmc_ch_sbm_100_tsit5/pmc_fetch $R/pmc_ch_sbm_100_tsit5/pmc_write $R/pmc_ch_sbm_100_tsit5/pmc_valu > /dev/null 2>&1
+python tools/pmc_to_json.py ch_rk4_128_f32_1env ${TAG} "tsit5_coop_kernel" $R/pmc_ch_rk4_128_f32_1env/pmc_fetch $R/pmc_ch_rk4_128_f32_1env/pmc_write $R/pmc_ch_rk4_128_f32_1env/pmc_valu > /dev/null 2>&1
 # the decomposed field's own kernel(s) at the tile sizes a gpurun box can run (one rank: 2048^2 = the 2 x 2 share of config 5; 4096^2 whole)
 python tools/pmc_to_json.py ch_rk4_decomp_tile2048x2048 ${TAG} "ch_rk4_quad_kernel|stage_pair_kernel" $R/pmc_decomp_tile2048/pmc_fetch $R/pmc_decomp_tile2048/pmc_write $R/pmc_decomp_tile2048/pmc_valu > /dev/null 2>&1
 python tools/pmc_to_json.py ch_rk4_decomp_tile4096x4096 ${TAG} "ch_rk4_quad_kernel|stage_pair_kernel" $R/pmc_decomp_tile4096/pmc_fetch $R/pmc_decomp_tile4096/pmc_write $R/pmc_decomp_tile4096/pmc_valu > /dev/null 2>&1

@@ -7,7 +7,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $ROOT
 mkdir -p gpurun_out/round
 timeout 1500 bash tools/profile_gpu.sh round/ch_rk4_1024_f32 > /dev/null 2>&1
-SECONDARY="ac_rk4_512_f32 ch_imex_1024_f32 gpe_strang_512_c64 ch_rk4_1024_f64 ch_rk4_64_f32_small ch_rk4_128_f32_small ac_rk4_64_f32_small ch_sbm_1024_f32 ch3d_rk4_128_f32 ch_sbm_100_tsit5"
+SECONDARY="ac_rk4_512_f32 ch_imex_1024_f32 gpe_strang_512_c64 ch_rk4_1024_f64 ch_rk4_64_f32_small ch_rk4_128_f32_small ac_rk4_64_f32_small ch_sbm_1024_f32 ch3d_rk4_128_f32 ch_sbm_100_tsit5 ch_rk4_128_f32_1env"
 for w in $SECONDARY; do
   timeout 400 bash tools/trace_only.sh round/$w --workload $w > gpurun_out/round/${w}_trace_summary.txt 2>&1
 done
