@@ -181,6 +181,9 @@ __device__ __forceinline__ void xstore(T* p, T v) { __hip_atomic_store(p, v, __A
 #define PDEOPT_COOP_THREADS 512  // 1024 threads cap a thread at 128 registers: the step loop's uniform doubles then spill (48-140 B fp32)
 #endif
 // the fixed-step mode holds no slopes and no controller: 51 - 95 registers in fp32 -> 1024 threads, 4 waves per SIMD
+#ifndef PDEOPT_COOP_FIXED_NEIGHBOURS
+#define PDEOPT_COOP_FIXED_NEIGHBOURS 1  // the fixed-step mode's exchange waits for the 8 neighbouring workgroups only
+#endif
 #ifndef PDEOPT_COOP_FIXED_THREADS_F32
 #define PDEOPT_COOP_FIXED_THREADS_F32 1024
 #endif
@@ -637,7 +640,18 @@ __global__ __launch_bounds__((coop_threads<T, MODE>())) void tsit5_coop_kernel(c
       if (tid < 64) {
         const unsigned long long t_in = __builtin_amdgcn_s_memrealtime();
         bool gave_up = false;
-        for (int i = tid; i < nwg; i += 64) {
+        // Whom to wait for: the workgroups whose tiles this one's ring is read from, and who read this one's tile -- the 8
+        // neighbours when every tile is at least H cells wide and high (lanes 0 .. 7, one each; workgroups further away may
+        // be a round ahead or behind: no environment-wide rendezvous), else everybody.
+        const bool near_only = PDEOPT_COOP_FIXED_NEIGHBOURS && nx / a.px >= H && ny / a.py >= H;
+        const int n_wait = near_only ? 8 : nwg;
+        for (int q = tid; q < n_wait; q += 64) {
+          int i = q;
+          if (near_only) {
+            const int di = q < 3 ? -1 : (q < 5 ? 0 : 1);                       // rows of the 3 x 3 block without its centre
+            const int dj = q < 3 ? q - 1 : (q < 5 ? (q == 3 ? -1 : 1) : q - 6);
+            i = wrap1(wi + di, a.px) * a.py + wrap1(wj + dj, a.py);
+          }
           for (;;) {
             if (xload(&tags[i]) >= tag) break;
             if (xload(a.abort_flag) != 0u) {
