@@ -130,6 +130,23 @@ def test_advection_diffusion_fixed_step(dtype):
         assert abs(float(got.astype(np.float64).mean() - y0.astype(np.float64).mean())) < (1e-12 if dtype is np.float64 else 1e-6)
 
 
+def test_tiles_narrower_than_the_halo_wait_for_every_workgroup(monkeypatch):
+    """tiles of 6 x 6 cells under an 8-cell halo: a ring reaches two tiles away, so the exchange waits for every workgroup
+    of the environment instead of the 8 neighbours (PDEOPT_COOP_TILE forces the tile edge)"""
+    monkeypatch.setenv("PDEOPT_COOP_TILE", "6")
+    nx, ny = 48, 60
+    dom = std_domain(P, nx, ny)
+    rng = np.random.default_rng(9)
+    eq = P.CahnHilliard2DPeriodic(dom, 0.002, MU["regsol"], MOB["c1mc"])
+    y0 = np.clip(0.5 + 0.05 * rng.standard_normal((1, nx, ny)), 0.05, 0.95)
+    got, kern = _advance(eq, y0, L.INT_RK4, 2e-7, 9, 2)
+    assert kern.startswith("rk4_coop") and "8x10 workgroups" in kern, kern
+    ref = y0[0]
+    for i in range(9):
+        ref = O.rk4_step(lambda t, u: O.ch_rhs_fd(u, *dom.dx, 0.002, MU["regsol"], MOB["c1mc"]), 0.0, ref, 2e-7)
+    assert rel_l2(got[0] - y0[0], ref - y0[0]) < 1e-9
+
+
 def test_auto_policy():
     """one mid-sized environment and enough substeps: several CUs per environment; a batch the tiled kernels sweep in one
     launch, a few substeps, a grid of the one-CU kernel's range or a caller-chosen tiled knob: the other paths"""
