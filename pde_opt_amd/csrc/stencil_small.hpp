@@ -192,7 +192,11 @@ struct SmallTile {
   }
 };
 
-template <typename T, int EQ, int CL, int KMAX, int NTMAX>
+// DB: the stage input is double-buffered in LDS ([input A][mu][input B]: three arrays, where they fit) -- a stage's update
+// writes the next input straight into the idle buffer while neighbours may still read the current one, so a stage costs
+// two barriers (mu pass | flux + update) instead of three (... | publish), Allen-Cahn one instead of two, and the next
+// input needs no registers (stencil_small_adaptive.hpp's scheme).  Same formulas, same bits.
+template <typename T, int EQ, int CL, int KMAX, int NTMAX, bool DB = false>
 __global__ __launch_bounds__(NTMAX) void small_persist_kernel(const SmallArgs<T> a) {
   using Tile = SmallTile<T, EQ, CL, KMAX>;
   using Vec = typename Tile::Vec;
@@ -200,6 +204,39 @@ __global__ __launch_bounds__(NTMAX) void small_persist_kernel(const SmallArgs<T>
   const int b = blockIdx.x;
   T* const yg = a.y + (int64_t)b * a.bstride;
   Tile tile;
+  if constexpr (DB) {
+    Vec y[KMAX], acc[KMAX];
+    tile.init(smem_raw, a.nx, a.ny, a.ep + b, a.mu, a.mob, a.rhx, a.rhy, a.rhx2, a.rhy2, yg, y);
+    T* sNext = tile.sU + 2 * tile.cells;
+    auto put = [&](int k, const Vec v) { *reinterpret_cast<Vec*>(sNext + tile.oc[k]) = v; };
+    auto flip = [&]() {  // the next input is complete once every thread is here; the current one is then free
+      __syncthreads();
+      T* const tmp = tile.sU;
+      tile.sU = sNext;
+      sNext = tmp;
+    };
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) acc[k] = Vec{};
+    for (int64_t s = 0; s < a.n; ++s) {
+      if (a.rk4) {
+        tile.rhs([&](int k, const Vec kv) { put(k, y[k] + a.h2 * kv); acc[k] = y[k] + a.h6 * kv; });
+        flip();
+        tile.rhs([&](int k, const Vec kv) { put(k, y[k] + a.h2 * kv); acc[k] = acc[k] + a.h3 * kv; });
+        flip();
+        tile.rhs([&](int k, const Vec kv) { put(k, y[k] + a.dt * kv); acc[k] = acc[k] + a.h3 * kv; });
+        flip();
+        tile.rhs([&](int k, const Vec kv) { y[k] = acc[k] + a.h6 * kv; put(k, y[k]); });
+        flip();
+      } else {
+        tile.rhs([&](int k, const Vec kv) { y[k] = y[k] + a.dt * kv; put(k, y[k]); });
+        flip();
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k)
+      if (tile.own(k)) *reinterpret_cast<Vec*>(yg + tile.oc[k]) = y[k];
+    return;
+  }
   Vec y[KMAX], acc[KMAX], w[KMAX];
   tile.init(smem_raw, a.nx, a.ny, a.ep + b, a.mu, a.mob, a.rhx, a.rhy, a.rhx2, a.rhy2, yg, y);
 #pragma unroll
@@ -234,6 +271,9 @@ inline size_t small_lds_bytes(const pdeopt_ctx* ctx) {
 }
 
 constexpr size_t kSmallLdsMax = 160 * 1024;
+#ifndef PDEOPT_SMALL_DOUBLE_BUFFER
+#define PDEOPT_SMALL_DOUBLE_BUFFER 1
+#endif
 constexpr int kSmallMaxVec = 8 * 512;  // vectors of one environment: 8 per thread of the 512-thread form (10 spill)
 // auto policy (stencil.hip: small_chosen)
 // measured, 100 RK4 substeps, Cahn-Hilliard fp32, whole-step vs tiled (tools/small_grid_bench.py, profiles/r03_small_grid.txt):
@@ -286,6 +326,9 @@ int launch_small_k(pdeopt_ctx* ctx, const SmallArgs<T>& s, int nt, int kmax, siz
     PDEOPT_HIP_CHECK(ctx, hipGetLastError());
     return PDEOPT_OK;
   };
+  // room for the double-buffered stage input (launch_small decides; grids of that size run 1 or 2 vectors per thread)
+  if (lds >= (size_t)3 * s.nx * s.ny * sizeof(T) && (nt > 512 || kmax <= 2))
+    return kmax <= 1 ? go(small_persist_kernel<T, EQ, CL, 1, 1024, true>) : go(small_persist_kernel<T, EQ, CL, 2, 1024, true>);
   if (nt > 512 || kmax <= 2) return kmax <= 1 ? go(small_persist_kernel<T, EQ, CL, 1, 1024>) : go(small_persist_kernel<T, EQ, CL, 2, 1024>);
   return go(small_persist_kernel<T, EQ, CL, 8, 512>);
 }
@@ -313,11 +356,15 @@ int launch_small(pdeopt_ctx* ctx, int integrator, double dt, int64_t n) {
   const int64_t nvec = (int64_t)d.nx * (d.ny / V);
   int nt, kmax;
   small_shape(nvec, &nt, &kmax);
-  const size_t lds = small_lds_bytes<T>(ctx);
+  // the stage input double-buffered where three arrays leave room for a second workgroup on the CU (<= 80 KB: up to 64^2
+  // fp32 -- the grids that run two environments per CU in large batches)
+  const size_t lds3 = (size_t)3 * d.nx * d.ny * sizeof(T);
+  const bool db = PDEOPT_SMALL_DOUBLE_BUFFER && lds3 <= kSmallLdsMax / 2;
+  const size_t lds = db ? lds3 : small_lds_bytes<T>(ctx);
   const int cl = classify_closures(p.mu, p.mob);
-  char name[96];
-  snprintf(name, sizeof(name), "small_persist<%s,%s,%s,%dx%d threads,%d vec/thread>", sizeof(T) == 4 ? "f32" : "f64",
-           p.equation == PDEOPT_EQ_ALLEN_CAHN ? "AC" : "CH", cl == CL_LOGIT ? "logit" : "poly", 1, nt, kmax);
+  char name[112];
+  snprintf(name, sizeof(name), "small_persist<%s,%s,%s,%dx%d threads,%d vec/thread%s>", sizeof(T) == 4 ? "f32" : "f64",
+           p.equation == PDEOPT_EQ_ALLEN_CAHN ? "AC" : "CH", cl == CL_LOGIT ? "logit" : "poly", 1, nt, kmax, db ? ",2 inputs" : "");
   ctx->last_kernel = name;
   ctx->n_stage_launches++;
   if (p.equation == PDEOPT_EQ_CAHN_HILLIARD) {
