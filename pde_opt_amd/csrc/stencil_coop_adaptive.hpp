@@ -120,12 +120,19 @@ __device__ __forceinline__ int wrap1(int i, int n) {  // |offset| <= n: one cond
 
 constexpr unsigned long long kCoopTimeoutTicks = 200000000ull;  // 2 s of s_memrealtime (100 MHz)
 
+// Every store this wave has issued is acknowledged at its scope once this returns.  __syncthreads() alone does NOT give
+// that: its workgroup-scope release needs no vmcnt wait when the workgroup's waves share one CU (the compiler emits
+// `s_waitcnt lgkmcnt(0); s_barrier`), so a slot word stored by one wave behind the barrier could become visible to a
+// partner before another wave's tile data -- seen once in ~10 runs of the fixed-step mode as a stale ring (an error of
+// one round's increment in a few cells), never in the adaptive step, whose reduction sits between data and slot stores.
+__device__ __forceinline__ void coop_stores_done() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 // Counter barrier over the nwg workgroups of one environment (the solve's prologue; the step loop's barrier is the slot
 // exchange in the kernel).  false: the solve was aborted (a partner did not arrive).  one_xcd = no fences: the exchange
 // data is written and read with agent-scope accesses (xstore / xload below), which need no cache maintenance -- see the
 // kernel; otherwise (-DPDEOPT_COOP_XCD_FENCES=1) agent-scope release / acquire fences write the L2 back and invalidate it.
 __device__ __forceinline__ bool coop_env_barrier(unsigned* bar, unsigned* abort_flag, int nwg, unsigned* gen, bool one_xcd) {
-  __syncthreads();  // every wave's stores have been acknowledged (s_waitcnt vmcnt(0) precedes the s_barrier)
+  coop_stores_done();
+  __syncthreads();  // every wave's stores have been acknowledged
   if (threadIdx.x == 0) {
     if (!one_xcd) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     const unsigned g = *gen;
@@ -262,7 +269,7 @@ __global__ __launch_bounds__((coop_threads<T, MODE>())) void tsit5_coop_kernel(c
   // take it past the caches that are not coherent at that scope -- the per-CU vector cache, and the per-XCD L2 when the
   // partner sits on another XCD -- so an environment spread over several XCDs needs no release / acquire fences (an L2
   // write-back + invalidate per barrier: 6.5 us on one XCD, 15 us across two, measured in this kernel's first version)
-  // either.  Ordering: a workgroup's data stores are acknowledged (s_waitcnt vmcnt(0) in front of the s_barrier) before its
+  // either.  Ordering: a workgroup's data stores are acknowledged (every wave: s_waitcnt vmcnt(0), then the s_barrier) before its
   // slot word is stored; a reader issues its data loads after it has seen the slot words.  -DPDEOPT_COOP_XCD_FENCES=1
   // keeps the fenced counter barrier for environments on several XCDs (384^2 CH: 61 us per trial step against 45).
 #ifndef PDEOPT_COOP_XCD_FENCES
@@ -634,6 +641,7 @@ __global__ __launch_bounds__((coop_threads<T, MODE>())) void tsit5_coop_kernel(c
       // between, i.e. has finished reading this one.
       T* const xb = a.xy[round & 1u] + xoff;
       region(0, [&](int o, int r, int c) { xstore(&xb[(int64_t)(i0 + r) * ny + (j0 + c)], y[o]); });
+      coop_stores_done();
       __syncthreads();  // every wave's exchange stores have been acknowledged
       const unsigned tag = round + 1u;
       if (tid == 0) xstore(&tags[w], tag);
@@ -830,6 +838,7 @@ __global__ __launch_bounds__((coop_threads<T, MODE>())) void tsit5_coop_kernel(c
     const unsigned tag = step + 1u;
     bool aborted = false;
     if (one_xcd) {
+      coop_stores_done();
       __syncthreads();  // every wave's exchange stores have been acknowledged, red[] is complete
       if (tid == 0) {
         double sum = 0.0;
