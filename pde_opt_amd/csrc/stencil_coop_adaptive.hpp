@@ -194,13 +194,18 @@ __device__ __forceinline__ void xstore(T* p, T v) { __hip_atomic_store(p, v, __A
 #ifndef PDEOPT_COOP_FIXED_THREADS_F32
 #define PDEOPT_COOP_FIXED_THREADS_F32 1024
 #endif
-template <typename T, int MODE>
-constexpr int coop_threads() { return MODE == 1 && sizeof(T) == 4 ? PDEOPT_COOP_FIXED_THREADS_F32 : PDEOPT_COOP_THREADS; }
+// (fp64: the fixed-closure periodic forms and advection-diffusion need 60 - 84 registers -> 1024 threads as well; the
+// smoothed-boundary forms (128 - 130) and the run-time closure walk stay at 512)
+template <typename T, int MODE, int EQ, bool FAST>
+constexpr int coop_threads() {
+  constexpr bool sbm = EQ == PDEOPT_EQ_ALLEN_CAHN_SBM || EQ == PDEOPT_EQ_CAHN_HILLIARD_SBM;
+  return MODE == 1 && (sizeof(T) == 4 || (FAST && !sbm)) ? PDEOPT_COOP_FIXED_THREADS_F32 : PDEOPT_COOP_THREADS;
+}
 // MODE 0: the adaptive Tsit5 solve.  MODE 1: n_sub substeps of explicit Euler / classical RK4 on the same tiling (one
 // environment on several compute units; see the fixed-step loop below).
 template <typename T, int EQ, bool FAST, int MODE = 0>
-__global__ __launch_bounds__((coop_threads<T, MODE>())) void tsit5_coop_kernel(const CoopArgs<T> a) {
-  constexpr int NT = coop_threads<T, MODE>();
+__global__ __launch_bounds__((coop_threads<T, MODE, EQ, FAST>())) void tsit5_coop_kernel(const CoopArgs<T> a) {
+  constexpr int NT = coop_threads<T, MODE, EQ, FAST>();
   constexpr bool kTwoPass = EQ == PDEOPT_EQ_CAHN_HILLIARD || EQ == PDEOPT_EQ_CAHN_HILLIARD_SBM;  // mu / inner array
   constexpr bool kSBM = EQ == PDEOPT_EQ_ALLEN_CAHN_SBM || EQ == PDEOPT_EQ_CAHN_HILLIARD_SBM;
   constexpr bool kAD = EQ == PDEOPT_EQ_ADVECTION_DIFFUSION;
@@ -1314,7 +1319,7 @@ bool coop_fixed_chosen(const pdeopt_ctx* ctx, int integrator, int64_t n) {
   const int64_t lo = sizeof(T) == 8 ? kSmallAutoCells - 1 : kSmallAutoCells;  // (fp64 64^2: 0.70 ms, 16 of them 0.79, against the one-CU kernel's 1.15)
   // (up to 16 environments on >= 16 compute units each -- 16 x 96^2: 0.73 ms against 1.29 tiled, 16 x 128^2: 0.87 / 0.85;
   // beyond that the tiled kernels' one launch per batch is the better use of the chip)
-  return n >= 8 && p.batch <= 16 && p.batch <= sh.envs_per_launch && pl.px * pl.py >= 16 && cells > lo && cells <= 192 * 192;
+  return n >= 8 && p.batch <= 16 && p.batch <= sh.envs_per_launch && pl.px * pl.py >= 16 && cells > lo && cells <= (sizeof(T) == 8 ? 256 * 256 : 192 * 192);  // (fp64 256^2: 1.08 ms against the stage pairs' 1.44)
 }
 
 template <typename T>
@@ -1388,6 +1393,8 @@ int coop_fixed_advance(pdeopt_ctx* ctx, int integrator, double t0, double dt, in
 #undef PDEOPT_COOP_KF
   }();
   PDEOPT_HIP_CHECK(ctx, hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds));
+  // (coop_threads<T, 1, EQ, FAST>() of the instantiation picked above)
+  const int nthreads = sizeof(T) == 4 || (fast && !sbm) ? PDEOPT_COOP_FIXED_THREADS_F32 : PDEOPT_COOP_THREADS;
   const T* s0 = nullptr; const T* s1 = nullptr; const T* s2 = nullptr;
   int64_t sstride = 0;
   if (sbm) {
@@ -1415,7 +1422,7 @@ int coop_fixed_advance(pdeopt_ctx* ctx, int integrator, double t0, double dt, in
     c.abort_flag = abort_dev;
     const int rows_used = (ne + 8 / sh.xs - 1) / (8 / sh.xs);
     void* params[] = {&c};
-    PDEOPT_HIP_CHECK(ctx, hipLaunchKernel(kern, dim3(8 * rows_used * sh.wpx), dim3(coop_threads<T, 1>()), params, pl.lds, ctx->stream));
+    PDEOPT_HIP_CHECK(ctx, hipLaunchKernel(kern, dim3(8 * rows_used * sh.wpx), dim3(nthreads), params, pl.lds, ctx->stream));
     ctx->n_stage_launches++;
   }
   unsigned aborted = 0;
