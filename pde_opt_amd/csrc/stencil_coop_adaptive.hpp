@@ -831,20 +831,19 @@ __global__ __launch_bounds__((coop_threads<T, MODE, EQ, FAST>())) void tsit5_coo
 #pragma unroll
     for (int sft = 32; sft > 0; sft >>= 1) part += __shfl_down(part, sft, 64);
     if ((tid & 63) == 0) red[tid >> 6] = part;
-    __syncthreads();
+    coop_stores_done();  // (this wave's y1 / k7 stores; the wait overlaps the other waves' reductions)
+    __syncthreads();     // red[] is complete and every wave's exchange stores have been acknowledged
     PDEOPT_COOP_TICK(2);
     // The per-step barrier IS the exchange of the partial norms: a workgroup posts its sum as two 64-bit words, each
     // carrying 32 bits of the double and the step's tag, into its slot of the step's parity; wave 0 of every workgroup
     // polls all slots (one lane each) until both tags match.  One store + one poll round per workgroup instead of an
     // atomic counter round trip, a generation word and a second read of the sums (one XCD: ~1 us less per step).  Slots
     // alternate by parity: a workgroup reaches its next write of a slot only after every partner has posted the step
-    // between, i.e. has finished reading this one.  Across XCDs the counter barrier with its fences stays.
+    // between, i.e. has finished reading this one.  (-DPDEOPT_COOP_XCD_FENCES=1: across XCDs the fenced counter barrier instead.)
     double* const parts = a.part + ((size_t)(step & 1u) * a.nenv + be) * nwg * 2;  // two words per workgroup
     const unsigned tag = step + 1u;
     bool aborted = false;
     if (one_xcd) {
-      coop_stores_done();
-      __syncthreads();  // every wave's exchange stores have been acknowledged, red[] is complete
       if (tid == 0) {
         double sum = 0.0;
         for (int i = 0; i < NT / 64; ++i) sum += red[i];
