@@ -840,6 +840,22 @@ __global__ __launch_bounds__((coop_threads<T, MODE, EQ, FAST>())) void tsit5_coo
     // atomic counter round trip, a generation word and a second read of the sums (one XCD: ~1 us less per step).  Slots
     // alternate by parity: a workgroup reaches its next write of a slot only after every partner has posted the step
     // between, i.e. has finished reading this one.  (-DPDEOPT_COOP_XCD_FENCES=1: across XCDs the fenced counter barrier instead.)
+    // The controller: ONE lane per workgroup (the same arithmetic on the same partial sums in the same order in every
+    // workgroup: one decision for the environment), broadcast through LDS -- all waves running the double-precision
+    // pow / sqrt / divisions redundantly cost 6 us per step (14 k ticks), a lone lane ~1
+    auto controller = [&]() {
+      double sum = 0.0;
+      for (int i = 0; i < nwg; ++i) sum += red[24 + i];  // one order in every workgroup: the same double everywhere
+      const double err = sqrt(sum * inv_cells);  // diffrax rms_norm
+      const bool keep_ = err < 1.0;              // a NaN norm rejects
+      const double inv_ = (err > 0.0 && err < __builtin_inf()) ? 1.0 / err : (err == 0.0 ? __builtin_inf() : 0.0);
+      double f_ = pid_term(inv_, a.pid.k1, a.pid) * pid_term(prev_inv, a.pid.k2, a.pid) * pid_term(prev_prev_inv, a.pid.k3, a.pid);
+      f_ = fmin(a.pid.factormax, fmax(a.pid.factormin, a.pid.safety * f_));
+      if (!keep_) f_ = fmin(1.0, f_);
+      red[19] = keep_ ? 1.0 : 0.0;
+      red[20] = inv_;
+      red[21] = f_;
+    };
     double* const parts = a.part + ((size_t)(step & 1u) * a.nenv + be) * nwg * 2;  // two words per workgroup
     const unsigned tag = step + 1u;
     bool aborted = false;
@@ -879,7 +895,15 @@ __global__ __launch_bounds__((coop_threads<T, MODE, EQ, FAST>())) void tsit5_coo
         // global-memory round trip to learn that nobody gave up (an abort raised elsewhere after this workgroup passed
         // is met at the next step's poll, where the partner's slot stays missing)
         const bool any = __any(gave_up);
-        if (tid == 0) red[22] = any ? 1.0 : 0.0;
+        // the polling wave's lane 0 runs the controller straight away: the sums it needs were staged by its own wave
+        // (LDS operations of one wave complete in order), so the step needs one workgroup barrier here, not two
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (tid == 0) {
+          red[22] = any ? 1.0 : 0.0;
+          if (!any) controller();
+        }
       }
       __syncthreads();
       aborted = red[22] != 0.0;
@@ -900,23 +924,11 @@ __global__ __launch_bounds__((coop_threads<T, MODE, EQ, FAST>())) void tsit5_coo
 #ifdef PDEOPT_COOP_RING_EARLY  // (measured slower: the fetched values live across the dense-output code and spill)
     if (ring_in_regs) ring_fetch(a.xy[cur ^ 1] + xoff, a.xk[cur ^ 1] + xoff);  // in flight under the controller
 #endif
-    // The controller: ONE lane per workgroup (the same arithmetic on the same partial sums in the same order in every
-    // workgroup: one decision for the environment), broadcast through LDS -- all waves running the double-precision
-    // pow / sqrt / divisions redundantly cost 6 us per step (14 k ticks), a lone lane ~1
-    if (tid == 0) {
-      double sum = 0.0;
-      for (int i = 0; i < nwg; ++i) sum += red[24 + i];  // one order in every workgroup: the same double everywhere
-      const double err = sqrt(sum * inv_cells);  // diffrax rms_norm
-      const bool keep_ = err < 1.0;              // a NaN norm rejects
-      const double inv_ = (err > 0.0 && err < __builtin_inf()) ? 1.0 / err : (err == 0.0 ? __builtin_inf() : 0.0);
-      double f_ = pid_term(inv_, a.pid.k1, a.pid) * pid_term(prev_inv, a.pid.k2, a.pid) * pid_term(prev_prev_inv, a.pid.k3, a.pid);
-      f_ = fmin(a.pid.factormax, fmax(a.pid.factormin, a.pid.safety * f_));
-      if (!keep_) f_ = fmin(1.0, f_);
-      red[19] = keep_ ? 1.0 : 0.0;
-      red[20] = inv_;
-      red[21] = f_;
+    if (!one_xcd) {  // (the fenced path: sums staged behind its own barrier)
+      __syncthreads();
+      if (tid == 0) controller();
+      __syncthreads();
     }
-    __syncthreads();
     const bool keep = red[19] != 0.0;
     const double inv = red[20];
     const double f = red[21];
