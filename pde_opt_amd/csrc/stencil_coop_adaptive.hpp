@@ -165,7 +165,7 @@ __device__ __forceinline__ void xstore(T* p, T v) { __hip_atomic_store(p, v, __A
 // cells per trip of the stage loops (region_u).  Measured on the 100^2 smoothed-boundary solve (profiles/r04_adaptive_variants_ab.txt):
 // 1, 2 and 4 cells a trip, 512 or 768 threads, hoisted or fresh loop geometry all land within 16.4 - 18.4 us per trial step,
 // inside the run-to-run spread of one build (~1 us): the stage loops are bound neither by VALU issue (27 % of the step's
-// cycles, SQ_INSTS_VALU) nor by the LDS pipe (33 %, SQ_LDS_IDX_ACTIVE) but by the 16 workgroup barriers of a step and the
+// cycles, SQ_INSTS_VALU) nor by the LDS pipe (33 %, SQ_LDS_IDX_ACTIVE) but by the ~14 workgroup barriers of a step and the
 // dependent LDS -> VALU chains between them.  One cell a trip is the smallest code.
 #ifndef PDEOPT_COOP_UNROLL
 #define PDEOPT_COOP_UNROLL 1
