@@ -130,6 +130,26 @@ def test_advection_diffusion_fixed_step(dtype):
         assert abs(float(got.astype(np.float64).mean() - y0.astype(np.float64).mean())) < (1e-12 if dtype is np.float64 else 1e-6)
 
 
+@pytest.mark.parametrize("dtype,shape", [(np.float32, (96, 96)), (np.float64, (64, 64))], ids=["f32-96", "f64-64"])
+def test_sixteen_environments_in_one_launch(dtype, shape):
+    """the automatic choice for a batch of 16: 4 x 4 workgroups per environment, two environments per XCD, all in ONE launch
+    (block -> (environment, tile) map over rows of XCD slots); per-environment kappa; first, middle and last environment
+    against the oracle"""
+    nx, ny = shape
+    dom = std_domain(P, nx, ny)
+    rng = np.random.default_rng(16)
+    eq = P.CahnHilliard2DPeriodic(dom, 0.002, MU["regsol"], MOB["c1mc"])
+    y0 = np.clip(0.5 + 0.05 * rng.standard_normal((16, nx, ny)), 0.05, 0.95).astype(dtype)
+    kappas = [0.002 + 1e-5 * b for b in range(16)]
+    got, kern = _advance(eq, y0, L.INT_RK4, 2e-7, 9, 0, kappas=kappas)
+    assert kern.startswith("rk4_coop") and "4x4 workgroups" in kern, kern
+    for b in (0, 7, 8, 15):
+        ref = y0[b].astype(np.float64)
+        for i in range(9):
+            ref = O.rk4_step(lambda t, u: O.ch_rhs_fd(u, *dom.dx, kappas[b], MU["regsol"], MOB["c1mc"]), 0.0, ref, 2e-7)
+        _check(got[b], ref, y0[b].astype(np.float64), dtype, kern)
+
+
 def test_tiles_narrower_than_the_halo_wait_for_every_workgroup(monkeypatch):
     """tiles of 6 x 6 cells under an 8-cell halo: a ring reaches two tiles away, so the exchange waits for every workgroup
     of the environment instead of the 8 neighbours (PDEOPT_COOP_TILE forces the tile edge)"""
