@@ -261,7 +261,9 @@ int pdeopt_state_device_ptr(pdeopt_ctx* ctx, void** dev_ptr, int64_t* bytes);
 /* out = equation.rhs(state, t) for every environment; host_out may be NULL (compute only). */
 int pdeopt_rhs(pdeopt_ctx* ctx, double t, void* host_out);
 /* n_substeps of size dt starting at local time t0:  the body of diffeqsolve's while-loop
- * under ConstantStepSize.  Asynchronous. */
+ * under ConstantStepSize.  Asynchronous -- except on the multi-workgroup path (a few mid-sized environments, see
+ * PDEOPT_OPT_SMALL_PERSIST), which returns once its one launch has finished and reports a launch whose workgroups
+ * could not all become resident as an error instead of hanging. */
 int pdeopt_advance(pdeopt_ctx* ctx, int integrator, double t0, double dt, int64_t n_substeps);
 /* Closures outside the in-kernel family (the reference accepts any pointwise callable: cahn_hilliard.py:51-54,
  * allen_cahn.py:47-50, functions/legendre.py:56-74 prior_fn): mu_body / mob_body are C function BODIES -- one line of
